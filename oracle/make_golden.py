@@ -1,0 +1,348 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by running the REFERENCE's own Python here.
+
+TEST INFRASTRUCTURE.  Runs only in the build container (needs /root/reference);
+nothing from /root/reference is copied -- only input/output tensors are saved.
+The reference imports third-party packages that are absent here (diffusers,
+torchvision, torchaudio, librosa, wandb, soundfile, progressbar); name-only stub
+modules are injected exactly as SURVEY.md 8(c)/Appendix B describes.  What each
+fixture pins is listed in tests/golden/README.md.
+
+Usage:  python oracle/make_golden.py [loops|audio|hifigan|unet|vae|all]
+"""
+import importlib.util
+import os
+import sys
+import types
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = "/root/reference/code"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+import transformers  # noqa: E402  (must precede the stubs)
+from transformers.audio_utils import mel_filter_bank  # noqa: E402
+
+from oracle import loops as oloops  # noqa: E402
+from oracle.scheduler import OracleDDIMScheduler  # noqa: E402
+from oracle.synth import synthetic_unet, prompt_vec, chirp_waveform  # noqa: E402
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+def install_stubs():
+    from dataclasses import dataclass
+
+    @dataclass
+    class UNet2DConditionOutput:
+        sample: torch.Tensor = None
+
+    dummy = type("Dummy", (), {})
+    _stub("diffusers", DDIMScheduler=dummy, UNet2DModel=dummy, VQModel=dummy,
+          CosineDPMSolverMultistepScheduler=dummy, AudioLDMPipeline=dummy, AudioLDM2Pipeline=dummy,
+          StableDiffusionPipeline=dummy, StableAudioPipeline=dummy)
+    _stub("diffusers.schedulers")
+    _stub("diffusers.schedulers.scheduling_dpmsolver_sde", BrownianTreeNoiseSampler=dummy)
+    _stub("diffusers.models")
+    _stub("diffusers.models.unets")
+    _stub("diffusers.models.unets.unet_2d_condition", UNet2DConditionOutput=UNet2DConditionOutput)
+    _stub("diffusers.models.embeddings", get_1d_rotary_pos_embed=None)
+    tvf = types.SimpleNamespace(gaussian_blur=lambda x, kernel_size, sigma: oloops.gaussian_blur(x, kernel_size, sigma))
+    tvt = _stub("torchvision.transforms", functional=tvf)
+    _stub("torchvision", transforms=tvt)
+    _stub("wandb")
+    _stub("torchaudio")
+    _stub("soundfile")
+    _stub("progressbar")
+    return UNet2DConditionOutput
+
+
+# --------------------------------------------------------------------------- loops
+def gen_loops():
+    UOut = install_stubs()
+    sys.path.insert(0, REF)
+    import models as ref_models  # reference code/models.py
+    from ddm_inversion import inversion_utils as ref_inv
+    from ddm_inversion import ddim_inversion as ref_ddim
+
+    class FakeRef(ref_models.PipelineWrapper):
+        """Reference PipelineWrapper + AudioLDM2Wrapper's variance helpers, synthetic eps-model."""
+        get_variance = ref_models.AudioLDM2Wrapper.get_variance
+        get_alpha_prod_t_prev = ref_models.AudioLDM2Wrapper.get_alpha_prod_t_prev
+
+        def __init__(self, sched, T):
+            super().__init__(model_id="fake", device=torch.device("cpu"))
+            sched.set_timesteps(T)
+            unet = SimpleNamespace(config=SimpleNamespace(in_channels=8))
+            self.model = SimpleNamespace(scheduler=sched, unet=unet)
+
+        def encode_text(self, prompts, **kw):
+            return None, torch.stack([prompt_vec(p) for p in prompts]), None
+
+        def unet_forward(self, sample, timestep, encoder_hidden_states=None, class_labels=None,
+                         encoder_attention_mask=None, **kw):
+            return UOut(sample=synthetic_unet(sample, timestep, class_labels)), None, None
+
+    def run_case(name, T, tstart, src, tgt, cfg_src, cfg_tar, pred="epsilon", alpha_one=False,
+                 seed=0, shape=(8, 16, 16), cutoff=None, fix_alpha=0.1):
+        sched = OracleDDIMScheduler(prediction_type=pred, set_alpha_to_one=alpha_one)
+        m = FakeRef(sched, T)
+        g = torch.Generator().manual_seed(100 + seed)
+        x0 = torch.randn((1, *shape), generator=g) * 0.7
+        torch.manual_seed(seed)
+        with torch.no_grad():
+            _, zs, wts, _ = ref_inv.inversion_forward_process(
+                m, x0, etas=1.0, prompts=list(src), cfg_scales=list(cfg_src), num_inference_steps=T,
+                numerical_fix=True, cutoff_points=cutoff)
+            ts = torch.tensor([tstart] * len(tgt), dtype=torch.int)
+            w0, _ = ref_inv.inversion_reverse_process(
+                m, xT=wts, tstart=ts, fix_alpha=fix_alpha, etas=1.0, prompts=list(tgt), neg_prompts=[""],
+                cfg_scales=list(cfg_tar), zs=zs[:int(tstart)], cutoff_points=cutoff)
+        # the independent x_t draws are re-derivable from (x0, seed); stored for convenience
+        torch.manual_seed(seed)
+        xts_init = m.sample_xts_from_x0(x0, num_inference_steps=T)
+        np.savez_compressed(os.path.join(OUT, f"loop_{name}.npz"),
+                            x0=x0.numpy(), xts_init=xts_init.numpy(), zs=zs.numpy(), xts=wts.numpy(),
+                            w_edit=w0.numpy(), T=T, tstart=tstart, seed=seed,
+                            cfg_src=np.array(cfg_src, dtype=np.float64), cfg_tar=np.array(cfg_tar, dtype=np.float64),
+                            src=np.array(list(src)), tgt=np.array(list(tgt)), pred=pred, alpha_one=alpha_one,
+                            fix_alpha=fix_alpha,
+                            alphas_cumprod=sched.alphas_cumprod.numpy(), timesteps=sched.timesteps.numpy())
+        print("loop", name, "zs", tuple(zs.shape), "finite w_edit:", bool(torch.isfinite(w0).all()))
+
+    run_case("ddpm_T20", 20, 10, ["a dog barking"], ["a cat meowing"], [3.0], [12.0])
+    run_case("ddpm_T20_emptysrc", 20, 12, [""], ["a cat meowing"], [3.0], [12.0], seed=1)
+    run_case("ddpm_T10_vpred", 10, 6, ["rain"], ["jazz"], [3.5], [9.0], pred="v_prediction", seed=2)
+    run_case("ddpm_T8_alphaone", 8, 5, ["rain"], ["jazz"], [3.0], [12.0], alpha_one=True, seed=3)
+    run_case("ddpm_T12_two_prompts", 12, 7, ["rain", "wind"], ["jazz", "rock"], [3.0], [12.0, 8.0],
+             seed=4, shape=(8, 32, 16))
+
+    # --- DDIM baseline (deterministic) ---
+    _stub("utils")  # ddim_inversion imports utils.get_text_embeddings; supply a minimal one
+    sched = OracleDDIMScheduler()
+    T = 10
+    m = FakeRef(sched, T)
+
+    def get_text_embeddings(tp, tn, model):
+        a = SimpleNamespace(embedding_hidden_states=None, boolean_prompt_mask=None,
+                            embedding_class_lables=model.encode_text(tp)[1])
+        b = SimpleNamespace(embedding_hidden_states=None, boolean_prompt_mask=None,
+                            embedding_class_lables=model.encode_text(tn)[1])
+        return a.embedding_class_lables, a, b
+    ref_ddim.get_text_embeddings = get_text_embeddings
+    g = torch.Generator().manual_seed(77)
+    w0 = torch.randn((1, 8, 16, 16), generator=g) * 0.7
+    skip = 3
+    wT = ref_ddim.ddim_inversion(m, w0, ["a dog barking"], 3.0, num_inference_steps=T, skip=skip)
+    w_rec = ref_ddim.text2image_ldm_stable(m, ["a cat meowing"], T, 12.0, wT, skip=skip)
+    np.savez_compressed(os.path.join(OUT, "loop_ddim_T10.npz"), w0=w0.numpy(), wT=wT.numpy(),
+                        w_edit=w_rec.numpy(), T=T, skip=skip, cfg_src=3.0, cfg_tar=12.0,
+                        src=np.array(["a dog barking"]), tgt=np.array(["a cat meowing"]))
+    print("ddim", float(wT.abs().mean()), float(w_rec.abs().mean()))
+
+    # --- bare step-math vectors (bit-exact targets for kernel K1) ---
+    sched = OracleDDIMScheduler()
+    T = 200
+    m = FakeRef(sched, T)
+    g = torch.Generator().manual_seed(5)
+    rec = {}
+    for i, t in enumerate([996, 501, 6, 1]):
+        tt = torch.tensor(t)
+        xt, xtm1, eps, z = (torch.randn((1, 8, 16, 16), generator=g) for _ in range(4))
+        zz, xfix, _ = m.get_zs_from_xts(xt, xtm1, eps, tt, eta=1.0, numerical_fix=True)
+        prev = m.reverse_step_with_custom_noise(eps, tt, xt, variance_noise=z, eta=1.0)
+        rec.update({f"t{i}": t, f"xt{i}": xt.numpy(), f"xtm1{i}": xtm1.numpy(), f"eps{i}": eps.numpy(),
+                    f"z_in{i}": z.numpy(), f"z{i}": zz.numpy(), f"xfix{i}": xfix.numpy(), f"prev{i}": prev.numpy()})
+    np.savez_compressed(os.path.join(OUT, "step_math_T200.npz"), n=4, **rec)
+    print("step math ok")
+
+
+# --------------------------------------------------------------------------- audio
+def _load_by_path(modname, path):
+    spec = importlib.util.spec_from_file_location(modname, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[modname] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def gen_audio():
+    install_stubs()
+
+    def slaney_mel(sr, n_fft, n_mels, fmin, fmax):
+        # librosa 0.9.2 filters.mel defaults: htk=False (Slaney scale), norm="slaney".
+        fb = mel_filter_bank(num_frequency_bins=n_fft // 2 + 1, num_mel_filters=n_mels, min_frequency=fmin,
+                             max_frequency=fmax, sampling_rate=sr, norm="slaney", mel_scale="slaney")
+        return fb.T.astype(np.float32)
+
+    _stub("librosa")
+    _stub("librosa.util", pad_center=lambda w, size=None, **kw: w, tiny=lambda x: np.finfo(np.float32).tiny,
+          normalize=lambda x, norm=None: x)
+    _stub("librosa.filters", mel=slaney_mel)
+    pkg = types.ModuleType("audioldm")
+    pkg.__path__ = [os.path.join(REF, "audioldm")]
+    sys.modules["audioldm"] = pkg
+    sub = types.ModuleType("audioldm.audio")
+    sub.__path__ = [os.path.join(REF, "audioldm", "audio")]
+    sys.modules["audioldm.audio"] = sub
+    _load_by_path("audioldm.audio.audio_processing", os.path.join(REF, "audioldm/audio/audio_processing.py"))
+    stft = _load_by_path("audioldm.audio.stft", os.path.join(REF, "audioldm/audio/stft.py"))
+    fn = stft.TacotronSTFT(1024, 160, 1024, 64, 16000, 0, 8000)
+    n = 160 * 64  # 64 frames' worth: small fixture, same code path
+    wav = chirp_waveform(n=n, seed=1234)
+    wav = wav - wav.mean()
+    wav = wav / (wav.abs().max() + 1e-8) * 0.5
+    mel, logmag, energy = fn.mel_spectrogram(wav[None])
+    mag, _ = fn.stft_fn.transform(wav[None])
+    np.savez_compressed(os.path.join(OUT, "stft_mel_64f.npz"), wav=wav.numpy(), mel=mel.numpy(), mag=mag.numpy(),
+                        energy=energy.numpy(), mel_basis=fn.mel_basis.numpy(),
+                        basis_rows=fn.stft_fn.forward_basis[[0, 1, 7, 512, 513, 514, 900, 1025], 0, :].numpy(),
+                        basis_row_ids=np.array([0, 1, 7, 512, 513, 514, 900, 1025]))
+    print("audio", tuple(mel.shape), float(mel.mean()))
+
+
+# --------------------------------------------------------------------------- hifigan
+def gen_hifigan():
+    from transformers import SpeechT5HifiGan, SpeechT5HifiGanConfig
+    cfg = SpeechT5HifiGanConfig(model_in_dim=64, sampling_rate=16000, upsample_initial_channel=64,
+                                upsample_rates=[5, 4, 2, 2, 2], upsample_kernel_sizes=[16, 16, 8, 4, 4],
+                                resblock_kernel_sizes=[3, 7, 11], resblock_dilation_sizes=[[1, 3, 5]] * 3,
+                                normalize_before=False)
+    torch.manual_seed(0)
+    voc = SpeechT5HifiGan(cfg).eval()
+    sd = {}
+    g = torch.Generator().manual_seed(11)
+    for k, v in voc.state_dict().items():
+        if v.dtype.is_floating_point and "mean" not in k and "scale" not in k:
+            v.copy_(torch.randn(v.shape, generator=g) * (0.08 if "weight" in k else 0.02))
+        sd[k] = v.numpy().copy()
+    mel = torch.randn((2, 24, 64), generator=g) * 2.0 - 4.0
+    with torch.no_grad():
+        wav = voc(mel)
+    np.savez_compressed(os.path.join(OUT, "hifigan_c64.npz"), mel=mel.numpy(), wav=wav.numpy(),
+                        **{"sd." + k: v for k, v in sd.items()})
+    print("hifigan", tuple(wav.shape), float(wav.abs().mean()))
+    # cross-check against the in-tree twin with the same weights (two independent implementations)
+    install_stubs()
+    pkg = types.ModuleType("audioldm_h")
+    sys.modules["audioldm_h"] = pkg
+    twin = _load_by_path("audioldm_h.models", os.path.join(REF, "audioldm/hifigan/models.py"))
+    h = SimpleNamespace(resblock_kernel_sizes=[3, 7, 11], upsample_rates=[5, 4, 2, 2, 2],
+                        upsample_kernel_sizes=[16, 16, 8, 4, 4], upsample_initial_channel=64,
+                        resblock_dilation_sizes=[[1, 3, 5]] * 3, num_mels=64)
+    gen = twin.Generator(h).eval()
+    gen.remove_weight_norm()
+    tsd = {}
+    for k, v in sd.items():
+        k2 = k.replace("upsampler.", "ups.")
+        if k2 in gen.state_dict():
+            tsd[k2] = torch.from_numpy(v)
+    gen.load_state_dict(tsd, strict=True)
+    with torch.no_grad():
+        wav2 = gen(mel.transpose(1, 2)).squeeze(1)
+    print("hifigan twin max|diff| =", float((wav2 - wav).abs().max()))
+
+
+# --------------------------------------------------------------------------- unet / vae twins
+def _load_twin_pkg():
+    install_stubs()
+    pkg = types.ModuleType("audioldm")
+    pkg.__path__ = [os.path.join(REF, "audioldm")]
+    sys.modules["audioldm"] = pkg
+    _load_by_path("audioldm.utils", os.path.join(REF, "audioldm/utils.py"))
+    ld = types.ModuleType("audioldm.latent_diffusion")
+    ld.__path__ = [os.path.join(REF, "audioldm/latent_diffusion")]
+    sys.modules["audioldm.latent_diffusion"] = ld
+    _load_by_path("audioldm.latent_diffusion.util", os.path.join(REF, "audioldm/latent_diffusion/util.py"))
+    _load_by_path("audioldm.latent_diffusion.attention", os.path.join(REF, "audioldm/latent_diffusion/attention.py"))
+    return _load_by_path("audioldm.latent_diffusion.openaimodel",
+                         os.path.join(REF, "audioldm/latent_diffusion/openaimodel.py"))
+
+
+def gen_unet():
+    oai = _load_twin_pkg()
+    torch.manual_seed(0)
+    cfg = dict(image_size=64, extra_film_condition_dim=24, extra_film_use_concat=True, in_channels=8,
+               out_channels=8, model_channels=32, attention_resolutions=[2], num_res_blocks=2,
+               channel_mult=[1, 2], num_head_channels=16, use_spatial_transformer=True)
+    net = oai.UNetModel(**cfg).eval()
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for n_, p in net.named_parameters():
+            if p.dim() > 1:
+                p.copy_(torch.randn(p.shape, generator=g) * (1.5 / (p[0].numel() ** 0.5)))
+            elif "norm" in n_ or n_.endswith("0.weight"):
+                p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g))
+            else:
+                p.copy_(0.1 * torch.randn(p.shape, generator=g))
+    x = torch.randn((2, 8, 32, 8), generator=g)
+    y = torch.randn((2, 24), generator=g)
+    t = torch.tensor([501, 37])
+    with torch.no_grad():
+        out = net(x, t, y=y)
+    sd = {k: v.numpy() for k, v in net.state_dict().items()}
+    np.savez_compressed(os.path.join(OUT, "unet_twin_c32.npz"), x=x.numpy(), y=y.numpy(), t=t.numpy(),
+                        out=out.numpy(), **{"sd." + k: v for k, v in sd.items()})
+    print("unet twin", tuple(out.shape), float(out.abs().mean()), "params", sum(p.numel() for p in net.parameters()))
+
+
+def gen_vae():
+    _load_twin_pkg()
+    va = types.ModuleType("audioldm.variational_autoencoder")
+    va.__path__ = [os.path.join(REF, "audioldm/variational_autoencoder")]
+    sys.modules["audioldm.variational_autoencoder"] = va
+    _load_by_path("audioldm.variational_autoencoder.distributions",
+                  os.path.join(REF, "audioldm/variational_autoencoder/distributions.py"))
+    mods = _load_by_path("audioldm.variational_autoencoder.modules",
+                         os.path.join(REF, "audioldm/variational_autoencoder/modules.py"))
+    dd = dict(double_z=True, z_channels=8, resolution=256, in_channels=1, out_ch=1, ch=32, ch_mult=[1, 1, 2],
+              num_res_blocks=2, attn_resolutions=[], dropout=0.0)
+    torch.manual_seed(0)
+    enc = mods.Encoder(**dd).eval()
+    dec = mods.Decoder(**dd).eval()
+    quant = torch.nn.Conv2d(16, 16, 1)
+    post = torch.nn.Conv2d(8, 8, 1)
+    g = torch.Generator().manual_seed(9)
+    with torch.no_grad():
+        for mod in (enc, dec, quant, post):
+            for n_, p in mod.named_parameters():
+                if p.dim() > 1:
+                    p.copy_(torch.randn(p.shape, generator=g) * (1.2 / (p[0].numel() ** 0.5)))
+                elif "norm" in n_ and n_.endswith("weight"):
+                    p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g))
+                else:
+                    p.copy_(0.1 * torch.randn(p.shape, generator=g))
+        mel = torch.randn((1, 1, 64, 32), generator=g)
+        moments = quant(enc(mel))
+        mean = moments[:, :8]
+        recon = dec(post(mean))
+    rec = {}
+    for pre, mod in (("encoder.", enc), ("decoder.", dec), ("quant_conv.", quant), ("post_quant_conv.", post)):
+        for k, v in mod.state_dict().items():
+            rec["sd." + pre + k] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, "vae_twin_c32.npz"), mel=mel.numpy(), mean=mean.numpy(),
+                        recon=recon.numpy(), **rec)
+    print("vae twin", tuple(mean.shape), tuple(recon.shape), float(recon.abs().mean()))
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    # each generator runs in a fresh interpreter when "all" (the stubs of one break another)
+    if what == "all":
+        import subprocess
+        for w in ("loops", "audio", "hifigan", "unet", "vae"):
+            subprocess.check_call([sys.executable, os.path.abspath(__file__), w])
+    else:
+        {"loops": gen_loops, "audio": gen_audio, "hifigan": gen_hifigan, "unet": gen_unet, "vae": gen_vae}[what]()

@@ -1,0 +1,172 @@
+"""Pin the CPU oracle (oracle/) to vectors produced by the reference's own code
+(oracle/make_golden.py, run in the build container).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import audio as oaudio
+from oracle import hifigan as ohifi
+from oracle import loops as oloops
+from oracle import unet as ounet
+from oracle import vae as ovae
+from oracle.scheduler import OracleDDIMScheduler
+from oracle.synth import prompt_vec, synthetic_unet
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _wrapper(T, pred="epsilon", alpha_one=False):
+    s = OracleDDIMScheduler(prediction_type=pred, set_alpha_to_one=bool(alpha_one))
+    s.set_timesteps(T)
+    return oloops.OracleWrapper(s, synthetic_unet)
+
+
+def _cond(prompts):
+    return torch.stack([prompt_vec(str(p)) for p in prompts])
+
+
+@pytest.mark.parametrize("name", ["ddpm_T20", "ddpm_T20_emptysrc", "ddpm_T10_vpred", "ddpm_T8_alphaone",
+                                  "ddpm_T12_two_prompts"])
+def test_ddpm_loops_match_reference(name):
+    g = np.load(os.path.join(G, f"loop_{name}.npz"))
+    T, tstart = int(g["T"]), int(g["tstart"])
+    w = _wrapper(T, str(g["pred"]), bool(g["alpha_one"]))
+    x0 = torch.from_numpy(g["x0"])
+    src, tgt = list(g["src"]), list(g["tgt"])
+    gen = torch.Generator().manual_seed(int(g["seed"]))
+    xts0 = w.sample_xts_from_x0(x0, T, generator=gen)
+    assert torch.equal(xts0, torch.from_numpy(g["xts_init"]))          # RNG draw order (models.py:79-81)
+    empty = (len(src) == 1 and src[0] == "")
+    _, zs, xts = oloops.invert(w, x0, _cond(src), _cond([""]), list(g["cfg_src"]), T, eta=1.0,
+                               src_is_empty=empty, n_prompts=len(src), xts=xts0.clone(),
+                               prompt_empty=[p == "" for p in src])
+    ref_zs, ref_xts = torch.from_numpy(g["zs"]), torch.from_numpy(g["xts"])
+    # idx 0 may hold inf/nan for set_alpha_to_one: compare with equal_nan
+    np.testing.assert_array_equal(zs.numpy(), ref_zs.numpy())
+    np.testing.assert_array_equal(xts.numpy(), ref_xts.numpy())
+    ts = torch.tensor([tstart] * len(tgt), dtype=torch.int)
+    w_edit = oloops.edit(w, xts, ts, _cond(tgt), _cond([""]), list(g["cfg_tar"]), zs[:tstart], eta=1.0,
+                         n_prompts=len(tgt), fix_alpha=float(g["fix_alpha"]))
+    np.testing.assert_array_equal(w_edit.numpy(), g["w_edit"])
+
+
+def test_trajectory_replay_invariant():
+    """SURVEY section 4 known-answer: replaying zs under the SAME prompt/cfg retraces xts bit-exactly."""
+    g = np.load(os.path.join(G, "loop_ddpm_T20.npz"))
+    T = int(g["T"])
+    w = _wrapper(T)
+    xts, zs = torch.from_numpy(g["xts"]), torch.from_numpy(g["zs"])
+    src = list(g["src"])
+    for tstart in (T - 1, 10):
+        ts = torch.tensor([tstart], dtype=torch.int)
+        xt = xts[tstart].unsqueeze(0)
+        cfg, _ = oloops.segment_scales(1, xt.shape[1:], list(g["cfg_src"]), None, xt.dtype)
+        s = w.model.scheduler
+        tl = s.timesteps[-tstart:]
+        for it, t in enumerate(tl):
+            idx = tstart - it - 1
+            eps = oloops.cfg_combine(w.unet(xt, t, _cond([""])), w.unet(xt, t, _cond(src)), cfg)
+            xt = w.reverse_step_with_custom_noise(eps, t, xt, variance_noise=zs[idx].unsqueeze(0), eta=1.0)
+            if idx >= 1:
+                assert torch.equal(xt[0], xts[idx]), (tstart, idx)
+
+
+def test_ddim_baseline_matches_reference():
+    g = np.load(os.path.join(G, "loop_ddim_T10.npz"))
+    T, skip = int(g["T"]), int(g["skip"])
+    w = _wrapper(T)
+    w0 = torch.from_numpy(g["w0"])
+    wT = oloops.ddim_invert(w, w0, _cond(g["src"]), _cond([""]), float(g["cfg_src"]), T, skip)
+    np.testing.assert_array_equal(wT.numpy(), g["wT"])
+    we = oloops.ddim_sample(w, wT, _cond(g["tgt"]), _cond([""]), float(g["cfg_tar"]), skip=skip)
+    np.testing.assert_array_equal(we.numpy(), g["w_edit"])
+
+
+def test_step_math_vectors():
+    g = np.load(os.path.join(G, "step_math_T200.npz"))
+    w = _wrapper(200)
+    for i in range(int(g["n"])):
+        t = torch.tensor(int(g[f"t{i}"]))
+        z, xfix = w.get_zs_from_xts(torch.from_numpy(g[f"xt{i}"]), torch.from_numpy(g[f"xtm1{i}"]),
+                                    torch.from_numpy(g[f"eps{i}"]), t, eta=1.0)
+        np.testing.assert_array_equal(z.numpy(), g[f"z{i}"])
+        np.testing.assert_array_equal(xfix.numpy(), g[f"xfix{i}"])
+        prev = w.reverse_step_with_custom_noise(torch.from_numpy(g[f"eps{i}"]), t, torch.from_numpy(g[f"xt{i}"]),
+                                                variance_noise=torch.from_numpy(g[f"z_in{i}"]), eta=1.0)
+        np.testing.assert_array_equal(prev.numpy(), g[f"prev{i}"])
+
+
+def test_scheduler_tables():
+    s = OracleDDIMScheduler()
+    s.set_timesteps(200)
+    assert s.timesteps[0] == 996 and s.timesteps[-1] == 1 and len(s.timesteps) == 200
+    g = np.load(os.path.join(G, "loop_ddpm_T20.npz"))
+    s.set_timesteps(20)
+    np.testing.assert_array_equal(s.timesteps.numpy(), g["timesteps"])
+    np.testing.assert_array_equal(s.alphas_cumprod.numpy(), g["alphas_cumprod"])
+
+
+def test_stft_mel_matches_reference():
+    g = np.load(os.path.join(G, "stft_mel_64f.npz"))
+    basis = oaudio.stft_basis()
+    np.testing.assert_allclose(basis[g["basis_row_ids"]], g["basis_rows"], atol=2e-7, rtol=0)
+    melb = oaudio.mel_basis()
+    np.testing.assert_allclose(melb, g["mel_basis"], atol=1e-7, rtol=1e-5)
+    wav = torch.from_numpy(g["wav"])[None]
+    mag = oaudio.stft_magnitude(wav, basis)
+    np.testing.assert_allclose(mag.numpy(), g["mag"], atol=2e-4, rtol=1e-4)
+    mel, _, energy = oaudio.mel_spectrogram(wav, basis, melb)
+    np.testing.assert_allclose(mel.numpy(), g["mel"], atol=1e-3, rtol=1e-4)
+    np.testing.assert_allclose(energy.numpy(), g["energy"], atol=1e-3, rtol=1e-4)
+
+
+def test_waveform_preparation_rules():
+    w = np.sin(np.arange(1000) / 7.0).astype(np.float32) + 0.3
+    out = oaudio.prepare_waveform(w, 1600)
+    assert out.shape == (1600,) and out.dtype == np.float32
+    assert abs(np.abs(out).max() - 0.5) < 1e-6            # second normalisation (tools.py:61-62)
+    assert np.all(out[1000:] == 0)
+    out2 = oaudio.prepare_waveform(w, 640)
+    assert out2.shape == (640,)
+    fb = oaudio.pad_spec(torch.ones(7, 65), 10)
+    assert fb.shape == (10, 64) and fb[7:].abs().sum() == 0   # even-bin trim + zero pad (tools.py:18-31)
+
+
+def test_hifigan_matches_transformers_class():
+    g = np.load(os.path.join(G, "hifigan_c64.npz"))
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd.")}
+    cfg = dict(upsample_rates=[5, 4, 2, 2, 2], upsample_kernel_sizes=[16, 16, 8, 4, 4],
+               resblock_kernel_sizes=[3, 7, 11], resblock_dilation_sizes=[[1, 3, 5]] * 3)
+    wav = ohifi.hifigan_forward(cfg, sd, torch.from_numpy(g["mel"]))
+    assert wav.shape == g["wav"].shape
+    np.testing.assert_allclose(wav.numpy(), g["wav"], atol=1e-6, rtol=1e-5)
+
+
+def test_unet_matches_twin():
+    g = np.load(os.path.join(G, "unet_twin_c32.npz"))
+    tsd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd.")}
+    sd = ounet.twin_to_diffusers(tsd, [1, 2], 2, {1})
+    assert len(sd) == len(tsd)
+    cfg = dict(block_out_channels=[32, 64], layers_per_block=2,
+               down_block_types=["DownBlock2D", "CrossAttnDownBlock2D"],
+               up_block_types=["CrossAttnUpBlock2D", "UpBlock2D"], attention_head_dim=[2, 4],
+               cross_attention_dim=[32, 64], class_embed_type="simple_projection",
+               class_embeddings_concat=True, norm_num_groups=32)
+    out, h_space, skips = ounet.unet_forward(cfg, sd, torch.from_numpy(g["x"]), torch.from_numpy(g["t"]),
+                                             class_labels=torch.from_numpy(g["y"]))
+    np.testing.assert_allclose(out.numpy(), g["out"], atol=2e-5, rtol=1e-5)
+    assert h_space.shape == (2, 64, 16, 4) and sorted(skips) == [0, 1]
+
+
+def test_vae_matches_twin():
+    g = np.load(os.path.join(G, "vae_twin_c32.npz"))
+    tsd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd.")}
+    sd = ovae.twin_to_diffusers(tsd, 3, 2)
+    assert len(sd) == len(tsd)
+    cfg = dict(block_out_channels=[32, 32, 64], layers_per_block=2, latent_channels=8, scaling_factor=1.0)
+    mom = ovae.encode_moments(cfg, sd, torch.from_numpy(g["mel"]))
+    np.testing.assert_allclose(mom[:, :8].numpy(), g["mean"], atol=5e-5, rtol=1e-4)
+    rec = ovae.decode(cfg, sd, torch.from_numpy(g["mean"]))
+    np.testing.assert_allclose(rec.numpy(), g["recon"], atol=1e-4, rtol=1e-4)

@@ -1,0 +1,171 @@
+// norm.hip -- GroupNorm (+SiLU) and LayerNorm on channels-last activations.
+//
+// GroupNorm over [B, HW, C] with G groups of C/G contiguous channels.  HBM-bound: the activation
+// is read twice and written once.  Two launches:
+//   gn_stats : grid (chunks, B); every block streams a slab of rows fully coalesced (float4 per
+//              lane) and emits per-group partial (sum, sumsq) -- deterministic tree, no atomics;
+//   gn_apply : every block re-reduces the <= few-hundred partials of its batch item in fp64,
+//              then normalises + affine (+SiLU) its slab.
+// LayerNorm: one 64-lane wavefront per token, two-pass variance, DPP/shuffle reductions.
+#include "aed_common.h"
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, float* __restrict__ part,
+                                                        int HW, int C, int G, int ldx, int rpc, int nchunks) {
+    __shared__ float sh[256][2];
+    __shared__ float gacc[64][2];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int row0 = chunk * rpc;
+    const int row1 = min(HW, row0 + rpc);
+    const int Q = C >> 2;
+    const int cpg4 = (C / G) >> 2;
+    if (tid < G) { gacc[tid][0] = 0.f; gacc[tid][1] = 0.f; }
+    __syncthreads();
+    for (int cbase = 0; cbase < Q; cbase += 256) {
+        const int ncol = min(256, Q - cbase);
+        const int rpi = 256 / ncol;
+        const int col = tid % ncol, rsub = tid / ncol;
+        float s = 0.f, ss = 0.f;
+        if (rsub < rpi) {
+            for (int r = row0 + rsub; r < row1; r += rpi) {
+                const float4 v = *reinterpret_cast<const float4*>(x + ((size_t)b * HW + r) * ldx + 4 * (cbase + col));
+                s += (v.x + v.y) + (v.z + v.w);
+                ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+            }
+        }
+        sh[tid][0] = s;
+        sh[tid][1] = ss;
+        __syncthreads();
+        if (tid < G) {
+            int c_lo = max(tid * cpg4, cbase), c_hi = min((tid + 1) * cpg4, cbase + ncol);
+            float a0 = 0.f, a1 = 0.f;
+            for (int rs = 0; rs < rpi; ++rs)
+                for (int c = c_lo; c < c_hi; ++c) {
+                    a0 += sh[rs * ncol + (c - cbase)][0];
+                    a1 += sh[rs * ncol + (c - cbase)][1];
+                }
+            gacc[tid][0] += a0;
+            gacc[tid][1] += a1;
+        }
+        __syncthreads();
+    }
+    if (tid < G) {
+        float* dst = part + (((size_t)b * nchunks + chunk) * G + tid) * 2;
+        dst[0] = gacc[tid][0];
+        dst[1] = gacc[tid][1];
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ part,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ y,
+                                                        int HW, int C, int G, int ldx, int ldy, int rpc, int nchunks,
+                                                        float eps, int act) {
+    __shared__ float mean_s[64], rstd_s[64];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    if (tid < G) {
+        double s = 0.0, ss = 0.0;
+        const float* src = part + ((size_t)b * nchunks * G + tid) * 2;
+        for (int c = 0; c < nchunks; ++c) {
+            s += (double)src[(size_t)c * G * 2];
+            ss += (double)src[(size_t)c * G * 2 + 1];
+        }
+        const double n = (double)HW * (double)(C / G);
+        const double mean = s / n;
+        double var = ss / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        mean_s[tid] = (float)mean;
+        rstd_s[tid] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    const int row0 = chunk * rpc;
+    const int row1 = min(HW, row0 + rpc);
+    const int Q = C >> 2;
+    const int cpg4 = (C / G) >> 2;
+    const int total = (row1 - row0) * Q;
+    for (int e = tid; e < total; e += 256) {
+        const int r = e / Q;
+        const int c4 = e - r * Q;
+        const int g = c4 / cpg4;
+        const size_t row = (size_t)b * HW + row0 + r;
+        float4 v = *reinterpret_cast<const float4*>(x + row * ldx + 4 * c4);
+        const float4 ga = *reinterpret_cast<const float4*>(gamma + 4 * c4);
+        const float4 be = *reinterpret_cast<const float4*>(beta + 4 * c4);
+        const float m = mean_s[g], rs = rstd_s[g];
+        v.x = (v.x - m) * rs * ga.x + be.x;
+        v.y = (v.y - m) * rs * ga.y + be.y;
+        v.z = (v.z - m) * rs * ga.z + be.z;
+        v.w = (v.w - m) * rs * ga.w + be.w;
+        if (act == AED_ACT_SILU) {
+            v.x = v.x / (1.0f + expf(-v.x));
+            v.y = v.y / (1.0f + expf(-v.y));
+            v.z = v.z / (1.0f + expf(-v.z));
+            v.w = v.w / (1.0f + expf(-v.w));
+        }
+        *reinterpret_cast<float4*>(y + row * ldy + 4 * c4) = v;
+    }
+}
+
+// slots: p0=x p1=partials ; i0=B i1=HW i2=C i3=G i4=ldx i5=rows_per_chunk i6=nchunks
+int launch_gn_stats(const aed_op* op, hipStream_t s) {
+    const int32_t* i = op->i;
+    AED_REQUIRE(op->p[0] && op->p[1], "gn_stats: null pointer");
+    AED_REQUIRE(i[3] <= 64 && i[2] % (4 * i[3]) == 0, "gn_stats: C=%d must be a multiple of 4*G (G=%d<=64)", i[2], i[3]);
+    AED_REQUIRE(i[4] % 4 == 0, "gn_stats: ldx %% 4");
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(i[6], i[0]), dim3(256), 0, s, (const float*)op->p[0], (float*)op->p[1],
+                       i[1], i[2], i[3], i[4], i[5], i[6]);
+    AED_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// slots: p0=x p1=partials p2=gamma p3=beta p4=y ; i0..i6 as gn_stats, i7=act, i8=ldy ; f0=eps
+int launch_gn_apply(const aed_op* op, hipStream_t s) {
+    const int32_t* i = op->i;
+    AED_REQUIRE(op->p[0] && op->p[1] && op->p[2] && op->p[3] && op->p[4], "gn_apply: null pointer");
+    AED_REQUIRE(i[3] <= 64 && i[2] % (4 * i[3]) == 0, "gn_apply: C=%d G=%d", i[2], i[3]);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(i[6], i[0]), dim3(256), 0, s, (const float*)op->p[0],
+                       (const float*)op->p[1], (const float*)op->p[2], (const float*)op->p[3], (float*)op->p[4], i[1],
+                       i[2], i[3], i[4], i[8], i[5], i[6], op->f[0], i[7]);
+    AED_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float* __restrict__ y,
+                                                         int M, int C, int ldx, int ldy, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + (size_t)row * ldx;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += xr[c];
+    const float mean = wave_sum(s) / (float)C;
+    float ss = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float d = xr[c] - mean;
+        ss += d * d;
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)C + eps);
+    float* yr = y + (size_t)row * ldy;
+    for (int c = lane; c < C; c += 64) yr[c] = (xr[c] - mean) * rstd * gamma[c] + beta[c];
+}
+
+// slots: p0=x p1=gamma p2=beta p3=y ; i0=M i1=C i2=ldx i3=ldy ; f0=eps
+int launch_layernorm(const aed_op* op, hipStream_t s) {
+    const int32_t* i = op->i;
+    AED_REQUIRE(op->p[0] && op->p[1] && op->p[2] && op->p[3], "layernorm: null pointer");
+    hipLaunchKernelGGL(layernorm_kernel, dim3(aed_cdiv(i[0], 4)), dim3(256), 0, s, (const float*)op->p[0],
+                       (const float*)op->p[1], (const float*)op->p[2], (float*)op->p[3], i[0], i[1], i[2], i[3],
+                       op->f[0]);
+    AED_CHECK_HIP(hipGetLastError());
+    return 0;
+}

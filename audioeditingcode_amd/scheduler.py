@@ -1,0 +1,168 @@
+"""DDIM scheduler state the reference reads through `model.model.scheduler`.
+
+The reference takes this object from diffusers (`DDIMScheduler.from_pretrained`,
+/root/reference/code/models.py:481,:567) and only ever touches: `.timesteps`, `.alphas_cumprod`,
+`.final_alpha_cumprod`, `.num_inference_steps`, `.config.{num_train_timesteps,prediction_type}`,
+`.scale_model_input`, `.init_noise_sigma`, `.set_timesteps`, `.step`, `._get_variance`,
+`.add_noise`.  This is that duck type, host-side, fp32 tables.
+
+`step_coefficients` evaluates the per-step scalars of get_zs_from_xts /
+reverse_step_with_custom_noise (models.py:91-113, :124-150) with the reference's own fp32
+0-dim-tensor expression order, so the device kernel (csrc/elementwise.hip, K1) is bit-exact.
+"""
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from ._lib import COEF_STRIDE
+
+
+class DDIMScheduler:
+    def __init__(self, num_train_timesteps=1000, beta_start=0.0015, beta_end=0.0195,
+                 beta_schedule="scaled_linear", set_alpha_to_one=False, steps_offset=1,
+                 prediction_type="epsilon", timestep_spacing="leading", clip_sample=False, **_ignored):
+        if beta_schedule == "scaled_linear":
+            betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        elif beta_schedule == "linear":
+            betas = torch.linspace(beta_start, beta_end, num_train_timesteps, dtype=torch.float32)
+        else:
+            raise NotImplementedError(f"beta_schedule={beta_schedule}")
+        if clip_sample:
+            raise NotImplementedError("clip_sample=True is not used by the AudioLDM/TANGO schedulers")
+        self.betas = betas
+        self.alphas = 1.0 - betas
+        self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)
+        self.final_alpha_cumprod = torch.tensor(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
+        self.init_noise_sigma = 1.0
+        self.config = SimpleNamespace(num_train_timesteps=num_train_timesteps, prediction_type=prediction_type,
+                                      steps_offset=steps_offset, timestep_spacing=timestep_spacing,
+                                      set_alpha_to_one=set_alpha_to_one, beta_start=beta_start, beta_end=beta_end,
+                                      beta_schedule=beta_schedule, clip_sample=clip_sample)
+        self.num_inference_steps = None
+        self.timesteps = torch.from_numpy(np.arange(0, num_train_timesteps)[::-1].copy().astype(np.int64))
+
+    @classmethod
+    def from_config(cls, cfg):
+        return cls(**{k: v for k, v in cfg.items() if not k.startswith("_")})
+
+    def set_timesteps(self, num_inference_steps, device=None):
+        n = self.config.num_train_timesteps
+        if num_inference_steps > n:
+            raise ValueError(f"num_inference_steps={num_inference_steps} > num_train_timesteps={n}")
+        self.num_inference_steps = num_inference_steps
+        sp = self.config.timestep_spacing
+        if sp == "leading":
+            ratio = n // num_inference_steps
+            ts = (np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.int64)
+            ts += self.config.steps_offset
+        elif sp == "trailing":
+            ts = np.round(np.arange(n, 0, -n / num_inference_steps)).astype(np.int64) - 1
+        elif sp == "linspace":
+            ts = np.linspace(0, n - 1, num_inference_steps).round()[::-1].copy().astype(np.int64)
+        else:
+            raise ValueError(f"timestep_spacing={sp}")
+        self.timesteps = torch.from_numpy(ts)
+        if device is not None:
+            self.timesteps = self.timesteps.to(device)
+
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    def _alpha_prev(self, prev_t):
+        return self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod
+
+    def _get_variance(self, timestep, prev_timestep):
+        a_t = self.alphas_cumprod[timestep]
+        a_p = self._alpha_prev(prev_timestep)
+        return ((1 - a_p) / (1 - a_t)) * (1 - a_t / a_p)
+
+    def prev_timestep(self, t):
+        return t - self.config.num_train_timesteps // self.num_inference_steps
+
+    def step(self, model_output, timestep, sample, eta=0.0, use_clipped_model_output=False, generator=None,
+             variance_noise=None, return_dict=True):
+        """diffusers-semantics DDIM step on whatever device the tensors live on (elementwise torch;
+        used by callers such as pc_drift.py, not by the native loops)."""
+        t = int(timestep)
+        pt = self.prev_timestep(t)
+        a_t = self.alphas_cumprod[t]
+        a_p = self._alpha_prev(pt)
+        b_t = 1 - a_t
+        if self.config.prediction_type == "epsilon":
+            x0 = (sample - float(b_t ** 0.5) * model_output) / float(a_t ** 0.5)
+            pe = model_output
+        else:
+            x0 = float(a_t ** 0.5) * sample - float(b_t ** 0.5) * model_output
+            pe = float(a_t ** 0.5) * model_output + float(b_t ** 0.5) * sample
+        var = self._get_variance(t, pt)
+        std = eta * var ** 0.5
+        prev = float(a_p ** 0.5) * x0 + float((1 - a_p - std ** 2) ** 0.5) * pe
+        if eta > 0:
+            if variance_noise is None:
+                variance_noise = torch.randn(model_output.shape, generator=generator).to(model_output.device)
+            prev = prev + float(std) * variance_noise
+        return SimpleNamespace(prev_sample=prev, pred_original_sample=x0)
+
+    def add_noise(self, original_samples, noise, timesteps):
+        ts = torch.as_tensor(timesteps).cpu()
+        a = (self.alphas_cumprod[ts] ** 0.5).to(original_samples.device)
+        s = ((1 - self.alphas_cumprod[ts]) ** 0.5).to(original_samples.device)
+        while a.dim() < original_samples.dim():
+            a, s = a.unsqueeze(-1), s.unsqueeze(-1)
+        return a * original_samples + s * noise
+
+
+def step_coefficients(sched, t, eta=1.0):
+    """[c0..c4] fp32 for one timestep, reference expression order (fp32 0-dim tensor arithmetic):
+    c0=(1-abar_t)**.5  c1=abar_t**.5  c2=abar_prev**.5  c3=(1-abar_prev-eta*var)**.5  c4=eta*var**.5"""
+    t = int(t)
+    abar = sched.alphas_cumprod
+    pt = sched.prev_timestep(t)
+    a_t = abar[t]
+    a_p = sched._alpha_prev(pt)
+    var = ((1 - a_p) / (1 - a_t)) * (1 - a_t / a_p)
+    c = torch.zeros(COEF_STRIDE, dtype=torch.float32)
+    c[0] = (1 - a_t) ** 0.5
+    c[1] = a_t ** 0.5
+    c[2] = a_p ** 0.5
+    c[3] = (1 - a_p - eta * var) ** 0.5
+    c[4] = eta * var ** 0.5
+    return c
+
+
+def ddim_next_coefficients(sched, t):
+    """next_step of the DDIM inversion baseline (ddim_inversion.py:10-20), same kernel form:
+    x_next = c2 * ((x - c0*eps)/c1) + c3*eps."""
+    t = int(t)
+    t_cur = min(t - sched.config.num_train_timesteps // sched.num_inference_steps, 999)
+    a_t = sched.alphas_cumprod[t_cur] if t_cur >= 0 else sched.final_alpha_cumprod
+    a_n = sched.alphas_cumprod[t]
+    c = torch.zeros(COEF_STRIDE, dtype=torch.float32)
+    c[0] = (1 - a_t) ** 0.5
+    c[1] = a_t ** 0.5
+    c[2] = a_n ** 0.5
+    c[3] = (1 - a_n) ** 0.5
+    return c
+
+
+def ddim_prev_coefficients(sched, t):
+    """scheduler.step(eta=0) of the DDIM sampling baseline (ddim_inversion.py:82)."""
+    t = int(t)
+    pt = sched.prev_timestep(t)
+    a_t = sched.alphas_cumprod[t]
+    a_p = sched._alpha_prev(pt)
+    var = ((1 - a_p) / (1 - a_t)) * (1 - a_t / a_p)
+    std = 0.0 * var ** 0.5
+    c = torch.zeros(COEF_STRIDE, dtype=torch.float32)
+    c[0] = (1 - a_t) ** 0.5
+    c[1] = a_t ** 0.5
+    c[2] = a_p ** 0.5
+    c[3] = (1 - a_p - std ** 2) ** 0.5
+    return c
+
+
+def coefficient_table(sched, timesteps, eta=1.0, kind="ddpm"):
+    fn = {"ddpm": lambda t: step_coefficients(sched, t, eta), "ddim_next": lambda t: ddim_next_coefficients(sched, t),
+          "ddim_prev": lambda t: ddim_prev_coefficients(sched, t)}[kind]
+    return torch.stack([fn(int(t)) for t in timesteps]).contiguous()

@@ -1,0 +1,254 @@
+"""Op-tape builder/executor: the host side of include/aed.h's `aed_op` records.
+
+A model forward (U-Net, VAE, vocoder, STFT) is compiled ONCE into a flat array of op records that
+reference pre-allocated device buffers; `Tape.run()` hands the array to the native executor
+(aed_tape_run), which issues every kernel from C++ on the caller's HIP stream -- no Python per
+kernel, and the whole tape can be captured in a hipGraph (`Tape.capture()` / `Tape.replay()`).
+
+Layout convention: activations are channels-last fp32 -- a [B,H,W,C] feature map IS the
+[B*H*W, C] token matrix; convolution weights are [Cout, KH, KW, Cin].
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib as L
+
+CU_COUNT = 256          # MI355X; tiling heuristics target this, overridable for tests
+
+
+class Tape:
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.ops = []
+        self.meta = []          # per-op dict(name, flops, bytes)
+        self.keep = []          # tensors referenced by raw pointer
+        self._arr = None
+        self._ws_need = 0
+        self._ws_ops = []
+        self.ws = None
+        self._graph = None
+
+    # ------------------------------------------------------------------ buffers
+    def alloc(self, *shape, zero=False):
+        t = (torch.zeros if zero else torch.empty)(shape, device=self.device, dtype=torch.float32)
+        self.keep.append(t)
+        return t
+
+    def hold(self, t):
+        self.keep.append(t)
+        return t
+
+    @staticmethod
+    def _ptr(t):
+        if t is None:
+            return None
+        if isinstance(t, int):
+            return t
+        return t.data_ptr()
+
+    def _add(self, code, i=(), f=(), p=(), name="", flops=0, nbytes=0):
+        op = L.aed_op()
+        op.code = code
+        for k, v in enumerate(i):
+            op.i[k] = int(v)
+        for k, v in enumerate(f):
+            op.f[k] = float(v)
+        for k, v in enumerate(p):
+            op.p[k] = self._ptr(v)
+            if torch.is_tensor(v):
+                self.keep.append(v)         # the record holds a raw pointer: keep the storage alive
+        self.ops.append(op)
+        self.meta.append(dict(name=name or L.OP_NAMES[code], code=code, flops=flops, bytes=nbytes))
+        self._arr = None
+        return len(self.ops) - 1
+
+    # ------------------------------------------------------------------ conv / linear
+    @staticmethod
+    def pick_tile(M, N, K, cus=None):
+        """Mirror of the C++ heuristic, made explicit so split-K workspaces can be sized here."""
+        cus = cus or CU_COUNT
+
+        def blocks(bm, bn):
+            return math.ceil(M / bm) * math.ceil(N / bn)
+        if N <= 32:
+            cfg, bm, bn = 5, 128, 32
+        elif M <= 32:
+            cfg, bm, bn = 6, 32, 128
+        elif N >= 128 and blocks(128, 128) >= 2 * cus:
+            cfg, bm, bn = 1, 128, 128
+        elif N >= 64 and blocks(128, 64) >= 2 * cus:
+            cfg, bm, bn = 2, 128, 64
+        elif N < 64:
+            cfg, bm, bn = 5, 128, 32
+        else:
+            cfg, bm, bn = 4, 64, 64
+        nblk = blocks(bm, bn)
+        nchunks = math.ceil(K / 32)
+        ksplit = 1
+        if nblk < cus and nchunks >= 8:
+            ksplit = max(1, min(math.ceil(2 * cus / nblk), nchunks // 4, 32))
+        return cfg, ksplit
+
+    def conv(self, x, w, bias, out, *, B, IH, IW, Cin, OH, OW, N, KH=1, KW=1, stride=1, pad_h=0, pad_w=0,
+             dil_h=1, dil_w=1, up=0, lda=None, a_bs=None, res=None, rowvec=None, ld_rv=0, in_act=0, in_slope=0.0,
+             out_act=0, out_p=0.0, accumulate=0, out_div=1.0, o_mul=1, o_add=0, o_len=None, out_bs=None,
+             ldc=None, ldr=None, ksplit=0, tile=0, name="conv"):
+        """Implicit-GEMM conv (AED_OP_CONV_GEMM).  x: [B,IH,IW,>=Cin] view, w: [N, KH*KW*Cin]."""
+        M = B * OH * OW
+        K = KH * KW * Cin
+        lda = x.stride(-2) if lda is None else lda
+        a_bs = IH * IW * lda if a_bs is None else a_bs
+        ldc = out.stride(-2) if ldc is None else ldc
+        if res is not None and ldr is None:
+            ldr = res.stride(-2)
+        o_len = OH * OW if o_len is None else o_len
+        out_bs = OH * OW if out_bs is None else out_bs
+        auto_tile, auto_split = self.pick_tile(M, N, K)
+        tile = tile or auto_tile
+        ksplit = ksplit or auto_split
+        i = [M, N, K, lda, ldc, ldr or 0, ld_rv, IH, IW, OH, OW, Cin, KH, KW, stride, pad_h, pad_w, dil_h, dil_w, up,
+             a_bs, o_mul, o_add, o_len, out_bs, in_act, out_act, accumulate, ksplit, tile]
+        idx = self._add(L.OP_CONV_GEMM, i, [in_slope, out_p, out_div], [x, w, bias, out, res, rowvec, None],
+                        name=name, flops=2 * M * N * K, nbytes=4 * (B * IH * IW * Cin + N * K + M * N))
+        if ksplit > 1:
+            self._ws_need = max(self._ws_need, ksplit * M * N)
+            self._ws_ops.append(idx)
+        return out
+
+    def linear(self, x, w, bias, out, *, M, K, N, lda=None, **kw):
+        """out[M,N] = x[M,K] @ w[N,K]^T (+bias ...).  x/out may be column views of wider buffers."""
+        lda = x.stride(-2) if lda is None else lda
+        return self.conv(x, w, bias, out, B=1, IH=M, IW=1, Cin=K, OH=M, OW=1, N=N, lda=lda, a_bs=0, **kw)
+
+    # ------------------------------------------------------------------ norms
+    def groupnorm(self, x, gamma, beta, out, *, B, HW, C, G=32, eps=1e-5, act=0, name="gn"):
+        ldx = x.stride(-2)
+        ldy = out.stride(-2)
+        target = max(1, (2 * CU_COUNT) // max(1, B))
+        rpc = max(1, math.ceil(HW / target))
+        rpc = max(rpc, 4)
+        nchunks = math.ceil(HW / rpc)
+        part = self.alloc(B, nchunks, G, 2)
+        nb = 4 * B * HW * C
+        self._add(L.OP_GN_STATS, [B, HW, C, G, ldx, rpc, nchunks], [], [x, part], name=name + ".stats", nbytes=nb)
+        self._add(L.OP_GN_APPLY, [B, HW, C, G, ldx, rpc, nchunks, act, ldy], [eps], [x, part, gamma, beta, out],
+                  name=name + ".apply", nbytes=2 * nb)
+        return out
+
+    def layernorm(self, x, gamma, beta, out, *, M, C, eps=1e-5, name="ln"):
+        self._add(L.OP_LAYERNORM, [M, C, x.stride(-2), out.stride(-2)], [eps], [x, gamma, beta, out], name=name,
+                  nbytes=8 * M * C)
+        return out
+
+    # ------------------------------------------------------------------ attention & friends
+    def attention(self, q, k, v, out, *, B, H, Nq, Nk, D, ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, scale,
+                  bias=None, ld_bias=0, name="attn"):
+        self._add(L.OP_ATTENTION, [B, H, Nq, Nk, D, ldq, ldk, ldv, ldo, ld_bias, bsq, bsk, bsv, bso], [scale],
+                  [q, k, v, bias, out], name=name, flops=4 * B * H * Nq * Nk * D,
+                  nbytes=4 * B * H * D * (2 * Nq + 2 * Nk))
+        return out
+
+    def geglu(self, h, out, *, M, Dff, name="geglu"):
+        self._add(L.OP_GEGLU, [M, Dff, h.stride(-2), out.stride(-2)], [], [h, out], name=name, nbytes=12 * M * Dff)
+        return out
+
+    def copy2d(self, src, dst, *, rows, cols, ld_src=None, ld_dst=None, name="copy"):
+        ld_src = src.stride(-2) if ld_src is None else ld_src
+        ld_dst = dst.stride(-2) if ld_dst is None else ld_dst
+        self._add(L.OP_COPY2D, [rows, cols, ld_src, ld_dst], [], [src, dst], name=name, nbytes=8 * rows * cols)
+        return dst
+
+    def time_embed(self, out, *, B, dim, flip=True, shift=0.0, timesteps=None, state=None, t_imm=0, name="time_embed"):
+        half = dim // 2
+        exponent = -math.log(10000) * torch.arange(half, dtype=torch.float32) / (half - shift)
+        freqs = torch.exp(exponent).to(self.device)
+        self._add(L.OP_TIME_EMBED, [B, dim, int(flip), out.stride(-2), t_imm], [shift, 10000.0],
+                  [out, timesteps, state, freqs], name=name)
+        return out
+
+    def softmax_rows(self, x, out, *, rows, cols, scale=1.0, name="softmax"):
+        self._add(L.OP_SOFTMAX_ROWS, [rows, cols, x.stride(-2), out.stride(-2)], [scale], [x, out], name=name,
+                  nbytes=8 * rows * cols)
+        return out
+
+    def transpose(self, src, dst, *, Bt, R, C, ld_src=None, ld_dst=None, bs_src=None, bs_dst=None, name="transpose"):
+        ld_src = C if ld_src is None else ld_src
+        ld_dst = R if ld_dst is None else ld_dst
+        bs_src = R * ld_src if bs_src is None else bs_src
+        bs_dst = C * ld_dst if bs_dst is None else bs_dst
+        self._add(L.OP_TRANSPOSE, [Bt, R, C, ld_src, ld_dst, bs_src, bs_dst], [], [src, dst], name=name,
+                  nbytes=8 * Bt * R * C)
+        return dst
+
+    def axpby(self, x, y, *, numel, a=1.0, b=0.0, name="axpby"):
+        self._add(L.OP_AXPBY, [numel & 0xFFFFFFFF, numel >> 32], [a, b], [x, y], name=name, nbytes=12 * numel)
+        return y
+
+    def advance(self, state, by=1):
+        self._add(L.OP_ADVANCE, [by], [], [state], name="advance")
+
+    def step(self, code, *, xts, zs, eps_u, eps_c, cfg, coef, state, out, numel, P, T, s_imm=0, v_pred=0, flag=1,
+             cfg_scalar=1.0, c_imm=(0, 0, 0, 0, 0), name="step"):
+        self._add(code, [numel & 0xFFFFFFFF, numel >> 32, P, T, s_imm, v_pred, flag], [cfg_scalar, *c_imm],
+                  [xts, zs, eps_u, eps_c, cfg, coef, state, out], name=name, nbytes=4 * numel * 6)
+
+    def reflect_pad(self, src, dst, *, B, N, pad, ldd, name="reflect_pad"):
+        self._add(L.OP_REFLECT_PAD, [B, N, pad, ldd], [], [src, dst], name=name, nbytes=8 * B * N)
+
+    def magnitude(self, ft, mag, *, F, cut, ld_ft, ld_mag, name="magnitude"):
+        self._add(L.OP_MAGNITUDE, [F, cut, ld_ft, ld_mag], [], [ft, mag], name=name, nbytes=4 * F * (2 * cut + ld_mag))
+
+    # ------------------------------------------------------------------ execution
+    def finalize(self):
+        if self._arr is None:
+            if self._ws_need and (self.ws is None or self.ws.numel() < self._ws_need):
+                self.ws = torch.empty(self._ws_need, device=self.device, dtype=torch.float32)
+            for idx in self._ws_ops:
+                self.ops[idx].p[6] = self.ws.data_ptr()
+            self._arr = (L.aed_op * len(self.ops))(*self.ops)
+        return self._arr
+
+    @property
+    def flops(self):
+        return sum(m["flops"] for m in self.meta)
+
+    def run(self, start=0, end=None):
+        arr = self.finalize()
+        end = len(self.ops) if end is None else end
+        if end <= start:
+            return
+        sub = ctypes.cast(ctypes.byref(arr, start * ctypes.sizeof(L.aed_op)), ctypes.POINTER(L.aed_op))
+        L.check(L.lib().aed_tape_run(sub, end - start, L.current_stream_ptr()), "aed_tape_run")
+
+    def profile(self):
+        """Per-op milliseconds (HIP events on the current stream)."""
+        arr = self.finalize()
+        ms = (ctypes.c_float * len(self.ops))()
+        L.check(L.lib().aed_tape_profile(arr, len(self.ops), L.current_stream_ptr(), ms), "aed_tape_profile")
+        return list(ms)
+
+    def capture(self):
+        """Capture the whole tape into a hipGraph on the current (non-default) stream."""
+        lib = L.lib()
+        sp = L.current_stream_ptr()
+        L.check(lib.aed_graph_begin(sp), "aed_graph_begin")
+        try:
+            self.run()
+        finally:
+            g = ctypes.c_void_p()
+            rc = lib.aed_graph_end(sp, ctypes.byref(g))
+        L.check(rc, "aed_graph_end")
+        self._graph = g
+        return g
+
+    def replay(self):
+        L.check(L.lib().aed_graph_launch(self._graph, L.current_stream_ptr()), "aed_graph_launch")
+
+    def __del__(self):
+        try:
+            if self._graph is not None:
+                L.lib().aed_graph_destroy(self._graph)
+        except Exception:
+            pass

@@ -1,0 +1,336 @@
+"""U-Net forward compiled to an op tape.
+
+One config-driven builder covers the three wrappers' U-Nets:
+  * diffusers UNet2DConditionModel as the reference drives it in PipelineWrapper.unet_forward
+    (/root/reference/code/models.py:160-393): AudioLDM-1 (CLAP FiLM through class_embedding,
+    attn2 degenerates to self-attention because encoder_hidden_states is None) and TANGO
+    (T5 cross-attention with an additive -10000 key mask);
+  * AudioLDM2UNet2DConditionModel as driven by AudioLDM2Wrapper.unet_forward (models.py:691-899):
+    three transformers per attention site -- [self,self], [self,cross->GPT-2 states],
+    [self,cross->T5 states + mask].
+Hooks of the reference forward (h-space tap/replace/add models.py:840-847, skip replace/zero
+:854-866) are exposed through `mid_index` (the tape is cut after the mid block) and `skips`.
+
+Everything here is host-side graph construction; arithmetic happens in libaed.so.
+Activations are channels-last; the NCHW<->NHWC change happens only at the wrapper boundary.
+"""
+import math
+
+import torch
+
+from . import _lib as L
+from .tape import Tape
+from .weights import ctx_dims_per_block, _per_block
+
+
+class UNetEngine:
+    def __init__(self, cfg, sd, device, batch, H, W, ctx_len0=0, ctx_len1=0, use_ehs=True,
+                 timesteps_dev=None, state_dev=None):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.B, self.H, self.W = batch, H, W
+        self.use_ehs = use_ehs
+        self.L0, self.L1 = ctx_len0, ctx_len1
+        self.timesteps_dev, self.state_dev = timesteps_dev, state_dev
+        self.tape = Tape(device)
+        self.ctx_tape = Tape(device)
+        self._tmp = {}
+        self.wd = {}
+        self._pack(sd)
+        self._build()
+
+    # ------------------------------------------------------------------ weights
+    def _dev(self, t):
+        return self.tape.hold(t.contiguous().to(self.device, torch.float32))
+
+    def _pack(self, sd):
+        """Re-lay weights: conv [O,I,kh,kw] -> [O, kh*kw*I]; fuse q/k/v; concatenate temb projections."""
+        wd = self.wd
+        temb_w, temb_b, self.temb_off = [], [], {}
+        off = 0
+        for k, v in sd.items():
+            if k.endswith("time_emb_proj.weight"):
+                base = k[: -len(".weight")]
+                self.temb_off[base] = off
+                off += v.shape[0]
+                temb_w.append(v)
+                temb_b.append(sd[base + ".bias"])
+        self.temb_total = off
+        wd["temb_all.weight"] = self._dev(torch.cat(temb_w, 0))
+        wd["temb_all.bias"] = self._dev(torch.cat(temb_b, 0))
+        for k, v in sd.items():
+            if "time_emb_proj" in k:
+                continue
+            if v.dim() == 4:
+                v = v.permute(0, 2, 3, 1).reshape(v.shape[0], -1)
+            if k.endswith(".to_q.weight"):
+                base = k[: -len(".to_q.weight")]
+                wq, wk, wv = v, sd[base + ".to_k.weight"], sd[base + ".to_v.weight"]
+                if wk.shape[1] == wq.shape[1]:
+                    wd[base + ".qkv.weight"] = self._dev(torch.cat([wq, wk, wv], 0))
+                wd[base + ".q.weight"] = self._dev(wq)
+                wd[base + ".kv.weight"] = self._dev(torch.cat([wk, wv], 0))
+                continue
+            if k.endswith(".to_k.weight") or k.endswith(".to_v.weight"):
+                continue
+            wd[k] = self._dev(v)
+
+    def tmp(self, tag, *shape):
+        key = (tag, tuple(shape))
+        if key not in self._tmp:
+            self._tmp[key] = self.tape.alloc(*shape)
+        return self._tmp[key]
+
+    # ------------------------------------------------------------------ modules
+    def _resnet(self, p, x, Cin, Cout, H, W, dest, groups, eps):
+        tp, wd, B = self.tape, self.wd, self.B
+        a = self.tmp("gn_a", B, H, W, Cin)
+        tp.groupnorm(x, wd[p + ".norm1.weight"], wd[p + ".norm1.bias"], a, B=B, HW=H * W, C=Cin, G=groups, eps=eps,
+                     act=L.ACT_SILU, name=p + ".norm1")
+        h = self.tmp("res_h", B, H, W, Cout)
+        off = self.temb_off[p + ".time_emb_proj"]
+        tp.conv(a, wd[p + ".conv1.weight"], wd[p + ".conv1.bias"], h, B=B, IH=H, IW=W, Cin=Cin, OH=H, OW=W, N=Cout,
+                KH=3, KW=3, pad_h=1, pad_w=1, rowvec=self.temb_all[:, off:off + Cout], ld_rv=self.temb_total,
+                name=p + ".conv1")
+        a2 = self.tmp("gn_a2", B, H, W, Cout)
+        tp.groupnorm(h, wd[p + ".norm2.weight"], wd[p + ".norm2.bias"], a2, B=B, HW=H * W, C=Cout, G=groups, eps=eps,
+                     act=L.ACT_SILU, name=p + ".norm2")
+        res = x
+        if (p + ".conv_shortcut.weight") in wd:
+            res = self.tmp("res_sc", B, H, W, Cout)
+            tp.conv(x, wd[p + ".conv_shortcut.weight"], wd[p + ".conv_shortcut.bias"], res, B=B, IH=H, IW=W, Cin=Cin,
+                    OH=H, OW=W, N=Cout, name=p + ".conv_shortcut")
+        tp.conv(a2, wd[p + ".conv2.weight"], wd[p + ".conv2.bias"], dest, B=B, IH=H, IW=W, Cin=Cout, OH=H, OW=W,
+                N=Cout, KH=3, KW=3, pad_h=1, pad_w=1, res=res, name=p + ".conv2")
+        return dest
+
+    def _attn(self, p, x_ln, C, N, heads, out, kv=None, Lk=0, bias=None):
+        """attention sub-layer input projections + fused attention.  x_ln: [B*N, C] (already LayerNormed)."""
+        tp, wd, B = self.tape, self.wd, self.B
+        M = B * N
+        D = C // heads
+        if kv is None:
+            qkv = self.tmp("t_qkv", M, 3 * C)
+            tp.linear(x_ln, wd[p + ".qkv.weight"], None, qkv, M=M, K=C, N=3 * C, name=p + ".qkv")
+            tp.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], out, B=B, H=heads, Nq=N, Nk=N, D=D, ldq=3 * C, ldk=3 * C,
+                         ldv=3 * C, ldo=C, bsq=N * 3 * C, bsk=N * 3 * C, bsv=N * 3 * C, bso=N * C,
+                         scale=D ** -0.5, name=p + ".sdpa")
+        else:
+            q = self.tmp("t_q", M, C)
+            tp.linear(x_ln, wd[p + ".q.weight"], None, q, M=M, K=C, N=C, name=p + ".q")
+            tp.attention(q, kv, kv[:, C:], out, B=B, H=heads, Nq=N, Nk=Lk, D=D, ldq=C, ldk=2 * C, ldv=2 * C, ldo=C,
+                         bsq=N * C, bsk=Lk * 2 * C, bsv=Lk * 2 * C, bso=N * C, scale=D ** -0.5, bias=bias,
+                         ld_bias=Lk if bias is not None else 0, name=p + ".sdpa_x")
+        return out
+
+    def _transformer(self, p, x, C, H, W, heads, kind, dest, groups):
+        tp, wd, B = self.tape, self.wd, self.B
+        N = H * W
+        M = B * N
+        n = self.tmp("t_n", M, C)
+        tp.groupnorm(x, wd[p + ".norm.weight"], wd[p + ".norm.bias"], n, B=B, HW=N, C=C, G=groups, eps=1e-6,
+                     name=p + ".norm")
+        t0 = self.tmp("t_0", M, C)
+        tp.linear(n, wd[p + ".proj_in.weight"], wd[p + ".proj_in.bias"], t0, M=M, K=C, N=C, name=p + ".proj_in")
+        b = p + ".transformer_blocks.0"
+        ln = self.tmp("t_l", M, C)
+        o = self.tmp("t_o", M, C)
+        tp.layernorm(t0, wd[b + ".norm1.weight"], wd[b + ".norm1.bias"], ln, M=M, C=C, name=b + ".norm1")
+        self._attn(b + ".attn1", ln, C, N, heads, o)
+        t1 = self.tmp("t_1", M, C)
+        tp.linear(o, wd[b + ".attn1.to_out.0.weight"], wd[b + ".attn1.to_out.0.bias"], t1, M=M, K=C, N=C, res=t0,
+                  name=b + ".attn1.to_out")
+        tp.layernorm(t1, wd[b + ".norm2.weight"], wd[b + ".norm2.bias"], ln, M=M, C=C, name=b + ".norm2")
+        if kind == "self2":
+            self._attn(b + ".attn2", ln, C, N, heads, o)
+        else:
+            which = 0 if kind == "cross0" else 1
+            Lk = self.L0 if which == 0 else self.L1
+            ctx = self.ehs0 if which == 0 else self.ehs1
+            cdim = ctx.shape[-1]
+            kv = self.ctx_tape.alloc(B * Lk, 2 * C)
+            self.ctx_tape.linear(ctx.view(B * Lk, cdim), wd[b + ".attn2.kv.weight"], None, kv, M=B * Lk, K=cdim,
+                                 N=2 * C, name=b + ".attn2.kv")
+            bias = self.bias0 if which == 0 else self.bias1
+            self._attn(b + ".attn2", ln, C, N, heads, o, kv=kv, Lk=Lk, bias=bias)
+        t2 = self.tmp("t_2", M, C)
+        tp.linear(o, wd[b + ".attn2.to_out.0.weight"], wd[b + ".attn2.to_out.0.bias"], t2, M=M, K=C, N=C, res=t1,
+                  name=b + ".attn2.to_out")
+        tp.layernorm(t2, wd[b + ".norm3.weight"], wd[b + ".norm3.bias"], ln, M=M, C=C, name=b + ".norm3")
+        g = self.tmp("t_g", M, 8 * C)
+        tp.linear(ln, wd[b + ".ff.net.0.proj.weight"], wd[b + ".ff.net.0.proj.bias"], g, M=M, K=C, N=8 * C,
+                  name=b + ".ff1")
+        f = self.tmp("t_f", M, 4 * C)
+        tp.geglu(g, f, M=M, Dff=4 * C, name=b + ".geglu")
+        t3 = self.tmp("t_3", M, C)
+        tp.linear(f, wd[b + ".ff.net.2.weight"], wd[b + ".ff.net.2.bias"], t3, M=M, K=4 * C, N=C, res=t2,
+                  name=b + ".ff2")
+        tp.linear(t3, wd[p + ".proj_out.weight"], wd[p + ".proj_out.bias"], dest, M=M, K=C, N=C, res=x,
+                  name=p + ".proj_out")
+        return dest
+
+    def _site(self, prefix, k0, x, C, H, W, heads, dims, groups):
+        """One attention site = len(dims) Transformer2D modules (3 for AudioLDM2)."""
+        for j, cdim in enumerate(dims):
+            if cdim is None or not self.use_ehs:
+                kind = "self2"
+            elif self.multi and j > 1:
+                kind = "cross1"
+            else:
+                kind = "cross0"
+            dest = self.tape.alloc(self.B, H, W, C)
+            x = self._transformer(f"{prefix}.attentions.{k0 + j}", x, C, H, W, heads, kind, dest, groups)
+        return x
+
+    # ------------------------------------------------------------------ graph
+    def _build(self):
+        cfg, tp, wd, B, H, W = self.cfg, self.tape, self.wd, self.B, self.H, self.W
+        boc = cfg["block_out_channels"]
+        nb = len(boc)
+        lpb = cfg.get("layers_per_block", 2)
+        groups = cfg.get("norm_num_groups", 32)
+        eps = cfg.get("norm_eps", 1e-5)
+        heads_pb = _per_block(cfg.get("num_attention_heads") or cfg.get("attention_head_dim", 8), nb)
+        ctx_pb, self.multi = ctx_dims_per_block(cfg)
+        cin, cout = cfg["in_channels"], cfg["out_channels"]
+        ted = boc[0] * 4
+        has_class = cfg.get("class_embed_type") is not None
+        concat = bool(cfg.get("class_embeddings_concat"))
+        emb_dim = 2 * ted if (has_class and concat) else ted
+
+        # ---- persistent inputs
+        self.x_in = tp.alloc(B, H, W, cin, zero=True)
+        self.ehs0 = self.ehs1 = self.bias0 = self.bias1 = self.class_labels = None
+        if self.use_ehs:
+            d0 = [c for blk in ctx_pb for c in blk if c is not None]
+            if self.multi:
+                dims0 = sorted({blk[1] for blk in ctx_pb if blk[1] is not None})
+                dims1 = sorted({blk[2] for blk in ctx_pb if len(blk) > 2 and blk[2] is not None})
+                self.ehs0 = tp.alloc(B, self.L0, dims0[0], zero=True)
+                self.ehs1 = tp.alloc(B, self.L1, dims1[0], zero=True)
+                self.bias1 = tp.alloc(B, self.L1, zero=True)
+            else:
+                self.ehs0 = tp.alloc(B, self.L0, d0[0], zero=True)
+                self.bias0 = tp.alloc(B, self.L0, zero=True)
+        if has_class:
+            self.class_labels = tp.alloc(B, cfg["projection_class_embeddings_input_dim"], zero=True)
+
+        # ---- time / class embedding, fused time_emb_proj for every resnet
+        t_emb = tp.alloc(B, boc[0])
+        self.time_op = len(tp.ops)
+        tp.time_embed(t_emb, B=B, dim=boc[0], flip=cfg.get("flip_sin_to_cos", True), shift=cfg.get("freq_shift", 0),
+                      timesteps=self.timesteps_dev, state=self.state_dev)
+        e1 = tp.alloc(B, ted)
+        tp.linear(t_emb, wd["time_embedding.linear_1.weight"], wd["time_embedding.linear_1.bias"], e1, M=B,
+                  K=boc[0], N=ted, out_act=L.ACT_SILU, name="time_embedding.linear_1")
+        self.emb = tp.alloc(B, emb_dim)
+        if has_class and not concat:
+            cemb = self.ctx_tape.alloc(B, ted)
+            self.ctx_tape.linear(self.class_labels, wd["class_embedding.weight"], wd["class_embedding.bias"], cemb,
+                                 M=B, K=self.class_labels.shape[1], N=ted, name="class_embedding")
+            tp.linear(e1, wd["time_embedding.linear_2.weight"], wd["time_embedding.linear_2.bias"], self.emb, M=B,
+                      K=ted, N=ted, res=cemb, name="time_embedding.linear_2")
+        else:
+            tp.linear(e1, wd["time_embedding.linear_2.weight"], wd["time_embedding.linear_2.bias"], self.emb, M=B,
+                      K=ted, N=ted, name="time_embedding.linear_2")
+            if has_class:
+                self.ctx_tape.linear(self.class_labels, wd["class_embedding.weight"], wd["class_embedding.bias"],
+                                     self.emb[:, ted:], M=B, K=self.class_labels.shape[1], N=ted,
+                                     name="class_embedding")
+        self.temb_all = tp.alloc(B, self.temb_total)
+        tp.linear(self.emb, wd["temb_all.weight"], wd["temb_all.bias"], self.temb_all, M=B, K=emb_dim,
+                  N=self.temb_total, in_act=L.ACT_SILU, name="time_emb_proj(all resnets)")
+
+        # ---- conv_in + down
+        h = tp.alloc(B, H, W, boc[0])
+        tp.conv(self.x_in, wd["conv_in.weight"], wd["conv_in.bias"], h, B=B, IH=H, IW=W, Cin=cin, OH=H, OW=W,
+                N=boc[0], KH=3, KW=3, pad_h=1, pad_w=1, name="conv_in")
+        skips = [(h, boc[0], H, W)]
+        ch, hh, ww = boc[0], H, W
+        for i, bt in enumerate(cfg["down_block_types"]):
+            co = boc[i]
+            for j in range(lpb):
+                d = tp.alloc(B, hh, ww, co)
+                h = self._resnet(f"down_blocks.{i}.resnets.{j}", h, ch, co, hh, ww, d, groups, eps)
+                ch = co
+                if "CrossAttn" in bt:
+                    h = self._site(f"down_blocks.{i}", j * len(ctx_pb[i]), h, co, hh, ww, heads_pb[i], ctx_pb[i],
+                                   groups)
+                skips.append((h, ch, hh, ww))
+            if i < nb - 1:
+                oh, ow = (hh + 2 - 3) // 2 + 1, (ww + 2 - 3) // 2 + 1
+                d = tp.alloc(B, oh, ow, co)
+                p = f"down_blocks.{i}.downsamplers.0.conv"
+                tp.conv(h, wd[p + ".weight"], wd[p + ".bias"], d, B=B, IH=hh, IW=ww, Cin=co, OH=oh, OW=ow, N=co,
+                        KH=3, KW=3, stride=2, pad_h=1, pad_w=1, name=p)
+                h, hh, ww = d, oh, ow
+                skips.append((h, ch, hh, ww))
+
+        # ---- mid
+        d = tp.alloc(B, hh, ww, ch)
+        h = self._resnet("mid_block.resnets.0", h, ch, ch, hh, ww, d, groups, eps)
+        h = self._site("mid_block", 0, h, ch, hh, ww, heads_pb[-1], ctx_pb[-1], groups)
+        self.h_space = tp.alloc(B, hh, ww, ch)
+        self._resnet("mid_block.resnets.1", h, ch, ch, hh, ww, self.h_space, groups, eps)
+        h = self.h_space
+        self.mid_index = len(tp.ops)
+        self.skips = [s[0] for s in skips]
+
+        # ---- up
+        for i, bt in enumerate(cfg["up_block_types"]):
+            lvl = nb - 1 - i
+            co = boc[lvl]
+            for j in range(lpb + 1):
+                sk, sc, sh_, sw_ = skips.pop()
+                assert (sh_, sw_) == (hh, ww), "skip / feature-map size mismatch (input not a multiple of 2^levels)"
+                cat = self.tmp("cat", B, hh, ww, ch + sc)
+                tp.copy2d(h, cat, rows=B * hh * ww, cols=ch, ld_src=h.stride(-2), ld_dst=ch + sc, name="cat.h")
+                tp.copy2d(sk, cat[..., ch:], rows=B * hh * ww, cols=sc, ld_src=sk.stride(-2), ld_dst=ch + sc,
+                          name="cat.skip")
+                d = tp.alloc(B, hh, ww, co)
+                h = self._resnet(f"up_blocks.{i}.resnets.{j}", cat, ch + sc, co, hh, ww, d, groups, eps)
+                ch = co
+                if "CrossAttn" in bt:
+                    h = self._site(f"up_blocks.{i}", j * len(ctx_pb[lvl]), h, co, hh, ww, heads_pb[lvl], ctx_pb[lvl],
+                                   groups)
+            if i < nb - 1:
+                p = f"up_blocks.{i}.upsamplers.0.conv"
+                d = tp.alloc(B, 2 * hh, 2 * ww, co)
+                tp.conv(h, wd[p + ".weight"], wd[p + ".bias"], d, B=B, IH=hh, IW=ww, Cin=co, OH=2 * hh, OW=2 * ww,
+                        N=co, KH=3, KW=3, pad_h=1, pad_w=1, up=1, name=p)
+                h, hh, ww = d, 2 * hh, 2 * ww
+
+        # ---- out
+        a = self.tmp("gn_a", B, hh, ww, ch)
+        tp.groupnorm(h, wd["conv_norm_out.weight"], wd["conv_norm_out.bias"], a, B=B, HW=hh * ww, C=ch, G=groups,
+                     eps=eps, act=L.ACT_SILU, name="conv_norm_out")
+        self.eps = tp.alloc(B, hh, ww, cout)
+        tp.conv(a, wd["conv_out.weight"], wd["conv_out.bias"], self.eps, B=B, IH=hh, IW=ww, Cin=ch, OH=hh, OW=ww,
+                N=cout, KH=3, KW=3, pad_h=1, pad_w=1, name="conv_out")
+        tp.finalize()
+        self.ctx_tape.finalize()
+
+    # ------------------------------------------------------------------ use
+    def set_conditioning(self, ehs0=None, ehs1=None, bias0=None, bias1=None, class_labels=None):
+        """Copy conditioning (already laid out [B, L, dim]) into the engine and run the per-prompt
+        precompute tape (cross-attention K/V projections, class embedding) -- once per prompt set."""
+        for dst, src in ((self.ehs0, ehs0), (self.ehs1, ehs1), (self.bias0, bias0), (self.bias1, bias1),
+                         (self.class_labels, class_labels)):
+            if dst is not None and src is not None:
+                dst.copy_(src.to(dst.device, torch.float32).reshape(dst.shape))
+        self.ctx_tape.run()
+
+    def set_timestep(self, t):
+        """Immediate-timestep mode (no device table): patch the time-embedding op."""
+        self.tape.ops[self.time_op].i[4] = int(t)
+        arr = self.tape.finalize()
+        arr[self.time_op].i[4] = int(t)
+
+    def forward(self, first_half_only=False, second_half_only=False):
+        if second_half_only:
+            self.tape.run(self.mid_index, None)
+        elif first_half_only:
+            self.tape.run(0, self.mid_index)
+        else:
+            self.tape.run()
+        return self.eps

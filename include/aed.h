@@ -1,0 +1,135 @@
+/*
+ * aed.h -- C ABI of libaed.so, the MI355X (gfx950) native engine underneath the
+ * reference's models.py wrapper API (HilaManor/AudioEditingCode).
+ *
+ * The reference has NO native boundary: its hot path crosses from the editing loops into
+ * torch/diffusers through the duck-typed Python class PipelineWrapper
+ * (/root/reference/code/models.py:14-393 and the AudioLDM/AudioLDM2/TANGO subclasses).
+ * This header is the boundary a maintainer would bind underneath that class (ctypes stub in
+ * INTEGRATION.md).  Conventions:
+ *   - extern "C", plain pointers and sizes, no torch types;
+ *   - every pointer is a DEVICE pointer borrowed from the caller (never freed here) unless
+ *     the name says _host;
+ *   - tensors are fp32, contiguous, CHANNELS-LAST: feature maps [B,H,W,C] (== token matrix
+ *     [B*H*W, C]), sequences [B,L,C]; weights [N,K] with K=(ky,kx,ci) for convolutions;
+ *   - every entry point takes a hipStream_t (passed as void*) and is asynchronous on it;
+ *   - return 0 = OK, non-zero = error with a message in aed_last_error().
+ *
+ * Two levels:
+ *   (1) path-level entry points named after the reference methods they replace
+ *       (aed_get_zs_from_xts, aed_reverse_step_with_custom_noise, ...);
+ *   (2) the op tape: a model forward (U-Net / VAE / vocoder / STFT) is a flat array of
+ *       aed_op records built once by the host and executed natively by aed_tape_run(),
+ *       optionally captured into a hipGraph (aed_graph_*).
+ */
+#ifndef AED_H
+#define AED_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AED_VERSION 1
+
+/* ----------------------------------------------------------------------------------------
+ * op tape
+ * -------------------------------------------------------------------------------------- */
+enum aed_opcode {
+    AED_OP_NOP = 0,
+    AED_OP_CONV_GEMM = 1,     /* implicit-GEMM conv / linear on fp32 MFMA (K5,K6,K11,K2,K3)   */
+    AED_OP_GN_STATS = 2,      /* GroupNorm partial sums (K4)                                   */
+    AED_OP_GN_APPLY = 3,      /* GroupNorm normalise + affine (+SiLU) (K4)                     */
+    AED_OP_LAYERNORM = 4,     /* LayerNorm over the last dim (K8)                              */
+    AED_OP_ATTENTION = 5,     /* softmax(QK^T*scale + bias)V, flash-style, fp32 MFMA (K7)      */
+    AED_OP_GEGLU = 6,         /* x * gelu(gate) (K8)                                           */
+    AED_OP_COPY2D = 7,        /* strided 2-D copy (skip concat, h-space tap/replace) (K10)     */
+    AED_OP_TIME_EMBED = 8,    /* sinusoidal timestep embedding (K9)                            */
+    AED_OP_SOFTMAX_ROWS = 9,  /* row softmax (VAE single-head attention)                       */
+    AED_OP_TRANSPOSE = 10,    /* batched 2-D transpose                                         */
+    AED_OP_AXPBY = 11,        /* y = a*x + b*y elementwise (h-space add, sample_xts)           */
+    AED_OP_INVERT_STEP = 12,  /* CFG + get_zs_from_xts (K1; models.py:85-117)                  */
+    AED_OP_REVERSE_STEP = 13, /* CFG + reverse_step_with_custom_noise (K1; models.py:119-158)  */
+    AED_OP_DDIM_STEP = 14,    /* CFG + DDIM next_step / scheduler.step(eta=0)                  */
+    AED_OP_ADVANCE = 15,      /* device step counter += 1                                      */
+    AED_OP_REFLECT_PAD = 16,  /* 1-D reflect pad (stft.py:60-65)                               */
+    AED_OP_MAGNITUDE = 17,    /* sqrt(re^2+im^2) (stft.py:78)                                  */
+    AED_OP_NCHW_TO_NHWC = 18, /* boundary layout change                                        */
+    AED_OP_NHWC_TO_NCHW = 19,
+    AED_OP_SPLITK_REDUCE = 20,
+    AED_OP_COUNT
+};
+
+/* One record of the tape.  Which slots an opcode reads is documented next to its launcher in
+ * audioeditingcode_amd/csrc (and mirrored by audioeditingcode_amd/tape.py). */
+typedef struct aed_op {
+    int32_t code;
+    int32_t flags;
+    int32_t i[32];
+    float   f[8];
+    void*   p[8];
+} aed_op;
+
+/* activation / transform codes used in aed_op slots */
+enum aed_act { AED_ACT_NONE = 0, AED_ACT_SILU = 1, AED_ACT_LEAKY = 2, AED_ACT_TANH = 3, AED_ACT_LOGCLAMP = 4 };
+
+int         aed_version(void);
+const char* aed_last_error(void);
+/* number of CUs, LDS bytes per CU and gcn arch name of the current device */
+int         aed_device_info(int* cu_count, int* lds_bytes, char* arch, int arch_len);
+
+/* Execute one op / a tape of n ops on `stream` (asynchronous). */
+int aed_launch(const aed_op* op, void* stream);
+int aed_tape_run(const aed_op* ops, int n, void* stream);
+/* Timed variant: records a hipEvent pair around every op on `stream`, synchronises, and
+ * writes per-op milliseconds into ms_host[n] (host pointer).  Used by bench.py's roofline leg. */
+int aed_tape_profile(const aed_op* ops, int n, void* stream, float* ms_host);
+
+/* hipGraph capture of everything launched on `stream` between begin and end. */
+int aed_graph_begin(void* stream);
+int aed_graph_end(void* stream, void** graph_exec_out);
+int aed_graph_launch(void* graph_exec, void* stream);
+int aed_graph_destroy(void* graph_exec);
+
+/* HIP-event helpers so hosts without a HIP binding can time a stream region. */
+int aed_event_create(void** ev_out);
+int aed_event_record(void* ev, void* stream);
+int aed_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms_out);   /* synchronises on ev_stop */
+int aed_event_destroy(void* ev);
+
+/* ----------------------------------------------------------------------------------------
+ * path-level entry points (reference method each one replaces)
+ * -------------------------------------------------------------------------------------- */
+
+/* Per-step scheduler coefficients, computed on the host in fp32 with the reference's
+ * expression order (models.py:91-113, :124-150) so that the device arithmetic is bit-exact:
+ *   c[0]=sqrt(1-abar_t)  c[1]=sqrt(abar_t)  c[2]=sqrt(abar_prev)
+ *   c[3]=sqrt(1-abar_prev-eta*var)          c[4]=eta*sqrt(var)     c[5..7] reserved        */
+#define AED_COEF_STRIDE 8
+
+/* PipelineWrapper.get_zs_from_xts (models.py:85-117) fused with the CFG combine of
+ * inversion_utils.py:97-102.  eps_c may be NULL (empty source prompt, inversion_utils.py:86).
+ * cfg: per-element guidance tensor [P,numel] (inversion_utils.py:29-51) or NULL -> cfg_scalar.
+ * Writes z[numel] and, when numerical_fix, overwrites xtm1 in place with mu + sigma*z.      */
+int aed_get_zs_from_xts(const float* xt, float* xtm1, const float* eps_u, const float* eps_c,
+                        const float* cfg, float cfg_scalar, int n_prompts, const float* coef_host,
+                        int v_prediction, int numerical_fix, float* z, float* noise_pred_out,
+                        int64_t numel, void* stream);
+
+/* PipelineWrapper.reverse_step_with_custom_noise (models.py:119-158) fused with the CFG
+ * combine of inversion_utils.py:276-281.  z may be NULL when eta == 0.                      */
+int aed_reverse_step_with_custom_noise(const float* xt, const float* eps_u, const float* eps_c,
+                                       const float* cfg, float cfg_scalar, int n_prompts,
+                                       const float* coef_host, int v_prediction, const float* z,
+                                       float* prev_out, int64_t numel, void* stream);
+
+/* PipelineWrapper.sample_xts_from_x0 inner statement (models.py:81):
+ * out = x0*sqrt_abar + noise*sqrt_1m_abar, for n_t rows (noise drawn by the host RNG).      */
+int aed_sample_xts_from_x0(const float* x0, const float* noise, const float* sqrt_abar,
+                           const float* sqrt_1m_abar, float* xts_out, int n_t, int64_t numel,
+                           void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AED_H */

@@ -93,6 +93,8 @@ def gen_loops():
                          encoder_attention_mask=None, **kw):
             return UOut(sample=synthetic_unet(sample, timestep, class_labels)), None, None
 
+    _probe_cond = torch.stack([prompt_vec("probe")])
+
     def run_case(name, T, tstart, src, tgt, cfg_src, cfg_tar, pred="epsilon", alpha_one=False,
                  seed=0, shape=(8, 16, 16), cutoff=None, fix_alpha=0.1):
         sched = OracleDDIMScheduler(prediction_type=pred, set_alpha_to_one=alpha_one)
@@ -117,7 +119,8 @@ def gen_loops():
                             cfg_src=np.array(cfg_src, dtype=np.float64), cfg_tar=np.array(cfg_tar, dtype=np.float64),
                             src=np.array(list(src)), tgt=np.array(list(tgt)), pred=pred, alpha_one=alpha_one,
                             fix_alpha=fix_alpha,
-                            alphas_cumprod=sched.alphas_cumprod.numpy(), timesteps=sched.timesteps.numpy())
+                            alphas_cumprod=sched.alphas_cumprod.numpy(), timesteps=sched.timesteps.numpy(),
+                            probe=synthetic_unet(x0, torch.tensor(501), _probe_cond).numpy())
         print("loop", name, "zs", tuple(zs.shape), "finite w_edit:", bool(torch.isfinite(w0).all()))
 
     run_case("ddpm_T20", 20, 10, ["a dog barking"], ["a cat meowing"], [3.0], [12.0])
@@ -161,9 +164,16 @@ def gen_loops():
         xt, xtm1, eps, z = (torch.randn((1, 8, 16, 16), generator=g) for _ in range(4))
         zz, xfix, _ = m.get_zs_from_xts(xt, xtm1, eps, tt, eta=1.0, numerical_fix=True)
         prev = m.reverse_step_with_custom_noise(eps, tt, xt, variance_noise=z, eta=1.0)
+        abar = sched.alphas_cumprod
+        prev_t = tt - 1000 // T
+        a_prev = m.get_alpha_prod_t_prev(prev_t)
+        var = m.get_variance(tt, prev_t)
+        coef = torch.stack([(1 - abar[tt]) ** 0.5, abar[tt] ** 0.5, a_prev ** 0.5, (1 - a_prev - 1.0 * var) ** 0.5,
+                            1.0 * var ** 0.5, torch.tensor(0.), torch.tensor(0.), torch.tensor(0.)])
+        rec[f"coef{i}"] = coef.numpy()
         rec.update({f"t{i}": t, f"xt{i}": xt.numpy(), f"xtm1{i}": xtm1.numpy(), f"eps{i}": eps.numpy(),
                     f"z_in{i}": z.numpy(), f"z{i}": zz.numpy(), f"xfix{i}": xfix.numpy(), f"prev{i}": prev.numpy()})
-    np.savez_compressed(os.path.join(OUT, "step_math_T200.npz"), n=4, **rec)
+    np.savez_compressed(os.path.join(OUT, "step_math_T200.npz"), n=4, alphas_cumprod=sched.alphas_cumprod.numpy(), **rec)
     print("step math ok")
 
 

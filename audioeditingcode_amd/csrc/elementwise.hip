@@ -39,8 +39,12 @@ int launch_geglu(const aed_op* op, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------ copy2d
+// Optional device-indexed source: src += (idx_off + idx_mul * state[0]) * idx_stride elements, so a
+// captured graph can walk the xts trajectory (inversion_utils.py:78 `xt = xts[idx+1]`).
 __global__ __launch_bounds__(256) void copy2d_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows,
-                                                      int cols, int lds_, int ldd, int vec) {
+                                                      int cols, int lds_, int ldd, int vec, const int* state,
+                                                      int idx_off, int idx_mul, long idx_stride) {
+    if (state) src += (size_t)(idx_off + idx_mul * state[0]) * (size_t)idx_stride;
     if (vec) {
         const int q = cols >> 2;
         const size_t total = (size_t)rows * q;
@@ -59,26 +63,29 @@ __global__ __launch_bounds__(256) void copy2d_kernel(const float* __restrict__ s
         }
     }
 }
-// slots: p0=src p1=dst ; i0=rows i1=cols i2=ld_src i3=ld_dst
+// slots: p0=src p1=dst p2=state(nullable) ; i0=rows i1=cols i2=ld_src i3=ld_dst i4=idx_off i5=idx_mul i6=idx_stride
 int launch_copy2d(const aed_op* op, hipStream_t s) {
     const int32_t* i = op->i;
     AED_REQUIRE(op->p[0] && op->p[1], "copy2d: null pointer");
     const int vec = (i[1] % 4 == 0) && (i[2] % 4 == 0) && (i[3] % 4 == 0) && ((uintptr_t)op->p[0] % 16 == 0) &&
-                    ((uintptr_t)op->p[1] % 16 == 0);
+                    ((uintptr_t)op->p[1] % 16 == 0) && (i[6] % 4 == 0);
     hipLaunchKernelGGL(copy2d_kernel, dim3(grid_for((size_t)i[0] * i[1] / (vec ? 4 : 1))), dim3(256), 0, s,
-                       (const float*)op->p[0], (float*)op->p[1], i[0], i[1], i[2], i[3], vec);
+                       (const float*)op->p[0], (float*)op->p[1], i[0], i[1], i[2], i[3], vec, (const int*)op->p[2],
+                       i[4], i[5], (long)i[6]);
     AED_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
 // ------------------------------------------------------------------------------------ timestep embedding
-__global__ void time_embed_kernel(float* out, const long long* tt, const int* state, const float* freqs, int B,
-                                  int dim, int flip, int ld, int t_imm, float shift, float max_period) {
+__global__ void time_embed_kernel(float* out, const long long* tt, const int* state, const float* freqs,
+                                  const int* row_tidx, int B, int dim, int flip, int ld, int t_imm, int tgroup,
+                                  float shift, float max_period) {
     const int half = dim / 2;
     const int s = state ? state[0] : 0;
-    const float t = (float)(tt ? tt[s] : (long long)t_imm);
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < B * half; e += gridDim.x * blockDim.x) {
         const int b = e / half, i = e - b * half;
+        // row b of a timestep-batched call uses table entry s*tgroup + row_tidx[b]
+        const float t = (float)(tt ? tt[s * tgroup + (row_tidx ? row_tidx[b] : 0)] : (long long)t_imm);
         // freqs (host table, computed exactly as diffusers' Timesteps does) keeps t*freq bit-identical
         const float fr = freqs ? freqs[i] : expf(-logf(max_period) * (float)i / ((float)half - shift));
         const float arg = t * fr;
@@ -89,13 +96,14 @@ __global__ void time_embed_kernel(float* out, const long long* tt, const int* st
     }
 }
 // slots: p0=out[B,dim] p1=timesteps(int64 dev, nullable) p2=state(int32 dev, nullable) p3=freqs[dim/2] (nullable)
+//        p4=row_tidx(int32[B], nullable)   i5 = timesteps per call (tgroup, default 1)
 //        i0=B i1=dim i2=flip_sin_to_cos i3=ld i4=t_imm ; f0=freq_shift f1=max_period
 int launch_time_embed(const aed_op* op, hipStream_t s) {
     const int32_t* i = op->i;
     AED_REQUIRE(op->p[0] && i[1] % 2 == 0, "time_embed: bad args");
     hipLaunchKernelGGL(time_embed_kernel, dim3(aed_cdiv(i[0] * i[1] / 2, 256)), dim3(256), 0, s, (float*)op->p[0],
-                       (const long long*)op->p[1], (const int*)op->p[2], (const float*)op->p[3], i[0], i[1], i[2], i[3],
-                       i[4], op->f[0],
+                       (const long long*)op->p[1], (const int*)op->p[2], (const float*)op->p[3], (const int*)op->p[4],
+                       i[0], i[1], i[2], i[3], i[4], i[5] > 0 ? i[5] : 1, op->f[0],
                        op->f[1] > 0.f ? op->f[1] : 10000.0f);
     AED_CHECK_HIP(hipGetLastError());
     return 0;
@@ -197,7 +205,7 @@ struct StepParams {
     const int* state;      // device step counter or null -> s_imm
     float* out;            // reverse: x_{t-1} out ; invert: optional noise_pred out
     size_t numel;
-    int P, T, s_imm, v_pred, fix, has_noise;
+    int P, T, s_imm, v_pred, fix, has_noise, s_mul, s_off;
     float cfg_scalar;
     float c[8];
 };
@@ -215,7 +223,7 @@ __device__ __forceinline__ float cfg_combine(const StepParams& p, size_t e) {
 }
 
 __global__ __launch_bounds__(256) void invert_step_kernel(StepParams p) {
-    const int s = p.state ? p.state[0] : p.s_imm;
+    const int s = p.state ? p.state[0] * p.s_mul + p.s_off : p.s_imm;
     float c0, c1, c2, c3, c4;
     if (p.coef) { const float* c = p.coef + (size_t)s * AED_COEF_STRIDE; c0 = c[0]; c1 = c[1]; c2 = c[2]; c3 = c[3]; c4 = c[4]; }
     else { c0 = p.c[0]; c1 = p.c[1]; c2 = p.c[2]; c3 = p.c[3]; c4 = p.c[4]; }
@@ -243,7 +251,7 @@ __global__ __launch_bounds__(256) void invert_step_kernel(StepParams p) {
 }
 
 __global__ __launch_bounds__(256) void reverse_step_kernel(StepParams p) {
-    const int s = p.state ? p.state[0] : p.s_imm;
+    const int s = p.state ? p.state[0] * p.s_mul + p.s_off : p.s_imm;
     float c0, c1, c2, c3, c4;
     if (p.coef) { const float* c = p.coef + (size_t)s * AED_COEF_STRIDE; c0 = c[0]; c1 = c[1]; c2 = c[2]; c3 = c[3]; c4 = c[4]; }
     else { c0 = p.c[0]; c1 = p.c[1]; c2 = p.c[2]; c3 = p.c[3]; c4 = p.c[4]; }
@@ -264,7 +272,7 @@ __global__ __launch_bounds__(256) void reverse_step_kernel(StepParams p) {
 
 // slots (both): p0=xts base | xt   p1=zs base | z   p2=eps_u  p3=eps_c  p4=cfg  p5=coef table  p6=state  p7=out
 //   i0,i1=numel lo/hi  i2=P  i3=T (invert: #steps; reverse: #zs, 0 => p1 is the explicit z)  i4=s_imm
-//   i5=v_pred  i6=numerical_fix | has_noise   i7=explicit (invert: 1 => p0=xt and xtm1 given in f-less slot p7?)
+//   i5=v_pred  i6=numerical_fix | has_noise   i7=s_mul i8=s_off (step = state*s_mul + s_off; timestep-batched loops)
 //   f0=cfg_scalar  f1..f5 = c0..c4 immediates (used when p5 is null)
 static void fill_step(const aed_op* op, StepParams& p) {
     p.xts = (float*)op->p[0]; p.zs = (float*)op->p[1]; p.xtm1 = nullptr;
@@ -273,6 +281,7 @@ static void fill_step(const aed_op* op, StepParams& p) {
     p.numel = (size_t)(uint32_t)op->i[0] | ((size_t)(uint32_t)op->i[1] << 32);
     p.P = op->i[2]; p.T = op->i[3]; p.s_imm = op->i[4]; p.v_pred = op->i[5];
     p.fix = op->i[6]; p.has_noise = op->i[6];
+    p.s_mul = op->i[7] > 0 ? op->i[7] : 1; p.s_off = op->i[8];
     p.cfg_scalar = op->f[0];
     for (int k = 0; k < 5; ++k) p.c[k] = op->f[1 + k];
 }
@@ -302,6 +311,7 @@ extern "C" int aed_get_zs_from_xts(const float* xt, float* xtm1, const float* ep
                                    int v_prediction, int numerical_fix, float* z, float* noise_pred_out,
                                    int64_t numel, void* stream) {
     StepParams p = {};
+    p.s_mul = 1;
     p.xts = const_cast<float*>(xt); p.xtm1 = xtm1; p.zs = z; p.eps_u = eps_u; p.eps_c = eps_c; p.cfg = cfg;
     p.cfg_scalar = cfg_scalar; p.P = n_prompts; p.v_pred = v_prediction; p.fix = numerical_fix;
     p.out = noise_pred_out; p.numel = (size_t)numel;
@@ -317,6 +327,7 @@ extern "C" int aed_reverse_step_with_custom_noise(const float* xt, const float* 
                                                   const float* coef_host, int v_prediction, const float* z,
                                                   float* prev_out, int64_t numel, void* stream) {
     StepParams p = {};
+    p.s_mul = 1;
     p.xts = const_cast<float*>(xt); p.zs = const_cast<float*>(z); p.eps_u = eps_u; p.eps_c = eps_c; p.cfg = cfg;
     p.cfg_scalar = cfg_scalar; p.P = n_prompts; p.v_pred = v_prediction; p.has_noise = z != nullptr; p.T = 0;
     p.out = prev_out; p.numel = (size_t)numel;

@@ -68,24 +68,36 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
                                                         const float* __restrict__ beta, float* __restrict__ y,
                                                         int HW, int C, int G, int ldx, int ldy, int rpc, int nchunks,
                                                         float eps, int act) {
+    // rpc here is the APPLY slab height; nchunks the number of STATS partials per batch item.
+    __shared__ double red_s[256], red_ss[256];
     __shared__ float mean_s[64], rstd_s[64];
     const int tid = threadIdx.x;
     const int b = blockIdx.y, chunk = blockIdx.x;
-    if (tid < G) {
+    {   // all 256 threads reduce the partials: thread -> (group g, lane j of 256/G), strided over chunks
+        const int per = 256 / G;            // G in {8,16,32,64}
+        const int g = tid % G, j = tid / G;
         double s = 0.0, ss = 0.0;
-        const float* src = part + ((size_t)b * nchunks * G + tid) * 2;
-        for (int c = 0; c < nchunks; ++c) {
-            s += (double)src[(size_t)c * G * 2];
-            ss += (double)src[(size_t)c * G * 2 + 1];
+        if (j < per) {
+            const float* src = part + ((size_t)b * nchunks * G + g) * 2;
+            for (int c = j; c < nchunks; c += per) {
+                s += (double)src[(size_t)c * G * 2];
+                ss += (double)src[(size_t)c * G * 2 + 1];
+            }
         }
-        const double n = (double)HW * (double)(C / G);
-        const double mean = s / n;
-        double var = ss / n - mean * mean;
-        if (var < 0.0) var = 0.0;
-        mean_s[tid] = (float)mean;
-        rstd_s[tid] = (float)(1.0 / sqrt(var + (double)eps));
+        red_s[tid] = s;
+        red_ss[tid] = ss;
+        __syncthreads();
+        if (tid < G) {
+            for (int k = 1; k < per; ++k) { s += red_s[tid + k * G]; ss += red_ss[tid + k * G]; }
+            const double n = (double)HW * (double)(C / G);
+            const double mean = s / n;
+            double var = ss / n - mean * mean;
+            if (var < 0.0) var = 0.0;
+            mean_s[tid] = (float)mean;
+            rstd_s[tid] = (float)(1.0 / sqrt(var + (double)eps));
+        }
+        __syncthreads();
     }
-    __syncthreads();
     const int row0 = chunk * rpc;
     const int row1 = min(HW, row0 + rpc);
     const int Q = C >> 2;
@@ -126,12 +138,13 @@ int launch_gn_stats(const aed_op* op, hipStream_t s) {
     return 0;
 }
 
-// slots: p0=x p1=partials p2=gamma p3=beta p4=y ; i0..i6 as gn_stats, i7=act, i8=ldy ; f0=eps
+// slots: p0=x p1=partials p2=gamma p3=beta p4=y ; i0..i4 as gn_stats, i5=apply rows/block, i6=#stats partials,
+//        i7=act, i8=ldy, i9=#apply blocks per batch item ; f0=eps
 int launch_gn_apply(const aed_op* op, hipStream_t s) {
     const int32_t* i = op->i;
     AED_REQUIRE(op->p[0] && op->p[1] && op->p[2] && op->p[3] && op->p[4], "gn_apply: null pointer");
-    AED_REQUIRE(i[3] <= 64 && i[2] % (4 * i[3]) == 0, "gn_apply: C=%d G=%d", i[2], i[3]);
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(i[6], i[0]), dim3(256), 0, s, (const float*)op->p[0],
+    AED_REQUIRE(i[3] <= 64 && 256 % i[3] == 0 && i[2] % (4 * i[3]) == 0, "gn_apply: C=%d G=%d", i[2], i[3]);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(i[9], i[0]), dim3(256), 0, s, (const float*)op->p[0],
                        (const float*)op->p[1], (const float*)op->p[2], (const float*)op->p[3], (float*)op->p[4], i[1],
                        i[2], i[3], i[4], i[8], i[5], i[6], op->f[0], i[7]);
     AED_CHECK_HIP(hipGetLastError());

@@ -1,0 +1,345 @@
+"""Device-resident DDPM-inversion / edit loops (build-plan step 6).
+
+What the reference does per diffusion step (ddm_inversion/inversion_utils.py:74-129 and :221-315):
+two batch-1 U-Net calls, ~12 elementwise torch launches and a host<->device round trip
+(`int(t)` dict lookups, `alphas_cumprod[t]` indexing).  Here one step is ONE fixed sequence of
+native launches -- broadcast x_t into the cond/uncond slots, the U-Net op tape, the fused
+CFG + step-math kernel (K1), `advance` -- whose step-dependent data (timestep, scheduler
+coefficients, trajectory slices) is indexed ON THE DEVICE from a step counter.  The sequence is
+captured once in a hipGraph and replayed T times; the host never synchronises inside the loop.
+
+Batch layout of one U-Net call for n clips and P prompts:  [uncond x n | prompt0 x n | ... ].
+Latents are channels-last inside the engine ([.., H, W, C]); NCHW only at the API boundary.
+
+Two schedules for the forward inversion:
+  * "sequential" -- the reference's order: step k's U-Net input is the numerically-fixed
+    x_t written by step k-1;
+  * "batched"    -- G timesteps per U-Net call.  Legal because the edit-friendly inversion draws
+    every x_t independently from x_0 (models.py:67-83), so all U-Net inputs are known up front;
+    the only deviation is that x_t enters the U-Net before its ~1-ulp numerical fix
+    (models.py:114-115).  Measured deviation is reported by tests/bench; default is sequential.
+"""
+import math
+
+import torch
+
+from . import _lib as L
+from .scheduler import coefficient_table
+from .tape import Tape
+from .unet import PackedUNetWeights, UNetEngine
+
+PAD_BIAS = -1.0e30      # padding keys (beyond a sample's own context length): exp() underflows to exactly 0
+MASK_BIAS = -10000.0    # the reference's additive mask value (models.py:740-755)
+
+
+class Conditioning:
+    """Conditioning of ONE U-Net batch row group, already encoded (SURVEY A15 is outside the loop).
+
+    ehs0: [R, L0, d0] or None   (AudioLDM2: GPT-2 generated states; TANGO: T5 states)
+    ehs1: [R, L1, d1] or None   (AudioLDM2: T5 states)
+    mask0/mask1: [R, L] 0/1 or None
+    class_labels: [R, d] or None (AudioLDM-1 CLAP embedding)
+    """
+
+    def __init__(self, ehs0=None, ehs1=None, mask0=None, mask1=None, class_labels=None):
+        self.ehs0, self.ehs1, self.mask0, self.mask1, self.class_labels = ehs0, ehs1, mask0, mask1, class_labels
+
+    @property
+    def rows(self):
+        for t in (self.ehs0, self.ehs1, self.class_labels):
+            if t is not None:
+                return t.shape[0]
+        return 0
+
+    def repeat(self, n):
+        f = lambda t: None if t is None else t.repeat_interleave(n, 0) if t.shape[0] == 1 else t  # noqa: E731
+        return Conditioning(f(self.ehs0), f(self.ehs1), f(self.mask0), f(self.mask1), f(self.class_labels))
+
+
+def _pad_ctx(parts, L, attr_e, attr_m):
+    """Stack per-group context tensors of different lengths into [R, L, d] + additive bias [R, L]."""
+    es, bs = [], []
+    for c in parts:
+        e = getattr(c, attr_e)
+        m = getattr(c, attr_m)
+        r, l, d = e.shape
+        ep = torch.zeros(r, L, d, dtype=torch.float32)
+        ep[:, :l] = e.float().cpu()
+        b = torch.full((r, L), PAD_BIAS, dtype=torch.float32)
+        b[:, :l] = 0.0 if m is None else (1 - m.float().cpu()) * MASK_BIAS
+        es.append(ep)
+        bs.append(b)
+    return torch.cat(es, 0), torch.cat(bs, 0)
+
+
+class EditEngine:
+    def __init__(self, unet_cfg, weights, scheduler, device, H, W, kind):
+        self.cfg, self.sched, self.device = unet_cfg, scheduler, torch.device(device)
+        self.H, self.W, self.C = H, W, unet_cfg["in_channels"]
+        self.kind = kind
+        self.weights = weights if isinstance(weights, PackedUNetWeights) else PackedUNetWeights(weights, device)
+        self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        self._unets = {}
+        self.state = torch.zeros(4, dtype=torch.int32, device=self.device)
+        self.ts_dev = torch.zeros(scheduler.config.num_train_timesteps, dtype=torch.int64, device=self.device)
+
+    # ------------------------------------------------------------------ helpers
+    def unet(self, B, L0=0, L1=0):
+        key = (B, L0, L1)
+        if key not in self._unets:
+            self._unets[key] = UNetEngine(self.cfg, self.weights, self.device, B, self.H, self.W, ctx_len0=L0,
+                                          ctx_len1=L1, use_ehs=self.kind != "audioldm",
+                                          timesteps_dev=self.ts_dev, state_dev=self.state)
+        return self._unets[key]
+
+    def _set_cond(self, eng, groups):
+        """groups: list of Conditioning, concatenated along the batch in order."""
+        if self.kind == "audioldm":
+            eng.set_conditioning(class_labels=torch.cat([g.class_labels.float().cpu() for g in groups], 0))
+        elif self.kind == "audioldm2":
+            e0 = torch.cat([g.ehs0.float().cpu() for g in groups], 0)
+            e1, b1 = _pad_ctx(groups, eng.L1, "ehs1", "mask1")
+            eng.set_conditioning(ehs0=e0, ehs1=e1, bias1=b1)
+        else:
+            e0, b0 = _pad_ctx(groups, eng.L0, "ehs0", "mask0")
+            eng.set_conditioning(ehs0=e0, bias0=b0)
+
+    def _ctx_lens(self, groups):
+        if self.kind == "audioldm":
+            return 0, 0
+        if self.kind == "audioldm2":
+            return groups[0].ehs0.shape[1], max(g.ehs1.shape[1] for g in groups)
+        return max(g.ehs0.shape[1] for g in groups), 0
+
+    def to_nhwc(self, x):
+        """[..., C, H, W] -> contiguous [..., H, W, C] on the device (native transpose kernel)."""
+        lead = x.shape[:-3]
+        C, H, W = x.shape[-3:]
+        src = x.to(self.device, torch.float32).contiguous()
+        dst = torch.empty(*lead, H, W, C, device=self.device, dtype=torch.float32)
+        tp = Tape(self.device)
+        tp.transpose(src, dst, Bt=max(1, math.prod(lead)), R=C, C=H * W)
+        tp.run()
+        return dst
+
+    def to_nchw(self, x):
+        lead = x.shape[:-3]
+        H, W, C = x.shape[-3:]
+        src = x.contiguous()
+        dst = torch.empty(*lead, C, H, W, device=self.device, dtype=torch.float32)
+        tp = Tape(self.device)
+        tp.transpose(src, dst, Bt=max(1, math.prod(lead)), R=H * W, C=C)
+        tp.run()
+        return dst
+
+    def _run_graph(self, body, steps, use_graph=True):
+        """Run `body()` `steps` times on the engine stream; captured once and replayed."""
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev1 = torch.cuda.Event(enable_timing=True)
+            if use_graph and steps > 1:
+                g = Tape.graph_capture(body)
+                ev0.record(self.stream)
+                for _ in range(steps):
+                    Tape.graph_replay(g)
+                ev1.record(self.stream)
+                self._last_events = (ev0, ev1)
+                self.stream.synchronize()
+                L.check(L.lib().aed_graph_destroy(g), "aed_graph_destroy")
+            else:
+                ev0.record(self.stream)
+                for _ in range(steps):
+                    body()
+                ev1.record(self.stream)
+                self._last_events = (ev0, ev1)
+        cur.wait_stream(self.stream)
+
+    def last_loop_ms(self):
+        ev0, ev1 = self._last_events
+        ev1.synchronize()
+        return ev0.elapsed_time(ev1)
+
+    # ------------------------------------------------------------------ A6: sample_xts_from_x0
+    def sample_xts(self, x0, noise=None, generator=None):
+        """models.py:67-83.  x0 [n,C,H,W]; noise [T,n,C,H,W] (drawn here on the CPU generator in the
+        reference's order -- ascending t, one randn per step -- when not given).  Returns NCHW xts
+        [T+1, n, C, H, W] on the device."""
+        s = self.sched
+        T = s.num_inference_steps
+        x0 = x0.to(self.device, torch.float32).contiguous()
+        if noise is None:
+            noise = torch.stack([torch.randn(x0.shape, generator=generator, dtype=torch.float32) for _ in range(T)])
+        noise = noise.to(self.device, torch.float32).contiguous()
+        ts = s.timesteps.cpu()
+        abar = s.alphas_cumprod
+        # row r <-> idx = r+1 <-> t = timesteps[T - idx]
+        t_rows = torch.stack([ts[T - (r + 1)] for r in range(T)])
+        sa = (abar[t_rows] ** 0.5).to(self.device)
+        sb = ((1 - abar) ** 0.5)[t_rows].to(self.device)
+        xts = torch.empty((T + 1, *x0.shape), device=self.device, dtype=torch.float32)
+        xts[0] = x0
+        L.check(L.lib().aed_sample_xts_from_x0(x0.data_ptr(), noise.data_ptr(), sa.data_ptr(), sb.data_ptr(),
+                                                xts[1:].data_ptr(), T, x0.numel(), L.current_stream_ptr()),
+                "aed_sample_xts_from_x0")
+        return xts
+
+    # ------------------------------------------------------------------ A7: forward inversion
+    def invert(self, x0, cond_src, cond_uncond, cfg_src, eta=1.0, numerical_fix=True, noise=None, generator=None,
+               xts=None, cfg_tensor=None, mode="sequential", group=8, use_graph=True):
+        """inversion_forward_process (inversion_utils.py:8-144) for n clips.
+
+        x0 [n,C,H,W]; cond_src: Conditioning with n*P rows ordered [prompt0 x n, prompt1 x n, ...] or None
+        for an empty source prompt (cond pass skipped, inversion_utils.py:86); cond_uncond: 1 or n rows.
+        Returns (zs, xts) channels-last on the device: zs [T,n,H,W,C], xts [T+1,n,H,W,C]."""
+        s = self.sched
+        T = s.num_inference_steps
+        n = x0.shape[0]
+        numel = n * self.C * self.H * self.W
+        if xts is None:
+            xts = self.sample_xts(x0, noise, generator)
+        xts = self.to_nhwc(xts)                                   # [T+1, n, H, W, C]
+        zs = torch.zeros((T, n, self.H, self.W, self.C), device=self.device, dtype=torch.float32)
+        P = 0 if cond_src is None else cond_src.rows // n
+        groups = [cond_uncond.repeat(n)] + ([cond_src] if P else [])
+        coef = coefficient_table(s, s.timesteps.cpu(), eta=eta, kind="ddpm").to(self.device)
+        self.ts_dev[:T] = s.timesteps.to(self.device)
+        v_pred = int(s.config.prediction_type == "v_prediction")
+        cfgt = None if cfg_tensor is None else self.to_nhwc(cfg_tensor.reshape(P, n, self.C, self.H, self.W)).contiguous()
+        scalar = float(cfg_src[0]) if (cfg_tensor is None and P) else 1.0
+
+        G = 1 if mode == "sequential" else max(1, min(group, T))
+        while T % G:
+            G -= 1
+        rows_per_t = n * (1 + P)
+        L0, L1 = self._ctx_lens(groups)
+        eng = self.unet(G * rows_per_t, L0, L1)
+        # batch rows: for g in G: [uncond x n | prompt_p x n ...]
+        self._set_cond(eng, [c for _ in range(G) for c in groups])
+        pre, post = Tape(self.device), Tape(self.device)
+        for g in range(G):
+            for blk in range(1 + P):
+                dst = eng.x_in[(g * (1 + P) + blk) * n:(g * (1 + P) + blk + 1) * n]
+                pre.copy2d(xts, dst, rows=1, cols=numel, ld_src=numel, ld_dst=numel, state=self.state,
+                           idx_off=T - g, idx_mul=-G, idx_stride=numel, name="x_in<-xts")
+        self._patch_time(eng, self.ts_dev, G, rows_per_t)
+        for g in range(G):
+            base = g * rows_per_t
+            eps_u = eng.eps[base:base + n]
+            eps_c = eng.eps[base + n:base + rows_per_t] if P else None
+            post.step(L.OP_INVERT_STEP, xts=xts, zs=zs, eps_u=eps_u, eps_c=eps_c, cfg=cfgt, coef=coef,
+                      state=self.state, out=None, numel=numel, P=max(P, 1), T=T, v_pred=v_pred,
+                      flag=int(numerical_fix), cfg_scalar=scalar, s_mul=G, s_off=g)
+        post.advance(self.state)
+        self.state.zero_()
+
+        pre.finalize()
+        post.finalize()
+
+        def body():
+            pre.run()
+            eng.tape.run()
+            post.run()
+        self._run_graph(body, T // G, use_graph)
+        zs[0].zero_()                                              # inversion_utils.py:131-133
+        return zs, xts
+
+    def _patch_time(self, eng, ts_dev, G, rows_per_t, offset=0):
+        """Point the U-Net's time-embedding op at (table + offset) with G timesteps per call."""
+        op = eng.tape.ops[eng.time_op]
+        arr = eng.tape.finalize()
+        ridx = torch.arange(eng.B, dtype=torch.int32) // max(1, rows_per_t)
+        eng._row_tidx = ridx.to(self.device)
+        for o in (op, arr[eng.time_op]):
+            o.p[1] = ts_dev.data_ptr() + 8 * offset
+            o.p[2] = self.state.data_ptr()
+            o.p[4] = eng._row_tidx.data_ptr()
+            o.i[5] = G
+
+    # ------------------------------------------------------------------ A11: reverse / edit
+    def edit(self, xts, zs, tstart, cond_tgt, cond_neg, cfg_tar, eta=1.0, cfg_tensor=None, use_graph=True,
+             table_kind="ddpm"):
+        """inversion_reverse_process (inversion_utils.py:147-323) from x_{tstart}, noise maps zs[:tstart].
+        xts/zs channels-last as returned by invert().  Returns the edited latent [n,H,W,C]."""
+        s = self.sched
+        T = s.num_inference_steps
+        n = xts.shape[1]
+        numel = n * self.C * self.H * self.W
+        Z = int(tstart)
+        P = cond_tgt.rows // n
+        groups = [cond_neg.repeat(n), cond_tgt]
+        ts = s.timesteps.cpu()[T - Z:]
+        coef = coefficient_table(s, ts, eta=eta, kind=table_kind).to(self.device)
+        self.ts_dev[:T] = s.timesteps.to(self.device)
+        v_pred = int(s.config.prediction_type == "v_prediction")
+        cfgt = None if cfg_tensor is None else self.to_nhwc(cfg_tensor.reshape(P, n, self.C, self.H, self.W)).contiguous()
+        scalar = float(cfg_tar[0]) if cfg_tensor is None else 1.0
+        L0, L1 = self._ctx_lens(groups)
+        eng = self.unet(n * (1 + P), L0, L1)
+        self._set_cond(eng, groups)
+        cur = xts[Z].clone()                                       # inversion_utils.py:203
+        zs_used = zs[:Z].contiguous() if zs is not None else None
+        pre, post = Tape(self.device), Tape(self.device)
+        for blk in range(1 + P):
+            pre.copy2d(cur, eng.x_in[blk * n:(blk + 1) * n], rows=1, cols=numel, ld_src=numel, ld_dst=numel,
+                       name="x_in<-x_t")
+        self._patch_time(eng, self.ts_dev, 1, n * (1 + P), offset=T - Z)
+        post.step(L.OP_REVERSE_STEP, xts=cur, zs=zs_used, eps_u=eng.eps[:n], eps_c=eng.eps[n:], cfg=cfgt, coef=coef,
+                  state=self.state, out=cur, numel=numel, P=P, T=Z, v_pred=v_pred,
+                  flag=int(eta > 0 and zs_used is not None), cfg_scalar=scalar)
+        post.advance(self.state)
+        self.state.zero_()
+
+        pre.finalize()
+        post.finalize()
+
+        def body():
+            pre.run()
+            eng.tape.run()
+            post.run()
+        self._run_graph(body, Z, use_graph)
+        return cur
+
+    # ------------------------------------------------------------------ A16: DDIM baseline
+    def ddim_invert(self, w0, cond_src, cond_uncond, cfg_scale, skip=0, use_graph=True):
+        """ddim_inversion (ddim_inversion.py:44-56): deterministic, ascending t.  w0 [n,C,H,W] -> [n,H,W,C]."""
+        s = self.sched
+        T = s.num_inference_steps
+        n = w0.shape[0]
+        numel = n * self.C * self.H * self.W
+        steps = T - skip
+        ts_asc = torch.flip(s.timesteps.cpu(), dims=[0])[:steps]
+        coef = coefficient_table(s, ts_asc, kind="ddim_next").to(self.device)
+        self.ts_dev[:steps] = ts_asc.to(self.device)
+        groups = [cond_uncond.repeat(n), cond_src]
+        L0, L1 = self._ctx_lens(groups)
+        eng = self.unet(2 * n, L0, L1)
+        self._set_cond(eng, groups)
+        cur = self.to_nhwc(w0).contiguous()
+        pre, post = Tape(self.device), Tape(self.device)
+        for blk in range(2):
+            pre.copy2d(cur, eng.x_in[blk * n:(blk + 1) * n], rows=1, cols=numel, ld_src=numel, ld_dst=numel)
+        self._patch_time(eng, self.ts_dev, 1, 2 * n)
+        post.step(L.OP_REVERSE_STEP, xts=cur, zs=None, eps_u=eng.eps[:n], eps_c=eng.eps[n:], cfg=None, coef=coef,
+                  state=self.state, out=cur, numel=numel, P=1, T=0, flag=0, cfg_scalar=float(cfg_scale))
+        post.advance(self.state)
+        self.state.zero_()
+
+        pre.finalize()
+        post.finalize()
+
+        def body():
+            pre.run()
+            eng.tape.run()
+            post.run()
+        self._run_graph(body, steps, use_graph)
+        return cur
+
+    def ddim_sample(self, xt, cond_tgt, cond_uncond, guidance_scale, skip=0, use_graph=True):
+        """text2image_ldm_stable (ddim_inversion.py:59-84): scheduler.step(eta=0) from timesteps[skip:]."""
+        s = self.sched
+        T = s.num_inference_steps
+        xts_like = xt.unsqueeze(0).expand(T - skip + 1, *xt.shape)
+        return self.edit(xts_like, None, T - skip, cond_tgt, cond_uncond, [guidance_scale], eta=0.0,
+                         use_graph=use_graph, table_kind="ddim_prev")

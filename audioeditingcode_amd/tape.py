@@ -126,15 +126,18 @@ class Tape:
     def groupnorm(self, x, gamma, beta, out, *, B, HW, C, G=32, eps=1e-5, act=0, name="gn"):
         ldx = x.stride(-2)
         ldy = out.stride(-2)
-        target = max(1, (2 * CU_COUNT) // max(1, B))
-        rpc = max(1, math.ceil(HW / target))
-        rpc = max(rpc, 4)
-        nchunks = math.ceil(HW / rpc)
-        part = self.alloc(B, nchunks, G, 2)
+        # stats: <=32 coarse slabs per batch item (few partials to re-reduce);
+        # apply: fine slabs for parallelism (~2 blocks per CU)
+        s_rpc = max(4, math.ceil(HW / 32))
+        s_chunks = math.ceil(HW / s_rpc)
+        a_target = max(1, (2 * CU_COUNT) // max(1, B))
+        a_rpc = max(4, math.ceil(HW / a_target))
+        a_chunks = math.ceil(HW / a_rpc)
+        part = self.alloc(B, s_chunks, G, 2)
         nb = 4 * B * HW * C
-        self._add(L.OP_GN_STATS, [B, HW, C, G, ldx, rpc, nchunks], [], [x, part], name=name + ".stats", nbytes=nb)
-        self._add(L.OP_GN_APPLY, [B, HW, C, G, ldx, rpc, nchunks, act, ldy], [eps], [x, part, gamma, beta, out],
-                  name=name + ".apply", nbytes=2 * nb)
+        self._add(L.OP_GN_STATS, [B, HW, C, G, ldx, s_rpc, s_chunks], [], [x, part], name=name + ".stats", nbytes=nb)
+        self._add(L.OP_GN_APPLY, [B, HW, C, G, ldx, a_rpc, s_chunks, act, ldy, a_chunks], [eps],
+                  [x, part, gamma, beta, out], name=name + ".apply", nbytes=2 * nb)
         return out
 
     def layernorm(self, x, gamma, beta, out, *, M, C, eps=1e-5, name="ln"):
@@ -154,18 +157,40 @@ class Tape:
         self._add(L.OP_GEGLU, [M, Dff, h.stride(-2), out.stride(-2)], [], [h, out], name=name, nbytes=12 * M * Dff)
         return out
 
-    def copy2d(self, src, dst, *, rows, cols, ld_src=None, ld_dst=None, name="copy"):
+    def copy2d(self, src, dst, *, rows, cols, ld_src=None, ld_dst=None, state=None, idx_off=0, idx_mul=0,
+               idx_stride=0, name="copy"):
+        """dst[r, :cols] = src[r, :cols]; with `state`, src is first advanced by
+        (idx_off + idx_mul*state[0]) * idx_stride elements on the device (trajectory walk)."""
         ld_src = src.stride(-2) if ld_src is None else ld_src
         ld_dst = dst.stride(-2) if ld_dst is None else ld_dst
-        self._add(L.OP_COPY2D, [rows, cols, ld_src, ld_dst], [], [src, dst], name=name, nbytes=8 * rows * cols)
+        self._add(L.OP_COPY2D, [rows, cols, ld_src, ld_dst, idx_off, idx_mul, idx_stride], [], [src, dst, state],
+                  name=name, nbytes=8 * rows * cols)
         return dst
+
+    @staticmethod
+    def graph_capture(fn):
+        """Capture everything `fn()` launches on the current stream (may run several tapes)."""
+        lib = L.lib()
+        sp = L.current_stream_ptr()
+        L.check(lib.aed_graph_begin(sp), "aed_graph_begin")
+        try:
+            fn()
+        finally:
+            g = ctypes.c_void_p()
+            rc = lib.aed_graph_end(sp, ctypes.byref(g))
+        L.check(rc, "aed_graph_end")
+        return g
+
+    @staticmethod
+    def graph_replay(g):
+        L.check(L.lib().aed_graph_launch(g, L.current_stream_ptr()), "aed_graph_launch")
 
     def time_embed(self, out, *, B, dim, flip=True, shift=0.0, timesteps=None, state=None, t_imm=0, name="time_embed"):
         half = dim // 2
         exponent = -math.log(10000) * torch.arange(half, dtype=torch.float32) / (half - shift)
         freqs = torch.exp(exponent).to(self.device)
-        self._add(L.OP_TIME_EMBED, [B, dim, int(flip), out.stride(-2), t_imm], [shift, 10000.0],
-                  [out, timesteps, state, freqs], name=name)
+        self._add(L.OP_TIME_EMBED, [B, dim, int(flip), out.stride(-2), t_imm, 1], [shift, 10000.0],
+                  [out, timesteps, state, freqs, None], name=name)
         return out
 
     def softmax_rows(self, x, out, *, rows, cols, scale=1.0, name="softmax"):
@@ -190,8 +215,9 @@ class Tape:
         self._add(L.OP_ADVANCE, [by], [], [state], name="advance")
 
     def step(self, code, *, xts, zs, eps_u, eps_c, cfg, coef, state, out, numel, P, T, s_imm=0, v_pred=0, flag=1,
-             cfg_scalar=1.0, c_imm=(0, 0, 0, 0, 0), name="step"):
-        self._add(code, [numel & 0xFFFFFFFF, numel >> 32, P, T, s_imm, v_pred, flag], [cfg_scalar, *c_imm],
+             cfg_scalar=1.0, c_imm=(0, 0, 0, 0, 0), s_mul=1, s_off=0, name="step"):
+        self._add(code, [numel & 0xFFFFFFFF, numel >> 32, P, T, s_imm, v_pred, flag, s_mul, s_off],
+                  [cfg_scalar, *c_imm],
                   [xts, zs, eps_u, eps_c, cfg, coef, state, out], name=name, nbytes=4 * numel * 6)
 
     def reflect_pad(self, src, dst, *, B, N, pad, ldd, name="reflect_pad"):

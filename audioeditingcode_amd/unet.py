@@ -23,25 +23,20 @@ from .tape import Tape
 from .weights import ctx_dims_per_block, _per_block
 
 
-class UNetEngine:
-    def __init__(self, cfg, sd, device, batch, H, W, ctx_len0=0, ctx_len1=0, use_ehs=True,
-                 timesteps_dev=None, state_dev=None):
-        self.cfg = cfg
+class PackedUNetWeights:
+    """Device-resident, engine-layout copy of a diffusers-named U-Net state dict (shared by every
+    UNetEngine built for the same model: batch shapes differ, weights do not)."""
+
+    def __init__(self, sd, device):
         self.device = torch.device(device)
-        self.B, self.H, self.W = batch, H, W
-        self.use_ehs = use_ehs
-        self.L0, self.L1 = ctx_len0, ctx_len1
-        self.timesteps_dev, self.state_dev = timesteps_dev, state_dev
-        self.tape = Tape(device)
-        self.ctx_tape = Tape(device)
-        self._tmp = {}
         self.wd = {}
         self._pack(sd)
-        self._build()
 
-    # ------------------------------------------------------------------ weights
     def _dev(self, t):
-        return self.tape.hold(t.contiguous().to(self.device, torch.float32))
+        return t.contiguous().to(self.device, torch.float32)
+
+    def nbytes(self):
+        return sum(v.numel() * 4 for v in self.wd.values())
 
     def _pack(self, sd):
         """Re-lay weights: conv [O,I,kh,kw] -> [O, kh*kw*I]; fuse q/k/v; concatenate temb projections."""
@@ -74,6 +69,25 @@ class UNetEngine:
             if k.endswith(".to_k.weight") or k.endswith(".to_v.weight"):
                 continue
             wd[k] = self._dev(v)
+
+
+class UNetEngine:
+    def __init__(self, cfg, weights, device, batch, H, W, ctx_len0=0, ctx_len1=0, use_ehs=True,
+                 timesteps_dev=None, state_dev=None):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.B, self.H, self.W = batch, H, W
+        self.use_ehs = use_ehs
+        self.L0, self.L1 = ctx_len0, ctx_len1
+        self.timesteps_dev, self.state_dev = timesteps_dev, state_dev
+        self.tape = Tape(device)
+        self.ctx_tape = Tape(device)
+        self._tmp = {}
+        if not isinstance(weights, PackedUNetWeights):
+            weights = PackedUNetWeights(weights, device)
+        self.weights = weights
+        self.wd, self.temb_off, self.temb_total = weights.wd, weights.temb_off, weights.temb_total
+        self._build()
 
     def tmp(self, tag, *shape):
         key = (tag, tuple(shape))

@@ -71,6 +71,8 @@ def family_of(model_id):
 
 
 def get_family(model_id):
+    if model_id.startswith("tiny/"):          # reduced-width twins for tests: "tiny/audioldm2", ...
+        return tiny_family(family_of(model_id))
     fam = copy.deepcopy(FAMILIES[family_of(model_id)])
     # the -m- / -l- AudioLDM variants widen the U-Net (audioldm/utils.py:195-200)
     if family_of(model_id) == "audioldm":

@@ -1,0 +1,248 @@
+"""Edit-friendly DDPM inversion + edit, same call signatures as the reference's
+code/ddm_inversion/inversion_utils.py (inversion_forward_process :8-144, inversion_reverse_process :147-323).
+
+Two execution paths, both entirely on HIP kernels:
+  * fast path (default): the device-resident hipGraph loops of editing.EditEngine;
+  * hook path: when the caller asks for h-space / skip-connection taps or replacements, or prompts
+    have unequal `tstart` (multi-prompt trajectory blend), the loop is driven step by step through the
+    wrapper's own methods exactly like the reference does.
+"""
+from typing import Dict, List, Optional, Tuple, Union
+
+import torch
+
+from ..editing import Conditioning
+
+
+def gaussian_blur(x, kernel_size=15, sigma=1.0):
+    """torchvision.transforms.functional.gaussian_blur restated (reflect pad, separable normalised kernel);
+    used only to soften multi-prompt segment masks (inversion_utils.py:49,197-198)."""
+    half = (kernel_size - 1) * 0.5
+    g = torch.linspace(-half, half, kernel_size)
+    pdf = torch.exp(-0.5 * (g / sigma) ** 2)
+    k1 = pdf / pdf.sum()
+    k2 = (k1[:, None] * k1[None, :]).to(x.dtype)
+    c = x.shape[-3]
+    pad = kernel_size // 2
+    xp = torch.nn.functional.pad(x, (pad, pad, pad, pad), mode="reflect")
+    return torch.nn.functional.conv2d(xp, k2.expand(c, 1, kernel_size, kernel_size), groups=c)
+
+
+def _segment_tensors(batch_size, shape, cfg_scales, cutoff_points, dtype, prompts=None):
+    """cfg-scale and mask tensors of inversion_utils.py:29-51 / :177-200 (host side, once per call)."""
+    cfg = torch.ones((batch_size, *shape), dtype=dtype)
+    masks = torch.ones((batch_size, *shape), dtype=dtype)
+    if batch_size > 1:
+        if cutoff_points is None:
+            cutoff_points = [i * 1 / batch_size for i in range(1, batch_size)]
+        if len(cfg_scales) == 1:
+            cfg_scales = list(cfg_scales) * batch_size
+        elif len(cfg_scales) < batch_size:
+            raise ValueError("Not enough target CFG scales")
+        cuts = [0, *[int(x * cfg.shape[2]) for x in cutoff_points], cfg.shape[2]]
+        for i, (start, end) in enumerate(zip(cuts[:-1], cuts[1:])):
+            cfg[i, :, end:] = 0
+            cfg[i, :, :start] = 0
+            masks[i, :, end:] = 0
+            masks[i, :, :start] = 0
+            cfg[i] *= cfg_scales[i]
+            if prompts is not None and prompts[i] == "":
+                cfg[i] = 0
+        cfg = gaussian_blur(cfg, kernel_size=15, sigma=1)
+        masks = gaussian_blur(masks, kernel_size=15, sigma=1)
+    else:
+        cfg *= cfg_scales[0]
+    return cfg, masks
+
+
+def conditioning_from_text(model, triple):
+    """Wrap encode_text's (hidden_states, class_labels, mask) triple for the loop engine."""
+    hs, cl, mask = triple
+    if model.kind == "audioldm2":
+        return Conditioning(ehs0=hs, ehs1=cl, mask1=mask)
+    if model.kind == "audioldm":
+        return Conditioning(class_labels=cl)
+    return Conditioning(ehs0=hs, mask0=mask)
+
+
+def inversion_forward_process(model, x0: torch.Tensor, etas: Optional[float] = None, prog_bar: bool = False,
+                              prompts: List[str] = [""], cfg_scales: List[float] = [3.5],
+                              num_inference_steps: int = 50, cutoff_points: Optional[List[float]] = None,
+                              numerical_fix: bool = False, extract_h_space: bool = False,
+                              extract_skipconns: bool = False, duration: Optional[float] = None,
+                              first_order: bool = False, schedule: str = "sequential",
+                              timestep_group: int = 8) -> Tuple:
+    if len(prompts) > 1 and extract_h_space:
+        raise NotImplementedError("How do you split cfg_scales for hspace? TODO")
+    if extract_h_space or extract_skipconns:
+        return _forward_with_taps(model, x0, etas, prompts, cfg_scales, num_inference_steps, cutoff_points,
+                                  numerical_fix, extract_h_space, extract_skipconns)
+    has_src = len(prompts) > 1 or prompts[0] != ""
+    sched = model.model.scheduler
+    if type(etas) in [int, float]:
+        etas = [etas] * sched.num_inference_steps
+    eta = float(etas[0]) if etas is not None else 0.0
+    if etas is not None and any(float(e) != eta for e in etas):
+        raise NotImplementedError("per-step eta schedules: the native loop takes one eta")
+    cond_src, cfg_tensor = None, None
+    P = len(prompts)
+    if has_src:
+        cond_src = conditioning_from_text(model, model.encode_text(prompts))
+        if P > 1:
+            cfg_tensor, _ = _segment_tensors(P, x0.shape[1:], cfg_scales, cutoff_points, x0.dtype, prompts)
+    cond_unc = conditioning_from_text(model, model.encode_text([""], negative=True))
+    ed = model.editor(x0.shape[-2], x0.shape[-1])
+    xts0 = model.sample_xts_from_x0(x0, num_inference_steps=num_inference_steps).unsqueeze(1)
+    zs, xts = ed.invert(x0, cond_src, cond_unc, cfg_scales, eta=eta, numerical_fix=numerical_fix, xts=xts0,
+                        cfg_tensor=cfg_tensor, mode=schedule, group=timestep_group)
+    zs_n = ed.to_nchw(zs)[:, 0]
+    xts_n = ed.to_nchw(xts)[:, 0]
+    xt = xts_n[1][None]
+    return xt, zs_n, xts_n, [None] * len(zs_n)
+
+
+def _forward_with_taps(model, x0, etas, prompts, cfg_scales, T, cutoff_points, numerical_fix, extract_h_space,
+                       extract_skipconns):
+    """Step-by-step variant that returns h-space / skip taps (inversion_utils.py:103-121)."""
+    has_src = len(prompts) > 1 or prompts[0] != ""
+    sched = model.model.scheduler
+    if type(etas) in [int, float]:
+        etas = [etas] * sched.num_inference_steps
+    if has_src:
+        hs, cl, mk = model.encode_text(prompts)
+        cfg_t, _ = _segment_tensors(len(prompts), x0.shape[1:], cfg_scales, cutoff_points, x0.dtype, prompts)
+        cfg_t = cfg_t.to(model.device)
+    uhs, ucl, umk = model.encode_text([""], negative=True)
+    timesteps = sched.timesteps
+    xts = model.sample_xts_from_x0(x0, num_inference_steps=T)
+    zs = torch.zeros(size=model.get_noise_shape(x0, T), device=model.device)
+    t_to_idx = {int(v): k for k, v in enumerate(timesteps)}
+    hspaces, skipconns = [], []
+    xt = x0
+    for t in timesteps:
+        idx = T - t_to_idx[int(t)] - 1
+        xt = xts[idx + 1][None]
+        out, out_h, out_s = model.unet_forward(xt, timestep=t, encoder_hidden_states=uhs, class_labels=ucl,
+                                               encoder_attention_mask=umk)
+        if has_src:
+            cout, cout_h, cout_s = model.unet_forward(xt.expand(len(prompts), -1, -1, -1), timestep=t,
+                                                      encoder_hidden_states=hs, class_labels=cl,
+                                                      encoder_attention_mask=mk)
+            noise_pred = out.sample + (cfg_t * (cout.sample - out.sample.expand(len(prompts), -1, -1, -1))
+                                       ).sum(axis=0).unsqueeze(0)
+            noise_h = out_h + cfg_scales[0] * (cout_h - out_h)
+            noise_s = {k: [out_s[k][j] + cfg_scales[0] * (cout_s[k][j] - out_s[k][j]) for j in range(len(out_s[k]))]
+                       for k in out_s} if extract_skipconns else None
+        else:
+            noise_pred, noise_h, noise_s = out.sample, out_h, out_s
+        hspaces.append(noise_h)
+        if extract_skipconns:
+            skipconns.append(noise_s)
+        z, xtm1, _ = model.get_zs_from_xts(xt, xts[idx][None], noise_pred, t, eta=etas[idx],
+                                           numerical_fix=numerical_fix)
+        zs[idx] = z
+        xts[idx] = xtm1
+    zs[0] = torch.zeros_like(zs[0])
+    hspaces = torch.concat(hspaces, axis=0)
+    if extract_h_space:
+        return xt, zs, xts, [None] * len(zs), hspaces
+    return xt, zs, xts, [None] * len(zs), hspaces, skipconns
+
+
+def inversion_reverse_process(model, xT: torch.Tensor, tstart: torch.Tensor, fix_alpha: float = 0.1,
+                              etas: float = 0, prompts: List[str] = [""], neg_prompts: List[str] = [""],
+                              cfg_scales: Optional[List[float]] = None, prog_bar: bool = False,
+                              zs: Optional[torch.Tensor] = None, cutoff_points: Optional[List[float]] = None,
+                              hspace_add: Optional[torch.Tensor] = None,
+                              hspace_replace: Optional[torch.Tensor] = None,
+                              skipconns_replace: Optional[Dict[int, torch.Tensor]] = None,
+                              zero_out_resconns: Optional[Union[int, List]] = None, extract_h_space: bool = False,
+                              extract_skipconns: bool = False, duration: Optional[float] = None,
+                              first_order: bool = False, extra_info: Optional[List] = None) -> Tuple:
+    batch_size = len(prompts)
+    tstart = torch.as_tensor(tstart).reshape(-1).cpu()
+    hooks = any(v is not None for v in (hspace_add, hspace_replace, skipconns_replace, zero_out_resconns)) \
+        or extract_h_space or extract_skipconns
+    uneven = bool((tstart.max() - tstart).any())
+    sched = model.model.scheduler
+    if etas is None:
+        etas = 0
+    if type(etas) in [int, float]:
+        etas = [etas] * sched.num_inference_steps
+    assert len(etas) == sched.num_inference_steps
+    if hooks or uneven:
+        return _reverse_with_hooks(model, xT, tstart, fix_alpha, etas, prompts, neg_prompts, cfg_scales, zs,
+                                   cutoff_points, hspace_add, hspace_replace, skipconns_replace, zero_out_resconns,
+                                   extract_h_space, extract_skipconns)
+    eta = float(etas[0])
+    cond_tgt = conditioning_from_text(model, model.encode_text(prompts))
+    cond_neg = conditioning_from_text(model, model.encode_text(neg_prompts, negative=True))
+    cfg_tensor = None
+    if batch_size > 1:
+        cfg_tensor, _ = _segment_tensors(batch_size, xT.shape[1:], cfg_scales, cutoff_points, xT.dtype)
+    ed = model.editor(xT.shape[-2], xT.shape[-1])
+    Z = zs.shape[0]
+    xts_c = ed.to_nhwc(xT.unsqueeze(1))
+    zs_c = ed.to_nhwc(zs.unsqueeze(1))
+    w = ed.edit(xts_c, zs_c, Z, cond_tgt, cond_neg, cfg_scales, eta=eta, cfg_tensor=cfg_tensor)
+    return ed.to_nchw(w), zs
+
+
+def _reverse_with_hooks(model, xT, tstart, fix_alpha, etas, prompts, neg_prompts, cfg_scales, zs, cutoff_points,
+                        hspace_add, hspace_replace, skipconns_replace, zero_out_resconns, extract_h_space,
+                        extract_skipconns):
+    """Step-by-step reverse process with the reference's hooks and multi-prompt trajectory blend
+    (inversion_utils.py:221-315)."""
+    batch_size = len(prompts)
+    sched = model.model.scheduler
+    hs, cl, mk = model.encode_text(prompts)
+    uhs, ucl, umk = model.encode_text(neg_prompts, negative=True)
+    cfg_t, masks = _segment_tensors(batch_size, xT.shape[1:], cfg_scales, cutoff_points, xT.dtype)
+    cfg_t, masks = cfg_t.to(model.device), masks.to(model.device)
+    xt = xT[tstart.max()].unsqueeze(0)
+    Z = zs.shape[0]
+    timesteps = sched.timesteps[-Z:]
+    t_to_idx = {int(v): k for k, v in enumerate(timesteps)}
+    hspaces, skipconns = [], []
+
+    def pick(v, it, unsq=False):
+        if v is None:
+            return None
+        if hasattr(v, "shape") and v.shape[0] > 1:
+            r = v[-Z:][it]
+            return r.unsqueeze(0) if unsq else r
+        return v
+    for it, t in enumerate(timesteps):
+        idx = sched.num_inference_steps - t_to_idx[int(t)] - (sched.num_inference_steps - Z + 1)
+        add = pick(hspace_add, it)
+        kw = dict(replace_h_space=pick(hspace_replace, it, unsq=True), zero_out_resconns=zero_out_resconns,
+                  replace_skip_conns=(None if skipconns_replace is None else
+                                      (skipconns_replace[-Z:][it] if len(skipconns_replace) > 1
+                                       else skipconns_replace)))
+        uo, uo_h, uo_s = model.unet_forward(xt, timestep=t, encoder_hidden_states=uhs, class_labels=ucl,
+                                            encoder_attention_mask=umk,
+                                            mid_block_additional_residual=None if add is None else
+                                            (1 / (cfg_scales[0] + 1)) * add, **kw)
+        co, co_h, co_s = model.unet_forward(xt.expand(batch_size, -1, -1, -1), timestep=t, encoder_hidden_states=hs,
+                                            class_labels=cl, encoder_attention_mask=mk,
+                                            mid_block_additional_residual=None if add is None else
+                                            (cfg_scales[0] / (cfg_scales[0] + 1)) * add, **kw)
+        noise_pred = uo.sample + (cfg_t * (co.sample - uo.sample.expand(batch_size, -1, -1, -1))
+                                  ).sum(axis=0).unsqueeze(0)
+        if extract_h_space or extract_skipconns:
+            hspaces.append(uo_h + cfg_scales[0] * (co_h - uo_h))
+        if extract_skipconns:
+            skipconns.append({k: [uo_s[k][j] + cfg_scales[0] * (co_s[k][j] - uo_s[k][j])
+                                  for j in range(len(uo_s[k]))] for k in uo_s})
+        z = zs[idx].unsqueeze(0)
+        xt = model.reverse_step_with_custom_noise(noise_pred, t, xt, variance_noise=z, eta=etas[idx])
+        apply_fix = ((tstart.max() - tstart) > it)
+        if apply_fix.any():
+            af = (apply_fix * fix_alpha).unsqueeze(1).unsqueeze(2).unsqueeze(3).to(xT.device)
+            xt = (masks * (xt.expand(batch_size, -1, -1, -1) * (1 - af)
+                           + af * xT[tstart.max() - it - 1].expand(batch_size, -1, -1, -1))).sum(axis=0).unsqueeze(0)
+    if extract_h_space:
+        return xt, zs, torch.concat(hspaces, axis=0)
+    if extract_skipconns:
+        return xt, zs, torch.concat(hspaces, axis=0), skipconns
+    return xt, zs

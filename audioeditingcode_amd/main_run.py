@@ -1,0 +1,78 @@
+"""Text-based edit CLI: the call pattern of the reference's code/main_run.py (:113-185), on the native path.
+
+python -m audioeditingcode_amd.main_run --init_aud clip.wav --source_prompt "..." --target_prompt "..." \
+       --model_id cvssp/audioldm2-music --tstart 100 --num_diffusion_steps 200
+Without --init_aud a synthetic 10 s clip is edited (no dataset exists in this container)."""
+import argparse
+import os
+import time
+
+import torch
+
+from .ddm_inversion.ddim_inversion import ddim_inversion, text2image_ldm_stable
+from .ddm_inversion.inversion_utils import inversion_forward_process, inversion_reverse_process
+from .models import load_model
+from .utils import load_audio, set_reproducability, synthetic_clip, write_wav
+
+
+def edit_clip(ldm_stable, x0, source_prompt, target_prompt, target_neg_prompt, cfg_src, cfg_tar, T, tstart,
+              mode="ours", eta=1.0, schedule="sequential", timestep_group=8):
+    """main_run.py:117-185 for one mel `x0` [1,1,T_mel,64]: returns (edited waveform, original-vocoded waveform)."""
+    with torch.inference_mode():
+        w0 = ldm_stable.vae_encode(x0)
+        if mode == "ddim":
+            skip = T - tstart
+            wT = ddim_inversion(ldm_stable, w0, source_prompt, cfg_src[0], num_inference_steps=T, skip=skip)
+            w_edit = text2image_ldm_stable(ldm_stable, target_prompt, T, cfg_tar[0], wT, skip=skip)
+        else:
+            _, zs, wts, _ = inversion_forward_process(ldm_stable, w0, etas=eta, prompts=source_prompt,
+                                                      cfg_scales=cfg_src, num_inference_steps=T, numerical_fix=True,
+                                                      schedule=schedule, timestep_group=timestep_group)
+            w_edit, _ = inversion_reverse_process(ldm_stable, xT=wts, tstart=torch.tensor([tstart]), etas=eta,
+                                                  prompts=target_prompt, neg_prompts=target_neg_prompt,
+                                                  cfg_scales=cfg_tar, zs=zs[:tstart])
+        x0_dec = ldm_stable.vae_decode(w_edit)
+        if x0_dec.dim() < 4:
+            x0_dec = x0_dec[None, :, :, :]
+        audio = ldm_stable.decode_to_mel(x0_dec)
+        orig_audio = ldm_stable.decode_to_mel(x0)
+    return audio, orig_audio, w_edit
+
+
+def main(argv=None):
+    p = argparse.ArgumentParser()
+    p.add_argument("--device_num", type=int, default=0)
+    p.add_argument("-s", "--seed", type=int, default=None)
+    p.add_argument("--model_id", type=str, default="cvssp/audioldm2-music")
+    p.add_argument("--init_aud", type=str, default=None)
+    p.add_argument("--cfg_src", type=float, nargs="+", default=[3])
+    p.add_argument("--cfg_tar", type=float, nargs="+", default=[12])
+    p.add_argument("--num_diffusion_steps", type=int, default=200)
+    p.add_argument("--target_prompt", type=str, nargs="+", default=[""])
+    p.add_argument("--source_prompt", type=str, nargs="*", default=[""])
+    p.add_argument("--target_neg_prompt", type=str, nargs="*", default=[""])
+    p.add_argument("--tstart", type=int, nargs="+", default=[100])
+    p.add_argument("--results_path", default="results")
+    p.add_argument("--mode", default="ours", choices=["ours", "ddim"])
+    p.add_argument("--schedule", default="sequential", choices=["sequential", "batched"])
+    args = p.parse_args(argv)
+    args.eta = 1.0
+    set_reproducability(args.seed, extreme=False)
+    device = f"cuda:{args.device_num}"
+    torch.cuda.set_device(args.device_num)
+    ldm_stable = load_model(args.model_id, device, args.num_diffusion_steps)
+    src = args.init_aud if args.init_aud else (synthetic_clip(), 16000)
+    x0, sr, duration = load_audio(src, ldm_stable.get_fn_STFT(), device=device, stft=True, model_sr=ldm_stable.get_sr())
+    t0 = time.time()
+    audio, orig, _ = edit_clip(ldm_stable, x0, args.source_prompt, args.target_prompt, args.target_neg_prompt,
+                               args.cfg_src, args.cfg_tar, args.num_diffusion_steps, args.tstart[0], args.mode,
+                               args.eta, args.schedule)
+    torch.cuda.synchronize()
+    print(f"edited {duration:.1f} s clip in {time.time() - t0:.2f} s ({ldm_stable.weights_source})")
+    os.makedirs(args.results_path, exist_ok=True)
+    write_wav(os.path.join(args.results_path, "edited.wav"), audio[0].numpy())
+    write_wav(os.path.join(args.results_path, "orig.wav"), orig[0].numpy())
+
+
+if __name__ == "__main__":
+    main()

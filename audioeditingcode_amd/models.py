@@ -1,0 +1,354 @@
+"""Wrapper API of the reference's code/models.py, MI355X-native underneath (THE drop-in boundary,
+SURVEY 8b).  Class names, method names, argument meaning and error behaviour mirror
+/root/reference/code/models.py (PipelineWrapper :14-393, TangoWrapper :396-472, AudioLDMWrapper :475-549,
+AudioLDM2Wrapper :552-899, load_model :1357-1374) so that main_run.py / main_pc_*.py style callers run
+unchanged; every tensor-valued method executes in libaed.so (HIP, gfx950) -- there is no torch/diffusers
+model underneath and no CPU fallback.
+
+Tensors cross this boundary exactly as in the reference: NCHW fp32 torch tensors on `device`.
+"""
+import ctypes
+import zlib
+from types import SimpleNamespace
+from typing import Dict, List, Optional, Tuple, Union
+
+import torch
+
+from . import _lib as L
+from . import configs, weights
+from .codec import STFTEngine, VAEDecoder, VAEEncoder, VocoderEngine
+from .editing import Conditioning, EditEngine
+from .scheduler import DDIMScheduler, step_coefficients
+from .tape import Tape
+from .unet import PackedUNetWeights, UNetEngine
+
+
+class UNet2DConditionOutput(SimpleNamespace):
+    """Stand-in for diffusers' output dataclass: callers only read `.sample`."""
+
+
+class _FnSTFT:
+    """`TacotronSTFT` duck type returned by get_fn_STFT (audioldm/audio/stft.py:130-180)."""
+
+    def __init__(self, owner):
+        self.owner = owner
+        self.n_mel_channels = owner.family["stft"]["n_mel_channels"]
+        self.sampling_rate = owner.family["stft"]["sampling_rate"]
+
+    def mel_spectrogram(self, y, normalize_fun=torch.log):
+        assert torch.min(y) >= -1, torch.min(y)
+        assert torch.max(y) <= 1, torch.max(y)
+        eng = self.owner._stft(y.shape[0], y.shape[1])
+        mel = eng(y)                                                   # [B, F, n_mels]
+        mag = eng.mag[:, : eng.n_fft // 2 + 1].view(y.shape[0], eng.frames, -1)
+        log_mag = torch.log(torch.clamp(mag, min=1e-5)).transpose(1, 2)
+        energy = torch.norm(mag, dim=2)
+        return mel.transpose(1, 2).contiguous(), log_mag, energy
+
+
+class PipelineWrapper(torch.nn.Module):
+    family_name = None
+
+    def __init__(self, model_id: str, device: torch.device, double_precision: bool = False,
+                 token: Optional[str] = None, seed: int = 0, *args, **kwargs) -> None:
+        super().__init__()
+        if double_precision:
+            raise NotImplementedError("double_precision=True: the native path is fp32 (the reference's default)")
+        self.model_id = model_id
+        self.device = torch.device(device)
+        self.double_precision = double_precision
+        self.token = token
+        if self.device.type != "cuda":
+            raise L.AedError(f"device={device}: the product path needs an MI355X (HIP); there is no CPU fallback. "
+                             f"The CPU restatement lives in oracle/ and is test infrastructure only.")
+        L.lib()                                                       # fail loudly if libaed.so is missing
+        self.family = configs.get_family(model_id)
+        self.kind = self.family["ctx"]["kind"]
+        ckpt = weights.find_checkpoint(model_id)
+        if ckpt is not None:
+            comp = weights.load_checkpoint(ckpt)
+            self.family["unet"], unet_sd = comp["unet"]
+            self.family["vae"], vae_sd = comp["vae"]
+            self.family["vocoder"], voc_sd = comp["vocoder"]
+            if "scheduler" in comp:
+                self.family["scheduler"] = comp["scheduler"]
+            self.weights_source = ckpt
+        else:
+            unet_sd = weights.random_state_dict(weights.unet_param_shapes(self.family["unet"]), seed=seed)
+            vae_sd = weights.random_state_dict(weights.vae_param_shapes(self.family["vae"]), seed=seed + 1)
+            voc_sd = weights.random_state_dict(weights.vocoder_param_shapes(self.family["vocoder"]), seed=seed + 2)
+            self.weights_source = f"seeded-random(seed={seed})"
+        self.state_dicts = dict(unet=unet_sd, vae=vae_sd, vocoder=voc_sd)
+        self.unet_weights = PackedUNetWeights(unet_sd, self.device)
+        ucfg, vcfg, ocfg = self.family["unet"], self.family["vae"], self.family["vocoder"]
+        n_up = sum(1 for _ in ucfg["up_block_types"]) - 1
+        self.model = SimpleNamespace(
+            scheduler=None,
+            unet=SimpleNamespace(config=SimpleNamespace(**{k: v for k, v in ucfg.items()}), num_upsamplers=n_up),
+            vae=SimpleNamespace(config=SimpleNamespace(scaling_factor=vcfg["scaling_factor"])),
+            vocoder=SimpleNamespace(config=SimpleNamespace(**ocfg)),
+            vae_scale_factor=2 ** (len(vcfg["block_out_channels"]) - 1))
+        self._engines = {}
+        self._editors = {}
+
+    # ------------------------------------------------------------------ engine caches
+    def _cached(self, key, make):
+        if key not in self._engines:
+            self._engines[key] = make()
+        return self._engines[key]
+
+    def _stft(self, B, N):
+        return self._cached(("stft", B, N), lambda: STFTEngine(self.family["stft"], self.device, B, N))
+
+    def _vae_enc(self, B, T, F):
+        return self._cached(("enc", B, T, F), lambda: VAEEncoder(self.family["vae"], self.state_dicts["vae"],
+                                                                   self.device, B, T, F))
+
+    def _vae_dec(self, B, h, w):
+        return self._cached(("dec", B, h, w), lambda: VAEDecoder(self.family["vae"], self.state_dicts["vae"],
+                                                                   self.device, B, h, w))
+
+    def _vocoder(self, B, T):
+        return self._cached(("voc", B, T), lambda: VocoderEngine(self.family["vocoder"], self.state_dicts["vocoder"],
+                                                                  self.device, B, T))
+
+    def editor(self, H, W) -> EditEngine:
+        """Device-resident loop engine for latents of size HxW (used by ddm_inversion.*)."""
+        if (H, W) not in self._editors:
+            self._editors[(H, W)] = EditEngine(self.family["unet"], self.unet_weights, self.model.scheduler,
+                                               self.device, H, W, self.kind)
+        self._editors[(H, W)].sched = self.model.scheduler
+        return self._editors[(H, W)]
+
+    # ------------------------------------------------------------------ reference API
+    def get_sigma(self, timestep: int) -> float:
+        return torch.sqrt(1.0 / self.model.scheduler.alphas_cumprod - 1)[timestep]
+
+    def load_scheduler(self) -> None:
+        self.model.scheduler = DDIMScheduler.from_config(self.family["scheduler"])
+
+    def get_fn_STFT(self):
+        return _FnSTFT(self)
+
+    def get_sr(self) -> int:
+        return 16000
+
+    def vae_encode(self, x: torch.Tensor) -> torch.Tensor:
+        if x.shape[2] % 4:                                              # front pad (models.py:583-584)
+            x = torch.nn.functional.pad(x, (0, 0, 4 - (x.shape[2] % 4), 0))
+        B, _, T, F = x.shape
+        enc = self._vae_enc(B, T, F)
+        lat = enc(x)                                                    # [B, h, w, C] channels-last
+        return lat.permute(0, 3, 1, 2).contiguous().float()
+
+    def vae_decode(self, x: torch.Tensor) -> torch.Tensor:
+        B, C, h, w = x.shape
+        dec = self._vae_dec(B, h, w)
+        mel = dec(x.to(self.device, torch.float32).permute(0, 2, 3, 1).contiguous())   # [B, T, F, 1]
+        return mel.permute(0, 3, 1, 2).contiguous()
+
+    def decode_to_mel(self, x: torch.Tensor) -> torch.Tensor:
+        mel = x[:, 0].detach().float()                                  # [B, T, n_mels]
+        voc = self._vocoder(mel.shape[0], mel.shape[1])
+        wav = voc(mel).detach().cpu().float()                           # pipeline returns a CPU tensor
+        if len(wav.shape) == 1:
+            wav = wav.unsqueeze(0)
+        return wav
+
+    def setup_extra_inputs(self, *args, **kwargs) -> None:
+        pass
+
+    def encode_text(self, prompts: List[str], **kwargs):
+        raise NotImplementedError
+
+    def get_variance(self, timestep, prev_timestep):
+        s = self.model.scheduler
+        a_t = s.alphas_cumprod[int(timestep)]
+        a_p = self.get_alpha_prod_t_prev(prev_timestep)
+        return ((1 - a_p) / (1 - a_t)) * (1 - a_t / a_p)
+
+    def get_alpha_prod_t_prev(self, prev_timestep):
+        s = self.model.scheduler
+        return s.alphas_cumprod[int(prev_timestep)] if prev_timestep >= 0 else s.final_alpha_cumprod
+
+    def get_noise_shape(self, x0: torch.Tensor, num_steps: int) -> Tuple[int, ...]:
+        return (num_steps, self.model.unet.config.in_channels, x0.shape[-2], x0.shape[-1])
+
+    def sample_xts_from_x0(self, x0: torch.Tensor, num_inference_steps: int = 50) -> torch.Tensor:
+        """Samples from P(x_1:T|x_0) (models.py:67-83); noise from the torch CPU generator in the reference's
+        draw order, arithmetic on the device."""
+        ed = self.editor(x0.shape[-2], x0.shape[-1])
+        x = x0.reshape(1, *x0.shape[-3:])
+        return ed.sample_xts(x)[:, 0]
+
+    def get_zs_from_xts(self, xt, xtm1, noise_pred, t, eta: float = 0, numerical_fix: bool = True, **kwargs):
+        c = step_coefficients(self.model.scheduler, int(t), eta=eta)
+        cf = (ctypes.c_float * L.COEF_STRIDE)(*c.tolist())
+        xt, noise_pred = xt.contiguous(), noise_pred.contiguous()
+        xtm1 = xtm1.contiguous().clone()
+        z = torch.empty_like(xt)
+        vp = int(self.model.scheduler.config.prediction_type == "v_prediction")
+        L.check(L.lib().aed_get_zs_from_xts(xt.data_ptr(), xtm1.data_ptr(), noise_pred.data_ptr(), None, None, 0.0, 0,
+                                            cf, vp, int(bool(numerical_fix)), z.data_ptr(), None, xt.numel(),
+                                            L.current_stream_ptr()), "aed_get_zs_from_xts")
+        return z, xtm1, None
+
+    def reverse_step_with_custom_noise(self, model_output, timestep, sample, variance_noise=None, eta: float = 0,
+                                       **kwargs):
+        c = step_coefficients(self.model.scheduler, int(timestep), eta=eta)
+        cf = (ctypes.c_float * L.COEF_STRIDE)(*c.tolist())
+        model_output, sample = model_output.contiguous(), sample.contiguous()
+        if eta > 0 and variance_noise is None:
+            variance_noise = torch.randn(model_output.shape).to(self.device)
+        z = variance_noise.contiguous() if eta > 0 else None
+        prev = torch.empty_like(sample)
+        vp = int(self.model.scheduler.config.prediction_type == "v_prediction")
+        L.check(L.lib().aed_reverse_step_with_custom_noise(sample.data_ptr(), model_output.data_ptr(), None, None, 0.0,
+                                                           0, cf, vp, None if z is None else z.data_ptr(),
+                                                           prev.data_ptr(), sample.numel(), L.current_stream_ptr()),
+                "aed_reverse_step_with_custom_noise")
+        return prev
+
+    # ------------------------------------------------------------------ unet_forward (models.py:160-393, :691-899)
+    def _cond_from_args(self, B, encoder_hidden_states, class_labels, encoder_attention_mask):
+        """Map the reference's positional conditioning triple to engine inputs."""
+        if self.kind == "audioldm2":      # (generated GPT-2 states, T5 states as class_labels, T5 mask)
+            return dict(ehs0=encoder_hidden_states, ehs1=class_labels,
+                        bias1=None if encoder_attention_mask is None else
+                        (1 - encoder_attention_mask.float()) * -10000.0), encoder_hidden_states.shape[1], \
+                class_labels.shape[1]
+        if self.kind == "audioldm":
+            return dict(class_labels=class_labels), 0, 0
+        return dict(ehs0=encoder_hidden_states,
+                    bias0=None if encoder_attention_mask is None else
+                    (1 - encoder_attention_mask.float()) * -10000.0), encoder_hidden_states.shape[1], 0
+
+    def unet_forward(self, sample, timestep, encoder_hidden_states=None, class_labels=None, timestep_cond=None,
+                     attention_mask=None, cross_attention_kwargs=None, added_cond_kwargs=None,
+                     down_block_additional_residuals=None, mid_block_additional_residual=None,
+                     encoder_attention_mask=None, replace_h_space=None, replace_skip_conns=None,
+                     return_dict: bool = True, zero_out_resconns=None):
+        B, C, H, W = sample.shape
+        up = 2 ** self.model.unet.num_upsamplers
+        if H % up or W % up:
+            raise NotImplementedError(f"latent {H}x{W} is not a multiple of {up}: forward_upsample_size path "
+                                      f"(models.py:186-188) is not built")
+        cond, L0, L1 = self._cond_from_args(B, encoder_hidden_states, class_labels, encoder_attention_mask)
+        eng = self._cached(("unet", B, H, W, L0, L1),
+                           lambda: UNetEngine(self.family["unet"], self.unet_weights, self.device, B, H, W,
+                                              ctx_len0=L0, ctx_len1=L1, use_ehs=self.kind != "audioldm"))
+        eng.set_conditioning(**{k: v for k, v in cond.items() if v is not None})
+        eng.x_in.copy_(sample.to(self.device, torch.float32).permute(0, 2, 3, 1))
+        eng.set_timestep(int(timestep))
+        hooks = (replace_h_space is not None or mid_block_additional_residual is not None
+                 or replace_skip_conns is not None or zero_out_resconns is not None)
+        eng.forward(first_half_only=True)
+        if replace_h_space is None:
+            h_space = eng.h_space.permute(0, 3, 1, 2).contiguous()
+        else:
+            h_space = replace_h_space
+            eng.h_space.copy_(replace_h_space.to(self.device).permute(0, 2, 3, 1).expand_as(eng.h_space))
+        if mid_block_additional_residual is not None:
+            eng.h_space.add_(mid_block_additional_residual.to(self.device).permute(0, 2, 3, 1))
+        nres = self.family["unet"].get("layers_per_block", 2) + 1
+        extracted, sk = {}, list(eng.skips)
+        for i in range(len(self.family["unet"]["up_block_types"])):
+            grp, sk = sk[-nres:], sk[:-nres]
+            if replace_skip_conns is not None and replace_skip_conns.get(i):
+                for buf, rep in zip(grp, replace_skip_conns.get(i)):
+                    buf.copy_(rep.to(self.device).permute(0, 2, 3, 1))
+            if zero_out_resconns is not None:
+                if (type(zero_out_resconns) is int and i >= (zero_out_resconns - 1)) or \
+                        (type(zero_out_resconns) is list and i in zero_out_resconns):
+                    for buf in grp:
+                        buf.zero_()
+            extracted[i] = [b.permute(0, 3, 1, 2).contiguous() for b in grp] if hooks or True else None
+        eng.forward(second_half_only=True)
+        out = eng.eps.permute(0, 3, 1, 2).contiguous()
+        if not return_dict:
+            return (out,)
+        return UNet2DConditionOutput(sample=out), h_space, extracted
+
+
+# --------------------------------------------------------------------------------------------------
+def _prompt_generator(prompt, salt):
+    return torch.Generator().manual_seed(zlib.crc32((salt + "|" + prompt).encode("utf-8")))
+
+
+class _SyntheticText:
+    """Deterministic stand-in for the text encoders (conditioning tensors are INPUTS to the
+    measured path; CLAP / T5 / GPT-2 weights do not exist in this container).  Shapes follow the real
+    encoders: T5 length = #whitespace tokens + 1 (EOS), so '' -> length 1 like `padding=True` tokenisation."""
+
+    @staticmethod
+    def t5(prompts, dim):
+        lens = [len(p.split()) + 1 for p in prompts]
+        Lm = max(lens)
+        e = torch.zeros(len(prompts), Lm, dim)
+        m = torch.zeros(len(prompts), Lm, dtype=torch.long)
+        for i, (p, l) in enumerate(zip(prompts, lens)):
+            e[i, :l] = torch.randn(l, dim, generator=_prompt_generator(p, "t5"))
+            m[i, :l] = 1
+        return e, m
+
+    @staticmethod
+    def vec(prompts, dim, salt):
+        return torch.stack([torch.randn(dim, generator=_prompt_generator(p, salt)) for p in prompts])
+
+
+class AudioLDMWrapper(PipelineWrapper):
+    family_name = "audioldm"
+
+    def encode_text(self, prompts: List[str], **kwargs):
+        """(None, L2-normalised CLAP text embedding [P,512], None) -- models.py:511-537."""
+        enc = getattr(self, "text_encoders", None)
+        if enc is not None:
+            return enc.encode_audioldm(prompts, self.device)
+        v = torch.nn.functional.normalize(_SyntheticText.vec(prompts, self.family["ctx"]["clap_dim"], "clap"), dim=-1)
+        return None, v.to(self.device), None
+
+
+class AudioLDM2Wrapper(PipelineWrapper):
+    family_name = "audioldm2"
+
+    def encode_text(self, prompts: List[str], **kwargs):
+        """(GPT-2 generated states [P,8,768], T5 states [P,L,1024], T5 mask [P,L]) -- models.py:599-677."""
+        enc = getattr(self, "text_encoders", None)
+        if enc is not None:
+            return enc.encode_audioldm2(prompts, self.device)
+        c = self.family["ctx"]
+        gen = torch.stack([torch.randn(c["gpt2_len"], c["gpt2_dim"], generator=_prompt_generator(p, "gpt2"))
+                           for p in prompts])
+        t5, mask = _SyntheticText.t5(prompts, c["t5_dim"])
+        return gen.to(self.device), t5.to(self.device), mask.to(self.device)
+
+
+class TangoWrapper(PipelineWrapper):
+    family_name = "tango"
+
+    def vae_encode(self, x: torch.Tensor) -> torch.Tensor:
+        if x.shape[2] % 4:
+            x = torch.nn.functional.pad(x, (0, 0, 4 - (x.shape[2] % 4), 0))
+        if x.shape[2] > 1700:
+            raise RuntimeWarning("This model dies at this point")        # models.py:444-445
+        return super().vae_encode(x)
+
+    def encode_text(self, prompts: List[str], **kwargs):
+        """(T5 states [P,L,1024], None, mask [P,L]) -- models.py:462-467."""
+        enc = getattr(self, "text_encoders", None)
+        if enc is not None:
+            return enc.encode_tango(prompts, self.device)
+        t5, mask = _SyntheticText.t5(prompts, self.family["ctx"]["t5_dim"])
+        return t5.to(self.device), None, mask.to(self.device)
+
+
+def load_model(model_id: str, device: torch.device, num_diffusion_steps: int, double_precision: bool = False,
+               token: Optional[str] = None, seed: int = 0) -> PipelineWrapper:
+    """Substring dispatch + scheduler setup of models.py:1357-1374."""
+    fam = configs.family_of(model_id)
+    cls = {"tango": TangoWrapper, "audioldm2": AudioLDM2Wrapper, "audioldm": AudioLDMWrapper}[fam]
+    ldm_stable = cls(model_id=model_id, device=device, double_precision=double_precision, token=token, seed=seed)
+    ldm_stable.load_scheduler()
+    ldm_stable.model.scheduler.set_timesteps(num_diffusion_steps, device=None)
+    torch.cuda.empty_cache()
+    return ldm_stable

@@ -296,7 +296,10 @@ class UNetEngine:
             co = boc[lvl]
             for j in range(lpb + 1):
                 sk, sc, sh_, sw_ = skips.pop()
-                assert (sh_, sw_) == (hh, ww), "skip / feature-map size mismatch (input not a multiple of 2^levels)"
+                if (sh_, sw_) != (hh, ww):
+                    raise NotImplementedError(
+                        f"latent {H}x{W} is not a multiple of 2^{nb - 1}: the reference's forward_upsample_size "
+                        f"path (models.py:186-188, nearest resize to the skip's size) is not built yet")
                 cat = self.tmp("cat", B, hh, ww, ch + sc)
                 tp.copy2d(h, cat, rows=B * hh * ww, cols=ch, ld_src=h.stride(-2), ld_dst=ch + sc, name="cat.h")
                 tp.copy2d(sk, cat[..., ch:], rows=B * hh * ww, cols=sc, ld_src=sk.stride(-2), ld_dst=ch + sc,

@@ -1,0 +1,126 @@
+"""End-to-end parity through the wrapper API (the drop-in boundary): clip -> mel -> latent -> inversion ->
+edit -> mel -> waveform, HIP path vs the CPU oracle with identical seeded weights and CPU-drawn noise."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from audioeditingcode_amd import models                                                   # noqa: E402
+from audioeditingcode_amd.ddm_inversion import inversion_forward_process, inversion_reverse_process  # noqa: E402
+from audioeditingcode_amd.main_run import edit_clip                                        # noqa: E402
+from audioeditingcode_amd.utils import load_audio, synthetic_clip                          # noqa: E402
+from oracle import audio as oaudio, hifigan as ohifi, loops as oloops, unet as ounet, vae as ovae   # noqa: E402
+from oracle.scheduler import OracleDDIMScheduler                                           # noqa: E402
+
+DEV = "cuda:0"
+
+
+def rel(a, b):
+    return ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
+
+
+def _oracle_wrapper(m, T):
+    cfg, sd = m.family["unet"], m.state_dicts["unet"]
+    osched = OracleDDIMScheduler()
+    osched.set_timesteps(T)
+
+    def unet_fn(x, t, cond):
+        hs, cl, mk = cond
+        ex = lambda v: None if v is None else v.cpu().expand(x.shape[0], *v.shape[1:])      # noqa: E731
+        if m.kind == "audioldm2":
+            return ounet.unet_forward(cfg, sd, x, t, encoder_hidden_states=ex(hs), encoder_hidden_states_1=ex(cl),
+                                      encoder_attention_mask_1=ex(mk))[0]
+        if m.kind == "audioldm":
+            return ounet.unet_forward(cfg, sd, x, t, class_labels=ex(cl))[0]
+        return ounet.unet_forward(cfg, sd, x, t, encoder_hidden_states=ex(hs), encoder_attention_mask=ex(mk))[0]
+    return oloops.OracleWrapper(osched, unet_fn)
+
+
+@pytest.mark.parametrize("model_id", ["tiny/audioldm2", "tiny/audioldm", "tiny/tango"])
+def test_clip_edit_end_to_end_vs_oracle(model_id):
+    T, tstart = 10, 6
+    m = models.load_model(model_id, DEV, T, seed=0)
+    wav = synthetic_clip(seconds=1.25, seed=7)
+    x0, sr, dur = load_audio((wav, 16000), m.get_fn_STFT(), device=DEV, stft=True, model_sr=m.get_sr())
+    assert x0.shape == (1, 1, 128, 64) and sr == 16000
+    # ---- oracle front end
+    fb, _ = oaudio.wav_to_fbank(wav, int(dur * 102.4))
+    assert (x0[0, 0].cpu() - fb).abs().max() < 5e-3
+    src, tgt = ["a dog barking"], ["a cat meowing loudly"]
+    torch.manual_seed(5)
+    audio, orig, w_edit = edit_clip(m, x0, src, tgt, [""], [3.0], [12.0], T, tstart)
+    torch.cuda.synchronize()
+    # ---- oracle path (same weights, same RNG stream for the x_t draws)
+    ow = _oracle_wrapper(m, T)
+    mel0 = fb[None, None]
+    w0 = ovae.vae_encode(m.family["vae"], m.state_dicts["vae"], mel0)
+    gen = torch.Generator().manual_seed(5)
+    xts0 = ow.sample_xts_from_x0(w0, T, generator=gen)
+    enc = lambda p, **k: tuple(None if t is None else t.cpu() for t in m.encode_text(p, **k))     # noqa: E731
+    _, zs_o, xts_o = oloops.invert(ow, w0, enc(src), enc([""]), [3.0], T, eta=1.0, xts=xts0)
+    w_o = oloops.edit(ow, xts_o, torch.tensor([tstart]), enc(tgt), enc([""]), [12.0], zs_o[:tstart], eta=1.0)
+    mel_o = ovae.vae_decode(m.family["vae"], m.state_dicts["vae"], w_o)
+    wav_o = ohifi.hifigan_forward(m.family["vocoder"], m.state_dicts["vocoder"], mel_o[:, 0])
+    wav_orig_o = ohifi.hifigan_forward(m.family["vocoder"], m.state_dicts["vocoder"], mel0[:, 0])
+    # stated tolerances (fp32; z = (x - mu)/sigma_t amplifies eps error, SURVEY section 7 "hard parts")
+    assert rel(w_edit.cpu(), w_o) < 5e-3, ("latent", rel(w_edit.cpu(), w_o))
+    assert rel(audio, wav_o) < 2e-2, ("waveform", rel(audio, wav_o))
+    assert rel(orig, wav_orig_o) < 1e-3, ("orig waveform", rel(orig, wav_orig_o))
+    assert audio.shape == wav_o.shape and audio.device.type == "cpu"
+
+
+def test_ddim_mode_end_to_end():
+    """BASELINE config 1 plumbing (--mode ddim) on the tiny AudioLDM-1 twin."""
+    T = 8
+    m = models.load_model("tiny/audioldm", DEV, T, seed=1)
+    x0, _, _ = load_audio((synthetic_clip(seconds=1.25, seed=3), 16000), m.get_fn_STFT(), device=DEV, stft=True)
+    audio, orig, w_edit = edit_clip(m, x0, ["rain"], ["jazz"], [""], [3.0], [12.0], T, tstart=T, mode="ddim")
+    ow = _oracle_wrapper(m, T)
+    fb = x0[0, 0].cpu()
+    w0 = ovae.vae_encode(m.family["vae"], m.state_dicts["vae"], fb[None, None])
+    enc = lambda p: tuple(None if t is None else t.cpu() for t in m.encode_text(p))         # noqa: E731
+    wT = oloops.ddim_invert(ow, w0, enc(["rain"]), enc([""]), 3.0, T, 0)
+    we = oloops.ddim_sample(ow, wT, enc(["jazz"]), enc([""]), 12.0, skip=0)
+    assert rel(w_edit.cpu(), we) < 5e-3, rel(w_edit.cpu(), we)
+
+
+def test_unet_forward_api_and_hooks_vs_oracle():
+    m = models.load_model("tiny/audioldm2", DEV, 10, seed=2)
+    cfg, sd = m.family["unet"], m.state_dicts["unet"]
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 8, 32, 16, generator=g)
+    hs, cl, mk = m.encode_text(["a dog", "a very long prompt about rain"])
+    t = torch.tensor(501)
+    kw = dict(encoder_hidden_states=hs.cpu(), encoder_hidden_states_1=cl.cpu(), encoder_attention_mask_1=mk.cpu())
+    out, h_space, skips = m.unet_forward(x.to(DEV), t, encoder_hidden_states=hs, class_labels=cl,
+                                         encoder_attention_mask=mk)
+    ref, ref_h, ref_s = ounet.unet_forward(cfg, sd, x, t, **kw)
+    assert rel(out.sample.cpu(), ref) < 1e-4 and rel(h_space.cpu(), ref_h) < 1e-4
+    assert sorted(skips) == sorted(ref_s) and all(rel(a.cpu(), b) < 1e-4 for a, b in zip(skips[1], ref_s[1]))
+    # h-space replace + additive residual + zeroed skips (models.py:840-866)
+    rep = torch.randn(ref_h.shape, generator=g)
+    add = 0.1 * torch.randn(ref_h.shape, generator=g)
+    out2, h2, _ = m.unet_forward(x.to(DEV), t, encoder_hidden_states=hs, class_labels=cl, encoder_attention_mask=mk,
+                                 replace_h_space=rep.to(DEV), mid_block_additional_residual=add.to(DEV),
+                                 zero_out_resconns=[3])
+    ref2, _, _ = ounet.unet_forward(cfg, sd, x, t, replace_h_space=rep, mid_block_additional_residual=add,
+                                    zero_out_resconns=[3], **kw)
+    assert rel(out2.sample.cpu(), ref2) < 1e-4
+    assert torch.equal(h2.cpu(), rep)
+
+
+def test_step_method_api_matches_oracle_functions():
+    m = models.load_model("tiny/audioldm2", DEV, 50, seed=0)
+    ow = _oracle_wrapper(m, 50)
+    g = torch.Generator().manual_seed(1)
+    xt, xtm1, eps, z = (torch.randn(1, 8, 32, 16, generator=g) for _ in range(4))
+    t = m.model.scheduler.timesteps[7]
+    zz, xfix, _ = m.get_zs_from_xts(xt.to(DEV), xtm1.to(DEV), eps.to(DEV), t, eta=1.0)
+    zo, xo = ow.get_zs_from_xts(xt, xtm1, eps, t, eta=1.0)
+    assert torch.equal(zz.cpu(), zo) and torch.equal(xfix.cpu(), xo)          # same host -> bit exact
+    pv = m.reverse_step_with_custom_noise(eps.to(DEV), t, xt.to(DEV), variance_noise=z.to(DEV), eta=1.0)
+    assert torch.equal(pv.cpu(), ow.reverse_step_with_custom_noise(eps, t, xt, variance_noise=z, eta=1.0))
+    assert m.get_noise_shape(xt, 50) == (50, 8, 32, 16) and m.get_sr() == 16000
+    with pytest.raises(Exception):
+        models.load_model("tiny/audioldm2", "cpu", 10)                        # no CPU fallback in the product

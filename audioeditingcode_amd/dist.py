@@ -1,0 +1,115 @@
+"""Clip-level data parallelism over the GPUs of one node (not in the reference, which is
+single-GPU: main_run.py:72-73).  One process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI
+on ROCm; "gloo" for the CPU tests).
+
+Clips are independent (no cross-clip term anywhere in inversion_utils.py), so the data path has NO
+collective: clip i -> rank i mod W.  Collectives exist only at the edges:
+  * one broadcast of the frozen weights from rank 0 (only rank 0 touches disk): the state dicts are
+    flattened into a few large contiguous fp32 arenas -- xGMI is point-to-point and ring broadcasts are
+    per-link bound, so few large messages beat ~1700 small ones;
+  * one gather of the edited latents ([n_local, 8, 256, 16] fp32 = 128 KiB per clip) to rank 0.
+"""
+import os
+from typing import Dict, List
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend=None):
+    """Initialise from the torchrun environment; returns (rank, world, local_rank). No-op at world size 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_clips(n_clips: int, rank: int, world: int) -> List[int]:
+    """Round-robin clip -> rank map (clip i runs on rank i mod W)."""
+    return list(range(rank, n_clips, world))
+
+
+def _arena_shapes(shapes: Dict[str, tuple]):
+    offs, total = {}, 0
+    for k, shp in shapes.items():
+        n = 1
+        for d in shp:
+            n *= d
+        offs[k] = (total, n, tuple(shp))
+        total += n
+    return offs, total
+
+
+def broadcast_state_dict(sd, shapes: Dict[str, tuple], device, src: int = 0, max_bucket: int = 1 << 28):
+    """Broadcast one component's weights as contiguous fp32 arenas of <= max_bucket elements (1 GiB).
+    `sd` is the real state dict on `src` and may be None elsewhere; `shapes` (name -> shape, identical and
+    identically ordered on every rank) comes from weights.*_param_shapes.  Returns the state dict."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return sd
+    rank = dist.get_rank()
+    offs, total = _arena_shapes(shapes)
+    out = {}
+    names = list(shapes)
+    i = 0
+    while i < len(names):
+        j, n = i, 0
+        while j < len(names) and (n == 0 or n + offs[names[j]][1] <= max_bucket):
+            n += offs[names[j]][1]
+            j += 1
+        arena = torch.empty(n, dtype=torch.float32, device=device)
+        if rank == src:
+            p = 0
+            for k in names[i:j]:
+                cnt = offs[k][1]
+                arena[p:p + cnt].copy_(sd[k].reshape(-1))
+                p += cnt
+        dist.broadcast(arena, src=src)
+        p = 0
+        cpu = arena.cpu()
+        for k in names[i:j]:
+            cnt, shp = offs[k][1], offs[k][2]
+            out[k] = cpu[p:p + cnt].view(shp).clone()
+            p += cnt
+        i = j
+    return out
+
+
+def state_checksum(sd) -> float:
+    """Order-independent fp64 checksum used to verify the broadcast (world-size invariance tests)."""
+    return float(sum(v.double().sum().item() for v in sd.values()))
+
+
+def gather_to_rank0(local: torch.Tensor, dst: int = 0):
+    """Gather equally-shaped per-rank tensors on `dst`; returns the list there, None elsewhere."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [local]
+    world = dist.get_world_size()
+    if dist.get_backend() == "nccl":
+        bufs = [torch.empty_like(local) for _ in range(world)]
+        dist.all_gather(bufs, local.contiguous())
+        return bufs if dist.get_rank() == dst else None
+    bufs = [torch.empty_like(local) for _ in range(world)] if dist.get_rank() == dst else None
+    dist.gather(local.contiguous(), bufs, dst=dst)
+    return bufs
+
+
+def max_over_ranks(x: float, device) -> float:
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return x
+    t = torch.tensor([x], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

@@ -50,7 +50,8 @@ class PipelineWrapper(torch.nn.Module):
     family_name = None
 
     def __init__(self, model_id: str, device: torch.device, double_precision: bool = False,
-                 token: Optional[str] = None, seed: int = 0, *args, **kwargs) -> None:
+                 token: Optional[str] = None, seed: int = 0, state_dicts: Optional[Dict] = None, *args,
+                 **kwargs) -> None:
         super().__init__()
         if double_precision:
             raise NotImplementedError("double_precision=True: the native path is fp32 (the reference's default)")
@@ -64,8 +65,11 @@ class PipelineWrapper(torch.nn.Module):
         L.lib()                                                       # fail loudly if libaed.so is missing
         self.family = configs.get_family(model_id)
         self.kind = self.family["ctx"]["kind"]
-        ckpt = weights.find_checkpoint(model_id)
-        if ckpt is not None:
+        ckpt = weights.find_checkpoint(model_id) if state_dicts is None else None
+        if state_dicts is not None:          # e.g. received through dist.broadcast_state_dicts
+            unet_sd, vae_sd, voc_sd = state_dicts["unet"], state_dicts["vae"], state_dicts["vocoder"]
+            self.weights_source = "caller-provided state dicts"
+        elif ckpt is not None:
             comp = weights.load_checkpoint(ckpt)
             self.family["unet"], unet_sd = comp["unet"]
             self.family["vae"], vae_sd = comp["vae"]
@@ -343,11 +347,12 @@ class TangoWrapper(PipelineWrapper):
 
 
 def load_model(model_id: str, device: torch.device, num_diffusion_steps: int, double_precision: bool = False,
-               token: Optional[str] = None, seed: int = 0) -> PipelineWrapper:
+               token: Optional[str] = None, seed: int = 0, state_dicts: Optional[Dict] = None) -> PipelineWrapper:
     """Substring dispatch + scheduler setup of models.py:1357-1374."""
     fam = configs.family_of(model_id)
     cls = {"tango": TangoWrapper, "audioldm2": AudioLDM2Wrapper, "audioldm": AudioLDMWrapper}[fam]
-    ldm_stable = cls(model_id=model_id, device=device, double_precision=double_precision, token=token, seed=seed)
+    ldm_stable = cls(model_id=model_id, device=device, double_precision=double_precision, token=token, seed=seed,
+                     state_dicts=state_dicts)
     ldm_stable.load_scheduler()
     ldm_stable.model.scheduler.set_timesteps(num_diffusion_steps, device=None)
     torch.cuda.empty_cache()

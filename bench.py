@@ -1,0 +1,194 @@
+#!/usr/bin/env python
+"""bench.py -- edited-clips/sec of the DDPM-inversion audio-editing hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): AudioLDM2 text-based edit of ONE synthetic 10 s / 16 kHz clip per
+step -- STFT/log-mel -> VAE encode -> 200-step edit-friendly DDPM inversion (cfg 3) -> 100-step edit from
+tstart=100 (cfg 12) -> VAE decode -> HiFi-GAN vocoder (edited + original, main_run.py:184-185) -- fp32,
+seeded-random weights of the real architecture (no checkpoints exist offline), synthetic conditioning.
+One "step" = one whole clip.  N GPUs = N independent clips per step (weak scaling, no data-path
+collective; weights broadcast once from rank 0 over RCCL, edited latents gathered to rank 0).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md: fp32-in MFMA peak
+
+
+def cpu_baseline(fam, state_dicts, cores):
+    """The oracle (CPU restatement pinned to the reference, oracle/) timed on the host cores on a bounded
+    sample: 1 warm + 3 timed AudioLDM2 U-Net forwards (B=1), one VAE encode/decode, one vocoder call, one
+    STFT; a clip is 600 U-Net forwards + enc + dec + 2 vocoder + STFT."""
+    from oracle import audio as oaudio, hifigan as ohifi, unet as ounet, vae as ovae
+    from oracle.synth import chirp_waveform
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 8, 256, 16, generator=g)
+    kw = dict(encoder_hidden_states=torch.randn(1, 8, 768, generator=g),
+              encoder_hidden_states_1=torch.randn(1, 16, 1024, generator=g),
+              encoder_attention_mask_1=torch.ones(1, 16))
+    with torch.no_grad():
+        ounet.unet_forward(fam["unet"], state_dicts["unet"], x, torch.tensor(500), **kw)
+        t0 = time.time()
+        for _ in range(3):
+            ounet.unet_forward(fam["unet"], state_dicts["unet"], x, torch.tensor(500), **kw)
+        t_unet = (time.time() - t0) / 3
+        wav = torch.from_numpy(oaudio.prepare_waveform(chirp_waveform().numpy(), 163840))[None]
+        t0 = time.time()
+        mel, _, _ = oaudio.mel_spectrogram(wav)
+        t_stft = time.time() - t0
+        mel4 = mel[:, :, :1024].transpose(1, 2)[:, None]
+        t0 = time.time()
+        lat = ovae.vae_encode(fam["vae"], state_dicts["vae"], mel4)
+        t_enc = time.time() - t0
+        t0 = time.time()
+        rec = ovae.vae_decode(fam["vae"], state_dicts["vae"], lat)
+        t_dec = time.time() - t0
+        t0 = time.time()
+        ohifi.hifigan_forward(fam["vocoder"], state_dicts["vocoder"], rec[:, 0])
+        t_voc = time.time() - t0
+    clip_s = 600 * t_unet + t_enc + t_dec + 2 * t_voc + t_stft
+    return dict(value=1.0 / clip_s, unit="edited-clips/sec", cores=cores, kind="port",
+                sample=f"oracle (torch CPU fp32): 3 AudioLDM2 U-Net fwd B=1 ({t_unet:.3f} s each), VAE enc "
+                       f"{t_enc:.2f} s, dec {t_dec:.2f} s, vocoder {t_voc:.2f} s, STFT {t_stft:.3f} s; "
+                       f"clip = 600*unet + enc + dec + 2*voc + stft = {clip_s:.1f} s (extrapolated)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--model_id", default="cvssp/audioldm2")
+    ap.add_argument("--T", type=int, default=200)
+    ap.add_argument("--tstart", type=int, default=100)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-batched", action="store_true", help="skip the extra timestep-batched-inversion timing")
+    ap.add_argument("--profile-forward", action="store_true", help="only run U-Net forwards (for rocprofv3)")
+    args = ap.parse_args()
+
+    from audioeditingcode_amd import configs, dist as adist, models, weights
+    from audioeditingcode_amd.main_run import edit_clip
+    from audioeditingcode_amd.utils import prepare_waveform, synthetic_clip
+
+    rank, world, local = adist.init_distributed()
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dev = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(dev)
+
+    # ---- weights: rank 0 materialises them, everyone else receives them over RCCL
+    fam = configs.get_family(args.model_id)
+    shapes = dict(unet=weights.unet_param_shapes(fam["unet"]), vae=weights.vae_param_shapes(fam["vae"]),
+                  vocoder=weights.vocoder_param_shapes(fam["vocoder"]))
+    sds = None
+    if rank == 0:
+        sds = {k: weights.random_state_dict(shapes[k], seed=i) for i, k in enumerate(("unet", "vae", "vocoder"))}
+    t0 = time.time()
+    if world > 1:
+        sds = {k: adist.broadcast_state_dict(None if sds is None else sds[k], shapes[k], dev) for k in shapes}
+        torch.cuda.synchronize()
+    t_bcast = time.time() - t0
+    m = models.load_model(args.model_id, dev, args.T, state_dicts=sds)
+
+    # ---- synthetic inputs, resident in HBM before the timed region
+    src, tgt, neg = ["a recording of a piano melody"], ["a recording of an electric guitar melody"], [""]
+    fn = m.get_fn_STFT()
+
+    def clip_wave(i):
+        w = prepare_waveform(synthetic_clip(10.0, seed=1234 + i), 1024 * 160)
+        return torch.clip(torch.from_numpy(w)[None], -1, 1).to(dev)
+
+    def run_clip(wave, schedule):
+        mel, _, _ = fn.mel_spectrogram(wave)                              # [1, 64, 1025]
+        x0 = mel[0].T[:1024][None, None].contiguous()                    # [1,1,1024,64]
+        return edit_clip(m, x0, src, tgt, neg, [3.0], [12.0], args.T, args.tstart, schedule=schedule,
+                         timestep_group=8)
+
+    if args.profile_forward:
+        ed = m.editor(256, 16)
+        torch.manual_seed(0)
+        for _ in range(max(1, args.warmup)):
+            run_clip(clip_wave(0), "sequential")
+        torch.cuda.synchronize()
+        return
+
+    def timed(schedule, K, W):
+        for i in range(W):
+            torch.manual_seed(1000 + i)
+            run_clip(clip_wave(rank * 1000 + i), schedule)
+        waves = [clip_wave(rank * 1000 + 100 + i) for i in range(K)]
+        lat = []
+        torch.cuda.synchronize()
+        adist.barrier()
+        t0 = time.perf_counter()
+        for i in range(K):
+            torch.manual_seed(2000 + i)
+            _, _, w_edit = run_clip(waves[i], schedule)
+            lat.append(w_edit)
+        local_lat = torch.cat(lat, 0)
+        gathered = adist.gather_to_rank0(local_lat)
+        torch.cuda.synchronize()
+        adist.barrier()
+        dt = adist.max_over_ranks(time.perf_counter() - t0, dev)
+        return dt, gathered
+
+    dt, gathered = timed("sequential", args.steps, args.warmup)
+    value = world * args.steps / dt
+    extra = {}
+    if not args.no_batched:
+        dtb, _ = timed("batched", args.steps, 1)
+        extra["value_batched_inversion"] = world * args.steps / dtb
+        extra["ms_per_step_batched_inversion"] = 1e3 * dtb / args.steps
+
+    # ---- roofline of the dominant kernel (conv_gemm_kernel, fp32 MFMA), HIP events on the engine stream
+    roof = None
+    if rank == 0:
+        ed = m.editor(256, 16)
+        eng = next(e for (B, _, _), e in ed._unets.items() if B == 2)
+        st = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(st):
+            eng.tape.profile()
+            ms = [eng.tape.profile() for _ in range(3)]
+        ms = [sum(x) / len(ms) for x in zip(*ms)]
+        conv = [(mt["flops"], t) for mt, t in zip(eng.tape.meta, ms) if mt["code"] == 1]
+        fl, tt = sum(f for f, _ in conv), sum(t for _, t in conv)
+        achieved = fl / (tt * 1e-3) / 1e12
+        per_clip_flops = (2 * args.T + 2 * args.tstart) / 2 * eng.tape.flops
+        roof = dict(bound="mfma", achieved=achieved, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
+                    frac=achieved / PEAK_FP32_MFMA_TFLOPS, traffic=None, kernel="conv_gemm_kernel",
+                    launches_per_forward=len(conv), avg_launch_us=1e3 * tt / len(conv),
+                    algorithmic_gflop_per_forward_B2=eng.tape.flops / 1e9,
+                    unet_forward_ms_B2=sum(ms), unet_loop_tflops=per_clip_flops / (dt / args.steps) / 1e12,
+                    unet_loop_frac=per_clip_flops / (dt / args.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS)
+    base = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        base = cpu_baseline(fam, m.state_dicts, os.cpu_count() or 1)
+
+    if rank == 0:
+        out = {"metric": "edited-clips/sec (200-step inv+edit, 10 s@16 kHz)", "value": value,
+               "unit": "edited-clips/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"AudioLDM2 ({args.model_id}, 346.9M-param U-Net, seeded-random weights) "
+                                      f"text-based edit, T={args.T}, tstart={args.tstart}, cfg 3/12, 1 clip of 10 s "
+                                      f"@16 kHz per GPU per step; reference step order (sequential inversion)",
+                          "clips_per_gpu_per_step": 1, "parallelism": f"clip-dp{world}",
+                          "weights_broadcast_s": t_bcast if world > 1 else 0.0,
+                          "gathered_latents": None if gathered is None else [list(g.shape) for g in gathered][:2]},
+               "roofline": roof, "cpu_baseline": base}
+        out.update(extra)
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

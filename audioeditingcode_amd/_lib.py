@@ -3,6 +3,9 @@ library is missing -- there is no CPU fallback anywhere in this package."""
 import ctypes
 import os
 
+import torch  # noqa: F401  -- MUST be imported before libaed.so is dlopen'ed: the library has to bind to the
+#                               HIP runtime torch already loaded (a second libamdhip64 in the process sees no device)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libaed.so")
 

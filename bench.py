@@ -25,6 +25,10 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md: fp32-in MFMA peak
 
 
+def log(*a):
+    print("[bench]", *a, file=sys.stderr, flush=True)
+
+
 def cpu_baseline(fam, state_dicts, cores):
     """The oracle (CPU restatement pinned to the reference, oracle/) timed on the host cores on a bounded
     sample: 1 warm + 3 timed AudioLDM2 U-Net forwards (B=1), one VAE encode/decode, one vocoder call, one
@@ -32,6 +36,7 @@ def cpu_baseline(fam, state_dicts, cores):
     from oracle import audio as oaudio, hifigan as ohifi, unet as ounet, vae as ovae
     from oracle.synth import chirp_waveform
     torch.set_num_threads(cores)
+    log(f"cpu_baseline: oracle on {cores} host threads")
     g = torch.Generator().manual_seed(0)
     x = torch.randn(1, 8, 256, 16, generator=g)
     kw = dict(encoder_hidden_states=torch.randn(1, 8, 768, generator=g),
@@ -142,13 +147,16 @@ def main():
         dt = adist.max_over_ranks(time.perf_counter() - t0, dev)
         return dt, gathered
 
+    log(f"model ready ({m.weights_source}); timing {args.steps} clip(s) after {args.warmup} warm-up")
     dt, gathered = timed("sequential", args.steps, args.warmup)
     value = world * args.steps / dt
+    log(f"sequential: {dt / args.steps:.3f} s/clip")
     extra = {}
     if not args.no_batched:
         dtb, _ = timed("batched", args.steps, 1)
         extra["value_batched_inversion"] = world * args.steps / dtb
         extra["ms_per_step_batched_inversion"] = 1e3 * dtb / args.steps
+        log(f"timestep-batched inversion: {dtb / args.steps:.3f} s/clip")
 
     # ---- roofline of the dominant kernel (conv_gemm_kernel, fp32 MFMA), HIP events on the engine stream
     roof = None
@@ -172,7 +180,9 @@ def main():
                     unet_loop_frac=per_clip_flops / (dt / args.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS)
     base = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        base = cpu_baseline(fam, m.state_dicts, os.cpu_count() or 1)
+        # many-core hosts (the MI355X box has 256) make torch's CPU kernels slower, not faster, on these
+        # small tensors: use at most 32 threads and report that number as `cores`
+        base = cpu_baseline(fam, m.state_dicts, min(os.cpu_count() or 1, 32))
 
     if rank == 0:
         out = {"metric": "edited-clips/sec (200-step inv+edit, 10 s@16 kHz)", "value": value,

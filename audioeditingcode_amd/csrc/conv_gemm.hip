@@ -12,11 +12,14 @@
 // Arithmetic: v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain, 157 TF peak) -- the parity
 // configuration of the reference, which runs strict fp32 (code/utils.py:113-116).
 //
-// Tiling: 256 threads = 4 waves; block tile BM x BN, K-chunk 32; operands staged through LDS with
-// a 4-float row pad (conflict-free ds_read_b128 fragment reads); the next K-chunk is prefetched
-// into registers while the current one feeds the MFMAs.  Each lane reads 4 consecutive k per
-// ds_read_b128; MFMA step s of a k-block uses k = {s, 4+s} (A and B agree, the sum over k is
-// order-free).
+// Tiling: 256 threads = 4 waves; block tile BM x BN, K-chunk BKT (64 when the channel count allows,
+// else 32) staged through LDS with a 4-float row pad (conflict-free ds_read_b128 fragment reads);
+// DEPTH chunks are kept in flight in registers.  Each lane reads 4 consecutive k per ds_read_b128;
+// MFMA step s of a k-block uses k = {s, 4+s} (A and B agree, the sum over k is order-free).
+//
+// At the batch sizes of the edit loop (U-Net batch 2) most launches are a few microseconds of MFMA
+// work, so the kernel is written for LATENCY: 32-bit offsets, no per-chunk integer divisions, one
+// batch of residual loads in the epilogue (measured with the in-kernel s_memtime timeline, p.dbg).
 #include "aed_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -29,6 +32,7 @@ struct CGParams {
     const float* res;
     const float* rowvec;
     float* ws;
+    long long* dbg;          // optional in-kernel timeline (block 0, lane 0): s_memtime stamps
     int M, N, K;
     int lda, ldc, ldr, ld_rv;
     int IH, IW, OH, OW, Cin;
@@ -37,12 +41,9 @@ struct CGParams {
     int o_mul, o_add, o_len, out_bs;
     int in_act, out_act, accumulate, ksplit;
     int rpb;                 // output rows per batch item = OH*OW
-    int nchunks;             // ceil(K/32)
+    int nchunks;             // ceil(K/BKT)
     float in_slope, out_p, out_div;
 };
-
-#define BK 32
-#define LDS_LD (BK + 4)
 
 __device__ __forceinline__ float in_transform(float v, int act, float slope) {
     if (act == AED_ACT_SILU) return v / (1.0f + __expf(-v));
@@ -50,8 +51,8 @@ __device__ __forceinline__ float in_transform(float v, int act, float slope) {
     return v;
 }
 
+// shared by the split-K reduce kernel (one element per thread: the slow general form is fine there)
 __device__ __forceinline__ void store_out(const CGParams& p, int m, int n, float v) {
-    // m < M, n < N guaranteed by caller
     int b = m / p.rpb;
     int q = m - b * p.rpb;
     int o = q * p.o_mul + p.o_add;
@@ -67,13 +68,16 @@ __device__ __forceinline__ void store_out(const CGParams& p, int m, int n, float
     *dst = v;
 }
 
-template <int BM, int BN, int WROWS, int WCOLS, bool GENERIC>
+template <int BM, int BN, int WROWS, int WCOLS, bool GENERIC, int DEPTH, int BKT>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(CGParams p) {
     constexpr int WM = BM / WROWS, WN = BN / WCOLS;
     constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int PA = BM / 32, PB = BN / 32;
+    constexpr int LDS_LD = BKT + 4;
+    constexpr int TPR = BKT / 4;            // loader threads per row (float4 each)
+    constexpr int RPP = 256 / TPR;          // rows per loader pass
+    constexpr int PA = BM / RPP, PB = BN / RPP;
     static_assert(WROWS * WCOLS == 4, "4 waves");
-    static_assert(TM >= 1 && TN >= 1, "wave tile");
+    static_assert(TM >= 1 && TN >= 1 && PA >= 1 && PB >= 1, "tile");
 
     __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * LDS_LD];
     float* As = lds;
@@ -85,8 +89,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(CGParams p) {
     const int wr = wave / WCOLS, wc = wave % WCOLS;
     const int m0 = blockIdx.y * BM;
     const int n0 = blockIdx.x * BN;
+    const bool dbg_on = p.dbg && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
+    int dbg_n = 0;
+#define STAMP() do { if (dbg_on && dbg_n < 30) p.dbg[dbg_n++] = __builtin_amdgcn_s_memtime(); } while (0)
+    STAMP();
 
-    // K-chunk range of this split
     int kc_begin = 0, kc_end = p.nchunks;
     if (p.ksplit > 1) {
         int per = (p.nchunks + p.ksplit - 1) / p.ksplit;
@@ -94,94 +101,105 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(CGParams p) {
         kc_end = min(p.nchunks, kc_begin + per);
     }
 
-    // loader coordinates: 8 threads x float4 per 32-float row, 32 rows per pass
-    const int lrow = tid >> 3;
-    const int lcol = (tid & 7) * 4;
+    const int lrow = tid / TPR;
+    const int lcol = (tid % TPR) * 4;
 
+    // per-row gather state (32-bit element offsets: every tensor on the path is < 2^31 elements)
     int ay0[PA], ax0[PA];
-    size_t abase[PA];
+    unsigned abase[PA];
     bool avalid[PA];
 #pragma unroll
     for (int q = 0; q < PA; ++q) {
-        int m = m0 + lrow + 32 * q;
+        const int m = m0 + lrow + RPP * q;
         avalid[q] = m < p.M;
-        int mm = avalid[q] ? m : 0;
-        int b = mm / p.rpb;
-        int r = mm - b * p.rpb;
-        int oy = r / p.OW;
-        int ox = r - oy * p.OW;
+        const int mm = avalid[q] ? m : 0;
+        const int b = mm / p.rpb;
+        const int r = mm - b * p.rpb;
+        const int oy = r / p.OW;
+        const int ox = r - oy * p.OW;
         ay0[q] = oy * p.stride - p.pad_h;
         ax0[q] = ox * p.stride - p.pad_w;
-        abase[q] = (size_t)b * (size_t)p.a_bs;
+        abase[q] = (unsigned)b * (unsigned)p.a_bs + lcol;
+    }
+    unsigned wbase[PB];
+    bool wvalid[PB];
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+        const int n = n0 + lrow + RPP * q;
+        wvalid[q] = n < p.N;
+        wbase[q] = (unsigned)(wvalid[q] ? n : 0) * (unsigned)p.K + lcol;
     }
     const int vIH = p.IH << p.up, vIW = p.IW << p.up;
 
-    float4 ra[PA], rb[PB];
+    // running (tap, channel) position of the NEXT chunk to prefetch (prefetch() is always called with
+    // consecutive kc): no per-chunk integer divisions
+    int pf_c0 = 0, pf_ty = 0, pf_tx = 0;
+    if constexpr (!GENERIC) {
+        const int k0 = kc_begin * BKT;
+        const int tap = k0 / p.Cin;
+        pf_c0 = k0 - tap * p.Cin;
+        pf_ty = tap / p.KW;
+        pf_tx = tap - pf_ty * p.KW;
+    }
 
-    auto prefetch = [&](int kc) {
-        const int k0 = kc * BK;
+    float4 rbuf_a[DEPTH][PA], rbuf_b[DEPTH][PB];
+    unsigned rmask[DEPTH];      // per stage: bit q set = A row q of that chunk is in-bounds (else zero padding)
+
+    auto prefetch = [&](int kc, float4 (&ra)[PA], float4 (&rb)[PB], unsigned& mask) {
+        const int k0 = kc * BKT;
         if constexpr (!GENERIC) {
-            const int tap = k0 / p.Cin;
-            const int c0 = k0 - tap * p.Cin;
-            const int ty = tap / p.KW;
-            const int tx = tap - ty * p.KW;
-            const int dy = ty * p.dil_h, dx = tx * p.dil_w;
+            const int c0 = pf_c0;
+            const int dy = pf_ty * p.dil_h, dx = pf_tx * p.dil_w;
+            pf_c0 += BKT;
+            if (pf_c0 >= p.Cin) {
+                pf_c0 = 0;
+                if (++pf_tx == p.KW) { pf_tx = 0; ++pf_ty; }
+            }
+            unsigned mk = 0;
 #pragma unroll
             for (int q = 0; q < PA; ++q) {
-                int iy = ay0[q] + dy, ix = ax0[q] + dx;
-                bool ok = avalid[q] && (unsigned)iy < (unsigned)vIH && (unsigned)ix < (unsigned)vIW;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ok) {
-                    const float* src = p.A + abase[q] +
-                                       ((size_t)(iy >> p.up) * p.IW + (size_t)(ix >> p.up)) * p.lda + c0 + lcol;
-                    v = *reinterpret_cast<const float4*>(src);
-                    if (p.in_act) {
-                        v.x = in_transform(v.x, p.in_act, p.in_slope);
-                        v.y = in_transform(v.y, p.in_act, p.in_slope);
-                        v.z = in_transform(v.z, p.in_act, p.in_slope);
-                        v.w = in_transform(v.w, p.in_act, p.in_slope);
-                    }
-                }
-                ra[q] = v;
+                const int iy = ay0[q] + dy, ix = ax0[q] + dx;
+                const bool ok = avalid[q] && (unsigned)iy < (unsigned)vIH && (unsigned)ix < (unsigned)vIW;
+                // clamped, always-valid address; the zero padding is applied at the LDS write so that the
+                // raw load stays in flight (nothing consumes it here)
+                const int cy = ok ? (iy >> p.up) : 0, cx = ok ? (ix >> p.up) : 0;
+                const unsigned off = abase[q] + (unsigned)(cy * p.IW + cx) * (unsigned)p.lda + c0;
+                ra[q] = *reinterpret_cast<const float4*>(p.A + (ok ? off : (unsigned)lcol));
+                mk |= ok ? (1u << q) : 0u;
             }
+            mask = mk;
 #pragma unroll
-            for (int q = 0; q < PB; ++q) {
-                int n = n0 + lrow + 32 * q;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (n < p.N) v = *reinterpret_cast<const float4*>(p.W + (size_t)n * p.K + k0 + lcol);
-                rb[q] = v;
-            }
+            for (int q = 0; q < PB; ++q) rb[q] = *reinterpret_cast<const float4*>(p.W + wbase[q] + k0);
         } else {
 #pragma unroll
             for (int q = 0; q < PA; ++q) {
                 float tmp[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    int k = k0 + lcol + e;
+                    const int k = k0 + lcol + e;
                     float v = 0.f;
                     if (k < p.K && avalid[q]) {
-                        int tap = k / p.Cin;
-                        int c = k - tap * p.Cin;
-                        int ty = tap / p.KW;
-                        int tx = tap - ty * p.KW;
-                        int iy = ay0[q] + ty * p.dil_h, ix = ax0[q] + tx * p.dil_w;
-                        if ((unsigned)iy < (unsigned)vIH && (unsigned)ix < (unsigned)vIW) {
-                            v = p.A[abase[q] + ((size_t)(iy >> p.up) * p.IW + (size_t)(ix >> p.up)) * p.lda + c];
-                            v = in_transform(v, p.in_act, p.in_slope);
-                        }
+                        const int tap = k / p.Cin;
+                        const int c = k - tap * p.Cin;
+                        const int ty = tap / p.KW;
+                        const int tx = tap - ty * p.KW;
+                        const int iy = ay0[q] + ty * p.dil_h, ix = ax0[q] + tx * p.dil_w;
+                        if ((unsigned)iy < (unsigned)vIH && (unsigned)ix < (unsigned)vIW)
+                            v = p.A[(size_t)(abase[q] - lcol) +
+                                    ((size_t)(iy >> p.up) * p.IW + (size_t)(ix >> p.up)) * p.lda + c];
                     }
                     tmp[e] = v;
                 }
                 ra[q] = make_float4(tmp[0], tmp[1], tmp[2], tmp[3]);
             }
+            mask = 0xffffffffu;
 #pragma unroll
             for (int q = 0; q < PB; ++q) {
-                int n = n0 + lrow + 32 * q;
                 float tmp[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    int k = k0 + lcol + e;
-                    tmp[e] = (n < p.N && k < p.K) ? p.W[(size_t)n * p.K + k] : 0.f;
+                    const int k = k0 + lcol + e;
+                    tmp[e] = (wvalid[q] && k < p.K) ? p.W[(size_t)(wbase[q] - lcol) + k] : 0.f;
                 }
                 rb[q] = make_float4(tmp[0], tmp[1], tmp[2], tmp[3]);
             }
@@ -201,55 +219,246 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(CGParams p) {
     const float* a_frag = As + (wr * WM + fi) * LDS_LD + 4 * fh;
     const float* b_frag = Ws + (wc * WN + fi) * LDS_LD + 4 * fh;
 
-    if (kc_begin < kc_end) prefetch(kc_begin);
-    for (int kc = kc_begin; kc < kc_end; ++kc) {
+    STAMP();
 #pragma unroll
-        for (int q = 0; q < PA; ++q)
-            *reinterpret_cast<float4*>(As + (lrow + 32 * q) * LDS_LD + lcol) = ra[q];
+    for (int d = 0; d < DEPTH; ++d)
+        if (kc_begin + d < kc_end) prefetch(kc_begin + d, rbuf_a[d], rbuf_b[d], rmask[d]);
+    STAMP();
+    for (int kc0 = kc_begin; kc0 < kc_end; kc0 += DEPTH) {
 #pragma unroll
-        for (int q = 0; q < PB; ++q)
-            *reinterpret_cast<float4*>(Ws + (lrow + 32 * q) * LDS_LD + lcol) = rb[q];
-        __syncthreads();
-        if (kc + 1 < kc_end) prefetch(kc + 1);
+        for (int d = 0; d < DEPTH; ++d) {
+            const int kc = kc0 + d;
+            if (kc >= kc_end) break;
 #pragma unroll
-        for (int kb = 0; kb < BK / 8; ++kb) {
-            float4 af[TM], bf[TN];
-#pragma unroll
-            for (int a = 0; a < TM; ++a)
-                af[a] = *reinterpret_cast<const float4*>(a_frag + a * 32 * LDS_LD + kb * 8);
-#pragma unroll
-            for (int b = 0; b < TN; ++b)
-                bf[b] = *reinterpret_cast<const float4*>(b_frag + b * 32 * LDS_LD + kb * 8);
-#pragma unroll
-            for (int a = 0; a < TM; ++a)
-#pragma unroll
-                for (int b = 0; b < TN; ++b) {
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].x, bf[b].x, acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].y, bf[b].y, acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].z, bf[b].z, acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].w, bf[b].w, acc[a][b], 0, 0, 0);
+            for (int q = 0; q < PA; ++q) {
+                float4 v = rbuf_a[d][q];
+                if (!((rmask[d] >> q) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.in_act) {         // SiLU / LeakyReLU of the A operand; f(0) = 0 keeps the zero padding
+                    v.x = in_transform(v.x, p.in_act, p.in_slope);
+                    v.y = in_transform(v.y, p.in_act, p.in_slope);
+                    v.z = in_transform(v.z, p.in_act, p.in_slope);
+                    v.w = in_transform(v.w, p.in_act, p.in_slope);
                 }
+                *reinterpret_cast<float4*>(As + (lrow + RPP * q) * LDS_LD + lcol) = v;
+            }
+#pragma unroll
+            for (int q = 0; q < PB; ++q)
+                *reinterpret_cast<float4*>(Ws + (lrow + RPP * q) * LDS_LD + lcol) =
+                    wvalid[q] ? rbuf_b[d][q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            __syncthreads();
+            STAMP();
+            if (kc + DEPTH < kc_end) prefetch(kc + DEPTH, rbuf_a[d], rbuf_b[d], rmask[d]);
+#pragma unroll
+            for (int kb = 0; kb < BKT / 8; ++kb) {
+                float4 af[TM], bf[TN];
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+                    af[a] = *reinterpret_cast<const float4*>(a_frag + a * 32 * LDS_LD + kb * 8);
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    bf[b] = *reinterpret_cast<const float4*>(b_frag + b * 32 * LDS_LD + kb * 8);
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) {
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].x, bf[b].x, acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].y, bf[b].y, acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].z, bf[b].z, acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].w, bf[b].w, acc[a][b], 0, 0, 0);
+                    }
+            }
+            __syncthreads();
+            STAMP();
         }
-        __syncthreads();
     }
 
-    // epilogue: acc[a][b][r] is C[row = (r&3) + 8*(r>>2) + 4*fh][col = fi] of the 32x32 tile
+    // ---- epilogue: acc[a][b][r] is C[row = (r&3) + 8*(r>>2) + 4*fh][col = fi] of the 32x32 tile.
+    // Straight-line: every flag is kernel-uniform, every address is clamped in-bounds, so the residual /
+    // previous-value loads of a tile issue as one batch (C may alias the residual: a per-element
+    // load->store chain costs ~25k cycles).
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
             const int n = n0 + wc * WN + b * 32 + fi;
+            const int mbase = m0 + wr * WM + a * 32 + 4 * fh;
             if (n >= p.N) continue;
+            if (p.ksplit > 1) {
+                float* wsp = p.ws + ((size_t)blockIdx.z * p.M + mbase) * p.N + n;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wr * WM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                if (m >= p.M) continue;
-                if (p.ksplit > 1)
-                    p.ws[((size_t)blockIdx.z * p.M + m) * p.N + n] = acc[a][b][r];
-                else
-                    store_out(p, m, n, acc[a][b][r]);
+                for (int r = 0; r < 16; ++r) {
+                    const int dm = (r & 3) + 8 * (r >> 2);
+                    if (mbase + dm < p.M) wsp[(unsigned)dm * (unsigned)p.N] = acc[a][b][r];
+                }
+                continue;
+            }
+            const float bias_v = p.bias ? p.bias[n] : 0.f;
+            unsigned rows[16];
+            bool ok[16];
+            {
+                const int mb = min(mbase, p.M - 1);
+                const int b0 = mb / p.rpb;
+                const int q0 = mb - b0 * p.rpb;
+                const int bmax = (p.M - 1) / p.rpb;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dm = (r & 3) + 8 * (r >> 2);
+                    int bb, q;
+                    if (p.rpb >= 32) {                 // at most one batch-item wrap inside a 32-row tile
+                        q = q0 + dm;
+                        const bool wrap = q >= p.rpb;
+                        bb = wrap ? b0 + 1 : b0;
+                        q = wrap ? q - p.rpb : q;
+                    } else {
+                        const int mm = min(mbase + dm, p.M - 1);
+                        bb = mm / p.rpb;
+                        q = mm - bb * p.rpb;
+                    }
+                    const int o = q * p.o_mul + p.o_add;
+                    ok[r] = (mbase + dm) < p.M && (unsigned)o < (unsigned)p.o_len;
+                    rows[r] = (unsigned)min(bb, bmax) * (unsigned)p.out_bs + (unsigned)min(max(o, 0), p.o_len - 1);
+                }
+            }
+            float val[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) val[r] = acc[a][b][r] + bias_v;
+            if (p.rowvec) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    val[r] += p.rowvec[(rows[r] / (unsigned)p.out_bs) * (unsigned)p.ld_rv + n];
+            }
+            if (p.res) {
+                float rv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rv[r] = p.res[rows[r] * (unsigned)p.ldr + n];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) val[r] += rv[r];
+            }
+            if (p.out_act != AED_ACT_NONE) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) val[r] = aed_apply_act(val[r], p.out_act, p.out_p);
+            }
+            if (p.accumulate) {
+                float pv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pv[r] = p.C[rows[r] * (unsigned)p.ldc + n];
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    val[r] = (p.accumulate == 1) ? val[r] + pv[r] : (pv[r] + val[r]) / p.out_div;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (ok[r]) p.C[rows[r] * (unsigned)p.ldc + n] = val[r];
+        }
+    STAMP();
+    if (dbg_on) p.dbg[31] = dbg_n;
+#undef STAMP
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Wave-split-K variant for the SMALL contractions of the edit loop (U-Net batch 2: M*N of a few hundred
+// 32x32 tiles, K of a few hundred).  There the LDS-staged kernel above is latency-bound (measured: ~10 us
+// floor for 3 us of MFMA work).  Here a block owns ONE 32x32 output tile and its 4 wavefronts split K:
+// every wave streams its own K range of the A and W rows straight into MFMA operand registers (lane
+// (i,h) loads 4 consecutive k of row i -- no LDS, no barrier in the main loop, loads of the next
+// k-blocks in flight behind the MFMAs), the four partial tiles meet once in LDS, are summed in a fixed
+// order (deterministic) and every thread finishes 4 outputs with coalesced stores.  4x more blocks than
+// 64x64 tiles and a 4x shorter dependent MFMA chain per wave.
+template <int UNROLL>
+__global__ __launch_bounds__(256) void conv_gemm_wsk_kernel(CGParams p) {
+    __shared__ float part[4][16][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fi = lane & 31, fh = lane >> 5;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+
+    // this wave's range of 8-wide k-blocks
+    const int nkb = p.K >> 3;
+    const int parts = 4 * p.ksplit;
+    const int part_id = blockIdx.z * 4 + wave;
+    const int base = nkb / parts, rem = nkb % parts;
+    const int kb_begin = part_id * base + min(part_id, rem);
+    const int kb_end = kb_begin + base + (part_id < rem ? 1 : 0);
+
+    // A row of this lane
+    const int m = m0 + fi;
+    const bool mvalid = m < p.M;
+    const int mm = mvalid ? m : 0;
+    const int bidx = mm / p.rpb;
+    const int rr = mm - bidx * p.rpb;
+    const int oy = rr / p.OW, ox = rr - oy * p.OW;
+    const int ay0 = oy * p.stride - p.pad_h, ax0 = ox * p.stride - p.pad_w;
+    const unsigned abase = (unsigned)bidx * (unsigned)p.a_bs + 4 * fh;
+    const int vIH = p.IH << p.up, vIW = p.IW << p.up;
+    const int n = n0 + fi;
+    const bool nvalid = n < p.N;
+    const float* wrow = p.W + (size_t)(nvalid ? n : 0) * p.K + 4 * fh;
+
+    // running tap position
+    int k0 = kb_begin * 8;
+    int tap = k0 / p.Cin;
+    int c0 = k0 - tap * p.Cin;
+    int ty = tap / p.KW, tx = tap - ty * p.KW;
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    for (int kb = kb_begin; kb < kb_end; kb += UNROLL) {
+        float4 av[UNROLL], wv[UNROLL];
+        bool aok[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const bool live = kb + u < kb_end;
+            const int iy = ay0 + ty * p.dil_h, ix = ax0 + tx * p.dil_w;
+            const bool ok = live && mvalid && (unsigned)iy < (unsigned)vIH && (unsigned)ix < (unsigned)vIW;
+            const int cy = ok ? (iy >> p.up) : 0, cx = ok ? (ix >> p.up) : 0;
+            const unsigned off = abase + (unsigned)(cy * p.IW + cx) * (unsigned)p.lda + c0;
+            av[u] = *reinterpret_cast<const float4*>(p.A + (ok ? off : 4u * fh));
+            wv[u] = *reinterpret_cast<const float4*>(wrow + (live ? k0 : 0));
+            aok[u] = ok;
+            if (!(live && nvalid)) wv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            k0 += 8;
+            c0 += 8;
+            if (c0 >= p.Cin) {
+                c0 = 0;
+                if (++tx == p.KW) { tx = 0; ++ty; }
             }
         }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            float4 a = aok[u] ? av[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.in_act) {
+                a.x = in_transform(a.x, p.in_act, p.in_slope);
+                a.y = in_transform(a.y, p.in_act, p.in_slope);
+                a.z = in_transform(a.z, p.in_act, p.in_slope);
+                a.w = in_transform(a.w, p.in_act, p.in_slope);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, wv[u].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, wv[u].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, wv[u].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, wv[u].w, acc, 0, 0, 0);
+        }
+    }
+    // partial tiles -> LDS.  acc[r] = C[row (r&3)+8*(r>>2)+4*fh][col fi]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[wave][r][lane] = acc[r];
+    __syncthreads();
+    // thread t finishes 4 outputs: (row, col) with col = t & 31 (coalesced), row = (t >> 5) + 8*j
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = (tid >> 5) + 8 * j;
+        const int col = tid & 31;
+        // inverse of the accumulator map: row = (r&3) + 8*(r>>2) + 4*h
+        const int h = (row >> 2) & 1;
+        const int r = (row & 3) + 4 * (row >> 3);
+        const int src_lane = col + 32 * h;
+        const float v = ((part[0][r][src_lane] + part[1][r][src_lane]) + part[2][r][src_lane]) + part[3][r][src_lane];
+        const int mo = m0 + row, no = n0 + col;
+        if (mo < p.M && no < p.N) {
+            if (p.ksplit > 1) p.ws[((size_t)blockIdx.z * p.M + mo) * p.N + no] = v;
+            else store_out(p, mo, no, v);
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(CGParams p) {
@@ -263,7 +472,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(CGParams p) {
     }
 }
 
-static int fill_params(const aed_op* op, CGParams& p) {
+static int fill_params(const aed_op* op, CGParams& p, int bkt) {
     p.A = (const float*)op->p[0];
     p.W = (const float*)op->p[1];
     p.bias = (const float*)op->p[2];
@@ -271,6 +480,7 @@ static int fill_params(const aed_op* op, CGParams& p) {
     p.res = (const float*)op->p[4];
     p.rowvec = (const float*)op->p[5];
     p.ws = (float*)op->p[6];
+    p.dbg = (long long*)op->p[7];
     const int32_t* i = op->i;
     p.M = i[0]; p.N = i[1]; p.K = i[2]; p.lda = i[3]; p.ldc = i[4]; p.ldr = i[5]; p.ld_rv = i[6];
     p.IH = i[7]; p.IW = i[8]; p.OH = i[9]; p.OW = i[10]; p.Cin = i[11]; p.KH = i[12]; p.KW = i[13];
@@ -279,51 +489,69 @@ static int fill_params(const aed_op* op, CGParams& p) {
     p.in_act = i[25]; p.out_act = i[26]; p.accumulate = i[27]; p.ksplit = i[28];
     p.in_slope = op->f[0]; p.out_p = op->f[1]; p.out_div = op->f[2];
     p.rpb = p.OH * p.OW;
-    p.nchunks = (p.K + BK - 1) / BK;
+    p.nchunks = (p.K + bkt - 1) / bkt;
     AED_REQUIRE(p.A && p.W && p.C, "conv_gemm: null operand");
     AED_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "conv_gemm: bad shape M=%d N=%d K=%d", p.M, p.N, p.K);
     AED_REQUIRE(p.K == p.KH * p.KW * p.Cin, "conv_gemm: K=%d != KH*KW*Cin=%d", p.K, p.KH * p.KW * p.Cin);
     AED_REQUIRE(p.rpb > 0 && p.M % p.rpb == 0, "conv_gemm: M=%d not a multiple of OH*OW=%d", p.M, p.rpb);
+    AED_REQUIRE((long long)(p.M / p.rpb) * p.a_bs + (long long)p.IH * p.IW * p.lda < (1LL << 31) &&
+                    (long long)p.N * p.K < (1LL << 31) &&
+                    ((long long)(p.M / p.rpb) * p.out_bs + 1) * (long long)(p.ldc > p.ldr ? p.ldc : p.ldr) < (1LL << 31),
+                "conv_gemm: operand exceeds the 32-bit element-offset range");
     if (p.ksplit < 1) p.ksplit = 1;
+    if (p.ksplit > p.nchunks) p.ksplit = p.nchunks;
     if (p.ksplit > 1) AED_REQUIRE(p.ws != nullptr, "conv_gemm: split-K needs a workspace");
     return 0;
 }
 
-template <int BM, int BN, int WR, int WC>
-static void launch_cfg(const CGParams& p, bool generic, hipStream_t s) {
+template <int BM, int BN, int WR, int WC, int D32, int D64>
+static void launch_cfg(const CGParams& p, bool generic, bool bk64, hipStream_t s) {
     dim3 grid(aed_cdiv(p.N, BN), aed_cdiv(p.M, BM), p.ksplit);
     if (generic)
-        hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WR, WC, true>), grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WR, WC, true, 1, 32>), grid, dim3(256), 0, s, p);
+    else if (bk64)
+        hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WR, WC, false, D64, 64>), grid, dim3(256), 0, s, p);
     else
-        hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WR, WC, false>), grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WR, WC, false, D32, 32>), grid, dim3(256), 0, s, p);
 }
 
 // tile_cfg: 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x128, 4 = 64x64, 5 = 128x32, 6 = 32x128
+// i[30] = 1 forces the 32-wide K chunk (A/B testing)
 int launch_conv_gemm(const aed_op* op, hipStream_t s) {
     CGParams p;
-    int rc = fill_params(op, p);
-    if (rc) return rc;
-    const bool generic = (p.Cin % BK != 0) || (p.lda % 4 != 0) || ((uintptr_t)p.A % 16 != 0) ||
-                         ((uintptr_t)p.W % 16 != 0);
-    int cfg = op->i[29];
+    const int32_t* i = op->i;
+    const int Cin = i[11];
+    const bool generic = (Cin % 32 != 0) || (i[3] % 4 != 0) || ((uintptr_t)op->p[0] % 16 != 0) ||
+                         ((uintptr_t)op->p[1] % 16 != 0);
+    int cfg = i[29];
     if (cfg == 0) {
         const int cus = aed_num_cus();
-        auto blocks = [&](int bm, int bn) { return (long)aed_cdiv(p.M, bm) * aed_cdiv(p.N, bn) * p.ksplit; };
-        const int n_small = p.N <= 32;
-        if (n_small) cfg = 5;
-        else if (p.M <= 32) cfg = 6;
-        else if (blocks(128, 128) >= 2L * cus && p.N >= 128) cfg = 1;
-        else if (blocks(128, 64) >= 2L * cus && p.N >= 64) cfg = 2;
+        const int M = i[0], N = i[1], ks = i[28] > 1 ? i[28] : 1;
+        auto blocks = [&](int bm, int bn) { return (long)aed_cdiv(M, bm) * aed_cdiv(N, bn) * ks; };
+        if (N <= 32) cfg = 5;
+        else if (M <= 32) cfg = 6;
+        else if (blocks(128, 128) >= 2L * cus && N >= 128) cfg = 1;
+        else if (blocks(128, 64) >= 2L * cus && N >= 64) cfg = 2;
         else cfg = 4;
-        if (p.N < 64 && cfg != 5) cfg = 5;
+        if (N < 64 && cfg != 5) cfg = 5;
     }
+    // 64-wide K chunks halve the barrier count; the 128x128 tile would need 70 KB of LDS, so it stays at 32
+    const bool bk64 = !generic && (Cin % 64 == 0) && i[30] != 1 && cfg != 1 && cfg != 7;
+    int rc = fill_params(op, p, cfg == 7 ? 8 : (bk64 ? 64 : 32));
+    if (rc) return rc;
     switch (cfg) {
-        case 1: launch_cfg<128, 128, 2, 2>(p, generic, s); break;
-        case 2: launch_cfg<128, 64, 2, 2>(p, generic, s); break;
-        case 3: launch_cfg<64, 128, 2, 2>(p, generic, s); break;
-        case 4: launch_cfg<64, 64, 2, 2>(p, generic, s); break;
-        case 5: launch_cfg<128, 32, 4, 1>(p, generic, s); break;
-        case 6: launch_cfg<32, 128, 1, 4>(p, generic, s); break;
+        case 1: launch_cfg<128, 128, 2, 2, 2, 1>(p, generic, bk64, s); break;
+        case 2: launch_cfg<128, 64, 2, 2, 3, 2>(p, generic, bk64, s); break;
+        case 3: launch_cfg<64, 128, 2, 2, 3, 2>(p, generic, bk64, s); break;
+        case 4: launch_cfg<64, 64, 2, 2, 4, 2>(p, generic, bk64, s); break;
+        case 5: launch_cfg<128, 32, 4, 1, 4, 2>(p, generic, bk64, s); break;
+        case 6: launch_cfg<32, 128, 1, 4, 4, 2>(p, generic, bk64, s); break;
+        case 7: {
+            AED_REQUIRE(!generic && p.Cin % 8 == 0, "conv_gemm: wave-split-K needs the vector path");
+            dim3 grid(aed_cdiv(p.N, 32), aed_cdiv(p.M, 32), p.ksplit);
+            hipLaunchKernelGGL((conv_gemm_wsk_kernel<4>), grid, dim3(256), 0, s, p);
+            break;
+        }
         default: AED_REQUIRE(false, "conv_gemm: bad tile cfg %d", cfg);
     }
     AED_CHECK_HIP(hipGetLastError());
@@ -339,7 +567,7 @@ int launch_conv_gemm(const aed_op* op, hipStream_t s) {
 
 int launch_splitk_reduce(const aed_op* op, hipStream_t s) {
     CGParams p;
-    int rc = fill_params(op, p);
+    int rc = fill_params(op, p, 32);
     if (rc) return rc;
     size_t total = (size_t)p.M * p.N;
     int grid = (int)((total + 255) / 256);

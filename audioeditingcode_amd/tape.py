@@ -66,12 +66,17 @@ class Tape:
 
     # ------------------------------------------------------------------ conv / linear
     @staticmethod
-    def pick_tile(M, N, K, cus=None):
-        """Mirror of the C++ heuristic, made explicit so split-K workspaces can be sized here."""
+    def pick_tile(M, N, K, cus=None, vector_ok=True):
+        """Tile / split-K choice, from the per-shape microbenchmarks of round 1 (scratch: mb_gemm):
+        small M*N with short K -> wave-split-K kernel (cfg 7, 32x32 tile per block, no reduce launch);
+        otherwise the LDS-staged kernel with the largest tile that still fills the chip, split-K
+        (deterministic slab reduce) when the grid would be < 1 block per CU."""
         cus = cus or CU_COUNT
 
         def blocks(bm, bn):
             return math.ceil(M / bm) * math.ceil(N / bn)
+        if vector_ok and N > 32 and M > 32 and blocks(64, 64) <= 192 and K <= 2560 and K % 8 == 0:
+            return 7, max(1, math.ceil(K / 1024))
         if N <= 32:
             cfg, bm, bn = 5, 128, 32
         elif M <= 32:
@@ -105,7 +110,8 @@ class Tape:
             ldr = res.stride(-2)
         o_len = OH * OW if o_len is None else o_len
         out_bs = OH * OW if out_bs is None else out_bs
-        auto_tile, auto_split = self.pick_tile(M, N, K)
+        vec_ok = (Cin % 32 == 0) and (lda % 4 == 0)
+        auto_tile, auto_split = self.pick_tile(M, N, K, vector_ok=vec_ok)
         tile = tile or auto_tile
         ksplit = ksplit or auto_split
         i = [M, N, K, lda, ldc, ldr or 0, ld_rv, IH, IW, OH, OW, Cin, KH, KW, stride, pad_h, pad_w, dil_h, dil_w, up,

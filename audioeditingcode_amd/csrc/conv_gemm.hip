@@ -43,6 +43,8 @@ struct CGParams {
     int rpb;                 // output rows per batch item = OH*OW
     int nchunks;             // ceil(K/BKT)
     float in_slope, out_p, out_div;
+    int ln_mode;             // 1: A rows are LayerNorm inputs; W has gamma folded in, rowvec = sum_k W'[n,k], bias = W.beta (+bias)
+    float ln_eps;
 };
 
 __device__ __forceinline__ float in_transform(float v, int act, float slope) {
@@ -59,7 +61,7 @@ __device__ __forceinline__ void store_out(const CGParams& p, int m, int n, float
     if ((unsigned)o >= (unsigned)p.o_len) return;
     size_t row = (size_t)b * p.out_bs + o;
     if (p.bias) v += p.bias[n];
-    if (p.rowvec) v += p.rowvec[(size_t)b * p.ld_rv + n];
+    if (p.rowvec && !p.ln_mode) v += p.rowvec[(size_t)b * p.ld_rv + n];
     if (p.res) v += p.res[row * p.ldr + n];
     v = aed_apply_act(v, p.out_act, p.out_p);
     float* dst = p.C + row * p.ldc + n;
@@ -143,6 +145,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(CGParams p) {
     }
 
     float4 rbuf_a[DEPTH][PA], rbuf_b[DEPTH][PB];
+    float ln_s1[PA], ln_s2[PA];   // fused LayerNorm: running sum / sum of squares of this thread's A rows
+#pragma unroll
+    for (int q = 0; q < PA; ++q) { ln_s1[q] = 0.f; ln_s2[q] = 0.f; }
     unsigned rmask[DEPTH];      // per stage: bit q set = A row q of that chunk is in-bounds (else zero padding)
 
     auto prefetch = [&](int kc, float4 (&ra)[PA], float4 (&rb)[PB], unsigned& mask) {
@@ -233,6 +238,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(CGParams p) {
             for (int q = 0; q < PA; ++q) {
                 float4 v = rbuf_a[d][q];
                 if (!((rmask[d] >> q) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.ln_mode) {
+                    ln_s1[q] += (v.x + v.y) + (v.z + v.w);
+                    ln_s2[q] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                }
                 if (p.in_act) {         // SiLU / LeakyReLU of the A operand; f(0) = 0 keeps the zero padding
                     v.x = in_transform(v.x, p.in_act, p.in_slope);
                     v.y = in_transform(v.y, p.in_act, p.in_slope);
@@ -270,6 +279,27 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(CGParams p) {
             __syncthreads();
             STAMP();
         }
+    }
+
+    // ---- fused LayerNorm: finish the per-row statistics (the loader threads of a row are TPR adjacent lanes)
+    float* ln_stat = lds;                 // [BM][2] (mean, rstd); the operand tiles are dead after the last barrier
+    if (p.ln_mode) {
+#pragma unroll
+        for (int q = 0; q < PA; ++q) {
+            float s1 = ln_s1[q], s2 = ln_s2[q];
+#pragma unroll
+            for (int o = TPR / 2; o > 0; o >>= 1) {
+                s1 += __shfl_xor(s1, o, 64);
+                s2 += __shfl_xor(s2, o, 64);
+            }
+            if ((tid % TPR) == 0) {
+                const float mean = s1 / (float)p.K;
+                const float var = fmaxf(s2 / (float)p.K - mean * mean, 0.f);
+                ln_stat[2 * (lrow + RPP * q)] = mean;
+                ln_stat[2 * (lrow + RPP * q) + 1] = 1.0f / sqrtf(var + p.ln_eps);
+            }
+        }
+        __syncthreads();
     }
 
     // ---- epilogue: acc[a][b][r] is C[row = (r&3) + 8*(r>>2) + 4*fh][col = fi] of the 32x32 tile.
@@ -320,9 +350,18 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(CGParams p) {
                 }
             }
             float val[16];
+            if (p.ln_mode) {       // LN(x).W = rstd*(x.W' - mean*sum_k W') + W.beta   (W' = W*gamma, folded on the host)
+                const float sn = p.rowvec[n];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) val[r] = acc[a][b][r] + bias_v;
-            if (p.rowvec) {
+                for (int r = 0; r < 16; ++r) {
+                    const int lr = wr * WM + a * 32 + 4 * fh + (r & 3) + 8 * (r >> 2);
+                    val[r] = ln_stat[2 * lr + 1] * (acc[a][b][r] - ln_stat[2 * lr] * sn) + bias_v;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) val[r] = acc[a][b][r] + bias_v;
+            }
+            if (p.rowvec && !p.ln_mode) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     val[r] += p.rowvec[(rows[r] / (unsigned)p.out_bs) * (unsigned)p.ld_rv + n];
@@ -367,6 +406,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(CGParams p) {
 template <int UNROLL>
 __global__ __launch_bounds__(256) void conv_gemm_wsk_kernel(CGParams p) {
     __shared__ float part[4][16][64];
+    __shared__ float ln_part[4][32][2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fi = lane & 31, fh = lane >> 5;
     const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
@@ -402,6 +442,7 @@ __global__ __launch_bounds__(256) void conv_gemm_wsk_kernel(CGParams p) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float ln_s1 = 0.f, ln_s2 = 0.f;
 
     for (int kb = kb_begin; kb < kb_end; kb += UNROLL) {
         float4 av[UNROLL], wv[UNROLL];
@@ -427,6 +468,10 @@ __global__ __launch_bounds__(256) void conv_gemm_wsk_kernel(CGParams p) {
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             float4 a = aok[u] ? av[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.ln_mode) {
+                ln_s1 += (a.x + a.y) + (a.z + a.w);
+                ln_s2 += (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
+            }
             if (p.in_act) {
                 a.x = in_transform(a.x, p.in_act, p.in_slope);
                 a.y = in_transform(a.y, p.in_act, p.in_slope);
@@ -442,6 +487,11 @@ __global__ __launch_bounds__(256) void conv_gemm_wsk_kernel(CGParams p) {
     // partial tiles -> LDS.  acc[r] = C[row (r&3)+8*(r>>2)+4*fh][col fi]
 #pragma unroll
     for (int r = 0; r < 16; ++r) part[wave][r][lane] = acc[r];
+    if (p.ln_mode) {
+        ln_s1 += __shfl_xor(ln_s1, 32, 64);
+        ln_s2 += __shfl_xor(ln_s2, 32, 64);
+        if (fh == 0) { ln_part[wave][fi][0] = ln_s1; ln_part[wave][fi][1] = ln_s2; }
+    }
     __syncthreads();
     // thread t finishes 4 outputs: (row, col) with col = t & 31 (coalesced), row = (t >> 5) + 8*j
 #pragma unroll
@@ -452,8 +502,15 @@ __global__ __launch_bounds__(256) void conv_gemm_wsk_kernel(CGParams p) {
         const int h = (row >> 2) & 1;
         const int r = (row & 3) + 4 * (row >> 3);
         const int src_lane = col + 32 * h;
-        const float v = ((part[0][r][src_lane] + part[1][r][src_lane]) + part[2][r][src_lane]) + part[3][r][src_lane];
+        float v = ((part[0][r][src_lane] + part[1][r][src_lane]) + part[2][r][src_lane]) + part[3][r][src_lane];
         const int mo = m0 + row, no = n0 + col;
+        if (p.ln_mode && no < p.N) {
+            const float s1 = ((ln_part[0][row][0] + ln_part[1][row][0]) + ln_part[2][row][0]) + ln_part[3][row][0];
+            const float s2 = ((ln_part[0][row][1] + ln_part[1][row][1]) + ln_part[2][row][1]) + ln_part[3][row][1];
+            const float mean = s1 / (float)p.K;
+            const float var = fmaxf(s2 / (float)p.K - mean * mean, 0.f);
+            v = (v - mean * p.rowvec[no]) / sqrtf(var + p.ln_eps);
+        }
         if (mo < p.M && no < p.N) {
             if (p.ksplit > 1) p.ws[((size_t)blockIdx.z * p.M + mo) * p.N + no] = v;
             else store_out(p, mo, no, v);
@@ -488,6 +545,7 @@ static int fill_params(const aed_op* op, CGParams& p, int bkt) {
     p.a_bs = i[20]; p.o_mul = i[21]; p.o_add = i[22]; p.o_len = i[23]; p.out_bs = i[24];
     p.in_act = i[25]; p.out_act = i[26]; p.accumulate = i[27]; p.ksplit = i[28];
     p.in_slope = op->f[0]; p.out_p = op->f[1]; p.out_div = op->f[2];
+    p.ln_mode = i[31]; p.ln_eps = op->f[3];
     p.rpb = p.OH * p.OW;
     p.nchunks = (p.K + bkt - 1) / bkt;
     AED_REQUIRE(p.A && p.W && p.C, "conv_gemm: null operand");
@@ -501,6 +559,9 @@ static int fill_params(const aed_op* op, CGParams& p, int bkt) {
     if (p.ksplit < 1) p.ksplit = 1;
     if (p.ksplit > p.nchunks) p.ksplit = p.nchunks;
     if (p.ksplit > 1) AED_REQUIRE(p.ws != nullptr, "conv_gemm: split-K needs a workspace");
+    if (p.ln_mode)
+        AED_REQUIRE(p.ksplit == 1 && p.KH * p.KW == 1 && p.rowvec && p.bias && p.in_act == 0,
+                    "conv_gemm: fused LayerNorm needs a 1-tap, unsplit GEMM with folded weights");
     return 0;
 }
 

@@ -99,7 +99,7 @@ class Tape:
     def conv(self, x, w, bias, out, *, B, IH, IW, Cin, OH, OW, N, KH=1, KW=1, stride=1, pad_h=0, pad_w=0,
              dil_h=1, dil_w=1, up=0, lda=None, a_bs=None, res=None, rowvec=None, ld_rv=0, in_act=0, in_slope=0.0,
              out_act=0, out_p=0.0, accumulate=0, out_div=1.0, o_mul=1, o_add=0, o_len=None, out_bs=None,
-             ldc=None, ldr=None, ksplit=0, tile=0, name="conv"):
+             ldc=None, ldr=None, ksplit=0, tile=0, ln_rowsum=None, ln_eps=1e-5, name="conv"):
         """Implicit-GEMM conv (AED_OP_CONV_GEMM).  x: [B,IH,IW,>=Cin] view, w: [N, KH*KW*Cin]."""
         M = B * OH * OW
         K = KH * KW * Cin
@@ -114,9 +114,16 @@ class Tape:
         auto_tile, auto_split = self.pick_tile(M, N, K, vector_ok=vec_ok)
         tile = tile or auto_tile
         ksplit = ksplit or auto_split
+        ln_mode = 0
+        if ln_rowsum is not None:
+            # fused LayerNorm: `w` carries gamma, `bias` = W.beta (+bias), `ln_rowsum`[n] = sum_k w[n,k]
+            assert KH * KW == 1 and rowvec is None and bias is not None and vec_ok
+            ln_mode, rowvec, ksplit = 1, ln_rowsum, 1
+            if tile == 7 and K > 1024:
+                tile = 4
         i = [M, N, K, lda, ldc, ldr or 0, ld_rv, IH, IW, OH, OW, Cin, KH, KW, stride, pad_h, pad_w, dil_h, dil_w, up,
-             a_bs, o_mul, o_add, o_len, out_bs, in_act, out_act, accumulate, ksplit, tile]
-        idx = self._add(L.OP_CONV_GEMM, i, [in_slope, out_p, out_div], [x, w, bias, out, res, rowvec, None],
+             a_bs, o_mul, o_add, o_len, out_bs, in_act, out_act, accumulate, ksplit, tile, 0, ln_mode]
+        idx = self._add(L.OP_CONV_GEMM, i, [in_slope, out_p, out_div, ln_eps], [x, w, bias, out, res, rowvec, None],
                         name=name, flops=2 * M * N * K, nbytes=4 * (B * IH * IW * Cin + N * K + M * N))
         if ksplit > 1:
             self._ws_need = max(self._ws_need, ksplit * M * N)

@@ -38,6 +38,17 @@ class PackedUNetWeights:
     def nbytes(self):
         return sum(v.numel() * 4 for v in self.wd.values())
 
+    def _fold_ln(self, name, w, gamma, beta, bias):
+        """Fold a LayerNorm's affine part into the following Linear (fp64 on the host, stored fp32)."""
+        w64, g64, b64 = w.double(), gamma.double(), beta.double()
+        wf = w64 * g64[None, :]
+        t = w64 @ b64
+        if bias is not None:
+            t = t + bias.double()
+        self.wd[name + ".weight"] = self._dev(wf.float())
+        self.wd[name + ".rowsum"] = self._dev(wf.float().double().sum(1).float())
+        self.wd[name + ".t"] = self._dev(t.float())
+
     def _pack(self, sd):
         """Re-lay weights: conv [O,I,kh,kw] -> [O, kh*kw*I]; fuse q/k/v; concatenate temb projections."""
         wd = self.wd
@@ -61,11 +72,22 @@ class PackedUNetWeights:
             if k.endswith(".to_q.weight"):
                 base = k[: -len(".to_q.weight")]
                 wq, wk, wv = v, sd[base + ".to_k.weight"], sd[base + ".to_v.weight"]
+                # the LayerNorm in front of this attention (norm1 -> attn1, norm2 -> attn2) is folded into the
+                # projection: LN(x).W^T = rstd*(x.(W*gamma)^T - mean*rowsum(W*gamma)) + W.beta
+                blk, which = base.rsplit(".", 1)
+                nrm = blk + (".norm1" if which == "attn1" else ".norm2")
                 if wk.shape[1] == wq.shape[1]:
-                    wd[base + ".qkv.weight"] = self._dev(torch.cat([wq, wk, wv], 0))
+                    wqkv = torch.cat([wq, wk, wv], 0)
+                    wd[base + ".qkv.weight"] = self._dev(wqkv)
+                    self._fold_ln(base + ".qkv_ln", wqkv, sd[nrm + ".weight"], sd[nrm + ".bias"], None)
                 wd[base + ".q.weight"] = self._dev(wq)
+                self._fold_ln(base + ".q_ln", wq, sd[nrm + ".weight"], sd[nrm + ".bias"], None)
                 wd[base + ".kv.weight"] = self._dev(torch.cat([wk, wv], 0))
                 continue
+            if k.endswith(".ff.net.0.proj.weight"):
+                blk = k[: -len(".ff.net.0.proj.weight")]
+                self._fold_ln(blk + ".ff1_ln", v, sd[blk + ".norm3.weight"], sd[blk + ".norm3.bias"],
+                              sd[blk + ".ff.net.0.proj.bias"])
             if k.endswith(".to_k.weight") or k.endswith(".to_v.weight"):
                 continue
             wd[k] = self._dev(v)
@@ -73,8 +95,9 @@ class PackedUNetWeights:
 
 class UNetEngine:
     def __init__(self, cfg, weights, device, batch, H, W, ctx_len0=0, ctx_len1=0, use_ehs=True,
-                 timesteps_dev=None, state_dev=None):
+                 timesteps_dev=None, state_dev=None, fuse_ln=True):
         self.cfg = cfg
+        self.fuse_ln = fuse_ln
         self.device = torch.device(device)
         self.B, self.H, self.W = batch, H, W
         self.use_ehs = use_ehs
@@ -118,20 +141,30 @@ class UNetEngine:
                 N=Cout, KH=3, KW=3, pad_h=1, pad_w=1, res=res, name=p + ".conv2")
         return dest
 
-    def _attn(self, p, x_ln, C, N, heads, out, kv=None, Lk=0, bias=None):
-        """attention sub-layer input projections + fused attention.  x_ln: [B*N, C] (already LayerNormed)."""
+    def _ln_linear(self, x, pfx, plain_w, plain_b, out, M, K, N, ln, name):
+        """Linear on LayerNorm(x).  Fused: raw x + gamma-folded weights + row statistics gathered inside the
+        GEMM (no LayerNorm launch, no normalised copy in HBM).  Unfused: `x` is already normalised."""
+        wd = self.wd
+        if ln:
+            self.tape.linear(x, wd[pfx + ".weight"], wd[pfx + ".t"], out, M=M, K=K, N=N,
+                             ln_rowsum=wd[pfx + ".rowsum"], name=name + "+ln")
+        else:
+            self.tape.linear(x, plain_w, plain_b, out, M=M, K=K, N=N, name=name)
+
+    def _attn(self, p, x_ln, C, N, heads, out, kv=None, Lk=0, bias=None, ln=False):
+        """attention sub-layer input projections + fused attention.  x_ln: [B*N, C] (LayerNormed, or raw if ln)."""
         tp, wd, B = self.tape, self.wd, self.B
         M = B * N
         D = C // heads
         if kv is None:
             qkv = self.tmp("t_qkv", M, 3 * C)
-            tp.linear(x_ln, wd[p + ".qkv.weight"], None, qkv, M=M, K=C, N=3 * C, name=p + ".qkv")
+            self._ln_linear(x_ln, p + ".qkv_ln", wd[p + ".qkv.weight"], None, qkv, M, C, 3 * C, ln, p + ".qkv")
             tp.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], out, B=B, H=heads, Nq=N, Nk=N, D=D, ldq=3 * C, ldk=3 * C,
                          ldv=3 * C, ldo=C, bsq=N * 3 * C, bsk=N * 3 * C, bsv=N * 3 * C, bso=N * C,
                          scale=D ** -0.5, name=p + ".sdpa")
         else:
             q = self.tmp("t_q", M, C)
-            tp.linear(x_ln, wd[p + ".q.weight"], None, q, M=M, K=C, N=C, name=p + ".q")
+            self._ln_linear(x_ln, p + ".q_ln", wd[p + ".q.weight"], None, q, M, C, C, ln, p + ".q")
             tp.attention(q, kv, kv[:, C:], out, B=B, H=heads, Nq=N, Nk=Lk, D=D, ldq=C, ldk=2 * C, ldv=2 * C, ldo=C,
                          bsq=N * C, bsk=Lk * 2 * C, bsv=Lk * 2 * C, bso=N * C, scale=D ** -0.5, bias=bias,
                          ld_bias=Lk if bias is not None else 0, name=p + ".sdpa_x")
@@ -149,14 +182,17 @@ class UNetEngine:
         b = p + ".transformer_blocks.0"
         ln = self.tmp("t_l", M, C)
         o = self.tmp("t_o", M, C)
-        tp.layernorm(t0, wd[b + ".norm1.weight"], wd[b + ".norm1.bias"], ln, M=M, C=C, name=b + ".norm1")
-        self._attn(b + ".attn1", ln, C, N, heads, o)
+        F = self.fuse_ln
+        if not F:
+            tp.layernorm(t0, wd[b + ".norm1.weight"], wd[b + ".norm1.bias"], ln, M=M, C=C, name=b + ".norm1")
+        self._attn(b + ".attn1", t0 if F else ln, C, N, heads, o, ln=F)
         t1 = self.tmp("t_1", M, C)
         tp.linear(o, wd[b + ".attn1.to_out.0.weight"], wd[b + ".attn1.to_out.0.bias"], t1, M=M, K=C, N=C, res=t0,
                   name=b + ".attn1.to_out")
-        tp.layernorm(t1, wd[b + ".norm2.weight"], wd[b + ".norm2.bias"], ln, M=M, C=C, name=b + ".norm2")
+        if not F:
+            tp.layernorm(t1, wd[b + ".norm2.weight"], wd[b + ".norm2.bias"], ln, M=M, C=C, name=b + ".norm2")
         if kind == "self2":
-            self._attn(b + ".attn2", ln, C, N, heads, o)
+            self._attn(b + ".attn2", t1 if F else ln, C, N, heads, o, ln=F)
         else:
             which = 0 if kind == "cross0" else 1
             Lk = self.L0 if which == 0 else self.L1
@@ -166,14 +202,15 @@ class UNetEngine:
             self.ctx_tape.linear(ctx.view(B * Lk, cdim), wd[b + ".attn2.kv.weight"], None, kv, M=B * Lk, K=cdim,
                                  N=2 * C, name=b + ".attn2.kv")
             bias = self.bias0 if which == 0 else self.bias1
-            self._attn(b + ".attn2", ln, C, N, heads, o, kv=kv, Lk=Lk, bias=bias)
+            self._attn(b + ".attn2", t1 if F else ln, C, N, heads, o, kv=kv, Lk=Lk, bias=bias, ln=F)
         t2 = self.tmp("t_2", M, C)
         tp.linear(o, wd[b + ".attn2.to_out.0.weight"], wd[b + ".attn2.to_out.0.bias"], t2, M=M, K=C, N=C, res=t1,
                   name=b + ".attn2.to_out")
-        tp.layernorm(t2, wd[b + ".norm3.weight"], wd[b + ".norm3.bias"], ln, M=M, C=C, name=b + ".norm3")
+        if not F:
+            tp.layernorm(t2, wd[b + ".norm3.weight"], wd[b + ".norm3.bias"], ln, M=M, C=C, name=b + ".norm3")
         g = self.tmp("t_g", M, 8 * C)
-        tp.linear(ln, wd[b + ".ff.net.0.proj.weight"], wd[b + ".ff.net.0.proj.bias"], g, M=M, K=C, N=8 * C,
-                  name=b + ".ff1")
+        self._ln_linear(t2 if F else ln, b + ".ff1_ln", wd[b + ".ff.net.0.proj.weight"],
+                        wd[b + ".ff.net.0.proj.bias"], g, M, C, 8 * C, F, b + ".ff1")
         f = self.tmp("t_f", M, 4 * C)
         tp.geglu(g, f, M=M, Dff=4 * C, name=b + ".geglu")
         t3 = self.tmp("t_3", M, C)

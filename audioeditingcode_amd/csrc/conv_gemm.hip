@@ -23,6 +23,7 @@
 #include "aed_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define GN_MAXC 1280   // largest GroupNorm'ed channel count on the path (up-block concat 640+640)
 
 struct CGParams {
     const float* A;
@@ -43,6 +44,8 @@ struct CGParams {
     int rpb;                 // output rows per batch item = OH*OW
     int nchunks;             // ceil(K/BKT)
     float in_slope, out_p, out_div;
+    const float* gn_ab;      // fused GroupNorm: per batch item [2][Cin] = (scale a, shift d); x' = act(x*a + d)
+    int gn_act;
     int ln_mode;             // 1: A rows are LayerNorm inputs; W has gamma folded in, rowvec = sum_k W'[n,k], bias = W.beta (+bias)
     float ln_eps;
 };
@@ -82,6 +85,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(CGParams p) {
     static_assert(TM >= 1 && TN >= 1 && PA >= 1 && PB >= 1, "tile");
 
     __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * LDS_LD];
+    __shared__ __attribute__((aligned(16))) float gn_lds[GENERIC ? 4 : 2 * GN_MAXC];
     float* As = lds;
     float* Ws = lds + BM * LDS_LD;
 
@@ -144,16 +148,27 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(CGParams p) {
         pf_tx = tap - pf_ty * p.KW;
     }
 
+    // fused GroupNorm (+SiLU): the block's rows belong to ONE batch item (host guarantees OH*OW % BM == 0);
+    // its per-channel scale/shift vectors are staged in LDS once and applied at the LDS write
+    if constexpr (!GENERIC) {
+        if (p.gn_ab) {
+            const float4* src = reinterpret_cast<const float4*>(p.gn_ab + (size_t)(m0 / p.rpb) * 2 * p.Cin);
+            for (int idx = tid; idx < p.Cin / 2; idx += 256) reinterpret_cast<float4*>(gn_lds)[idx] = src[idx];
+            __syncthreads();
+        }
+    }
+    int rc0[DEPTH];              // channel offset of each in-flight chunk (for the GroupNorm vectors)
     float4 rbuf_a[DEPTH][PA], rbuf_b[DEPTH][PB];
     float ln_s1[PA], ln_s2[PA];   // fused LayerNorm: running sum / sum of squares of this thread's A rows
 #pragma unroll
     for (int q = 0; q < PA; ++q) { ln_s1[q] = 0.f; ln_s2[q] = 0.f; }
     unsigned rmask[DEPTH];      // per stage: bit q set = A row q of that chunk is in-bounds (else zero padding)
 
-    auto prefetch = [&](int kc, float4 (&ra)[PA], float4 (&rb)[PB], unsigned& mask) {
+    auto prefetch = [&](int kc, float4 (&ra)[PA], float4 (&rb)[PB], unsigned& mask, int& cc0) {
         const int k0 = kc * BKT;
         if constexpr (!GENERIC) {
             const int c0 = pf_c0;
+            cc0 = c0;
             const int dy = pf_ty * p.dil_h, dx = pf_tx * p.dil_w;
             pf_c0 += BKT;
             if (pf_c0 >= p.Cin) {
@@ -198,6 +213,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(CGParams p) {
                 ra[q] = make_float4(tmp[0], tmp[1], tmp[2], tmp[3]);
             }
             mask = 0xffffffffu;
+            cc0 = 0;
 #pragma unroll
             for (int q = 0; q < PB; ++q) {
                 float tmp[4];
@@ -227,7 +243,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(CGParams p) {
     STAMP();
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d)
-        if (kc_begin + d < kc_end) prefetch(kc_begin + d, rbuf_a[d], rbuf_b[d], rmask[d]);
+        if (kc_begin + d < kc_end) prefetch(kc_begin + d, rbuf_a[d], rbuf_b[d], rmask[d], rc0[d]);
     STAMP();
     for (int kc0 = kc_begin; kc0 < kc_end; kc0 += DEPTH) {
 #pragma unroll
@@ -237,6 +253,18 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(CGParams p) {
 #pragma unroll
             for (int q = 0; q < PA; ++q) {
                 float4 v = rbuf_a[d][q];
+                if constexpr (!GENERIC) {
+                    if (p.gn_ab) {
+                        const float4 ga = *reinterpret_cast<const float4*>(gn_lds + rc0[d] + lcol);
+                        const float4 gd = *reinterpret_cast<const float4*>(gn_lds + p.Cin + rc0[d] + lcol);
+                        v.x = v.x * ga.x + gd.x; v.y = v.y * ga.y + gd.y;
+                        v.z = v.z * ga.z + gd.z; v.w = v.w * ga.w + gd.w;
+                        if (p.gn_act) {
+                            v.x = __fdividef(v.x, 1.0f + __expf(-v.x)); v.y = __fdividef(v.y, 1.0f + __expf(-v.y));
+                            v.z = __fdividef(v.z, 1.0f + __expf(-v.z)); v.w = __fdividef(v.w, 1.0f + __expf(-v.w));
+                        }
+                    }
+                }
                 if (!((rmask[d] >> q) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (p.ln_mode) {
                     ln_s1[q] += (v.x + v.y) + (v.z + v.w);
@@ -256,7 +284,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(CGParams p) {
                     wvalid[q] ? rbuf_b[d][q] : make_float4(0.f, 0.f, 0.f, 0.f);
             __syncthreads();
             STAMP();
-            if (kc + DEPTH < kc_end) prefetch(kc + DEPTH, rbuf_a[d], rbuf_b[d], rmask[d]);
+            if (kc + DEPTH < kc_end) prefetch(kc + DEPTH, rbuf_a[d], rbuf_b[d], rmask[d], rc0[d]);
 #pragma unroll
             for (int kb = 0; kb < BKT / 8; ++kb) {
                 float4 af[TM], bf[TN];
@@ -407,6 +435,7 @@ template <int UNROLL>
 __global__ __launch_bounds__(256) void conv_gemm_wsk_kernel(CGParams p) {
     __shared__ float part[4][16][64];
     __shared__ float ln_part[4][32][2];
+    __shared__ __attribute__((aligned(16))) float gn_lds[2 * GN_MAXC];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fi = lane & 31, fh = lane >> 5;
     const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
@@ -439,6 +468,11 @@ __global__ __launch_bounds__(256) void conv_gemm_wsk_kernel(CGParams p) {
     int c0 = k0 - tap * p.Cin;
     int ty = tap / p.KW, tx = tap - ty * p.KW;
 
+    if (p.gn_ab) {     // fused GroupNorm: one batch item per block (OH*OW % 32 == 0)
+        const float4* src = reinterpret_cast<const float4*>(p.gn_ab + (size_t)(m0 / p.rpb) * 2 * p.Cin);
+        for (int idx = tid; idx < p.Cin / 2; idx += 256) reinterpret_cast<float4*>(gn_lds)[idx] = src[idx];
+        __syncthreads();
+    }
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -447,6 +481,7 @@ __global__ __launch_bounds__(256) void conv_gemm_wsk_kernel(CGParams p) {
     for (int kb = kb_begin; kb < kb_end; kb += UNROLL) {
         float4 av[UNROLL], wv[UNROLL];
         bool aok[UNROLL];
+        int ac0[UNROLL];
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             const bool live = kb + u < kb_end;
@@ -457,6 +492,7 @@ __global__ __launch_bounds__(256) void conv_gemm_wsk_kernel(CGParams p) {
             av[u] = *reinterpret_cast<const float4*>(p.A + (ok ? off : 4u * fh));
             wv[u] = *reinterpret_cast<const float4*>(wrow + (live ? k0 : 0));
             aok[u] = ok;
+            ac0[u] = c0;
             if (!(live && nvalid)) wv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             k0 += 8;
             c0 += 8;
@@ -467,7 +503,17 @@ __global__ __launch_bounds__(256) void conv_gemm_wsk_kernel(CGParams p) {
         }
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
-            float4 a = aok[u] ? av[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 a = av[u];
+            if (p.gn_ab) {
+                const float4 ga = *reinterpret_cast<const float4*>(gn_lds + ac0[u] + 4 * fh);
+                const float4 gd = *reinterpret_cast<const float4*>(gn_lds + p.Cin + ac0[u] + 4 * fh);
+                a.x = a.x * ga.x + gd.x; a.y = a.y * ga.y + gd.y; a.z = a.z * ga.z + gd.z; a.w = a.w * ga.w + gd.w;
+                if (p.gn_act) {
+                    a.x = __fdividef(a.x, 1.0f + __expf(-a.x)); a.y = __fdividef(a.y, 1.0f + __expf(-a.y));
+                    a.z = __fdividef(a.z, 1.0f + __expf(-a.z)); a.w = __fdividef(a.w, 1.0f + __expf(-a.w));
+                }
+            }
+            if (!aok[u]) a = make_float4(0.f, 0.f, 0.f, 0.f);
             if (p.ln_mode) {
                 ln_s1 += (a.x + a.y) + (a.z + a.w);
                 ln_s2 += (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
@@ -537,7 +583,9 @@ static int fill_params(const aed_op* op, CGParams& p, int bkt) {
     p.res = (const float*)op->p[4];
     p.rowvec = (const float*)op->p[5];
     p.ws = (float*)op->p[6];
-    p.dbg = (long long*)op->p[7];
+    p.dbg = (op->flags & 1) ? (long long*)op->p[7] : nullptr;
+    p.gn_ab = (op->flags & 2) ? (const float*)op->p[7] : nullptr;
+    p.gn_act = (op->flags >> 2) & 1;
     const int32_t* i = op->i;
     p.M = i[0]; p.N = i[1]; p.K = i[2]; p.lda = i[3]; p.ldc = i[4]; p.ldr = i[5]; p.ld_rv = i[6];
     p.IH = i[7]; p.IW = i[8]; p.OH = i[9]; p.OW = i[10]; p.Cin = i[11]; p.KH = i[12]; p.KW = i[13];
@@ -559,6 +607,7 @@ static int fill_params(const aed_op* op, CGParams& p, int bkt) {
     if (p.ksplit < 1) p.ksplit = 1;
     if (p.ksplit > p.nchunks) p.ksplit = p.nchunks;
     if (p.ksplit > 1) AED_REQUIRE(p.ws != nullptr, "conv_gemm: split-K needs a workspace");
+    if (p.gn_ab) AED_REQUIRE(p.Cin <= GN_MAXC && p.Cin % 4 == 0 && p.in_act == 0, "conv_gemm: fused GroupNorm Cin=%d", p.Cin);
     if (p.ln_mode)
         AED_REQUIRE(p.ksplit == 1 && p.KH * p.KW == 1 && p.rowvec && p.bias && p.in_act == 0,
                     "conv_gemm: fused LayerNorm needs a 1-tap, unsplit GEMM with folded weights");

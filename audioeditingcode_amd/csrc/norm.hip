@@ -126,6 +126,58 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     }
 }
 
+// GroupNorm statistics folded into per-channel (scale, shift) vectors for the FUSED path: the consumer
+// conv applies x' = act(x*a + d) inside its A-loader (conv_gemm.hip), so the normalised activation never
+// exists in HBM and GroupNorm costs one small launch instead of two + a round trip.
+//   a[b][c] = rstd[b,g(c)] * gamma[c]        d[b][c] = beta[c] - mean[b,g(c)] * a[b][c]
+// grid (G, B): one block per (group, batch item); used for the U-Net's small feature maps.
+__global__ __launch_bounds__(256) void gn_scale_shift_kernel(const float* __restrict__ x,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float* __restrict__ ab,
+                                                              int HW, int C, int G, int ldx, float eps) {
+    __shared__ double rs[4], rss[4];
+    const int tid = threadIdx.x, g = blockIdx.x, b = blockIdx.y;
+    const int cpg = C / G, cpg4 = cpg >> 2;
+    const float* xb = x + (size_t)b * HW * ldx + g * cpg;
+    const int total = HW * cpg4;
+    float s = 0.f, ss = 0.f;
+    for (int e = tid; e < total; e += 256) {
+        const int row = e / cpg4, j = e - row * cpg4;
+        const float4 v = *reinterpret_cast<const float4*>(xb + (size_t)row * ldx + 4 * j);
+        s += (v.x + v.y) + (v.z + v.w);
+        ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+    double ds = (double)s, dss = (double)ss;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { ds += __shfl_xor(ds, o, 64); dss += __shfl_xor(dss, o, 64); }
+    if ((tid & 63) == 0) { rs[tid >> 6] = ds; rss[tid >> 6] = dss; }
+    __syncthreads();
+    ds = (rs[0] + rs[1]) + (rs[2] + rs[3]);
+    dss = (rss[0] + rss[1]) + (rss[2] + rss[3]);
+    const double n = (double)HW * (double)cpg;
+    const double mean = ds / n;
+    double var = dss / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (tid < cpg) {
+        const int c = g * cpg + tid;
+        const float a = rstd * gamma[c];
+        ab[(size_t)b * 2 * C + c] = a;
+        ab[(size_t)b * 2 * C + C + c] = beta[c] - (float)mean * a;
+    }
+}
+// slots: p0=x p1=gamma p2=beta p3=ab[B][2][C] ; i0=B i1=HW i2=C i3=G i4=ldx ; f0=eps
+int launch_gn_scale_shift(const aed_op* op, hipStream_t s) {
+    const int32_t* i = op->i;
+    AED_REQUIRE(op->p[0] && op->p[1] && op->p[2] && op->p[3], "gn_scale_shift: null pointer");
+    AED_REQUIRE(i[2] % (4 * i[3]) == 0 && i[2] / i[3] <= 256 && i[4] % 4 == 0, "gn_scale_shift: C=%d G=%d", i[2], i[3]);
+    hipLaunchKernelGGL(gn_scale_shift_kernel, dim3(i[3], i[0]), dim3(256), 0, s, (const float*)op->p[0],
+                       (const float*)op->p[1], (const float*)op->p[2], (float*)op->p[3], i[1], i[2], i[3], i[4],
+                       op->f[0]);
+    AED_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 // slots: p0=x p1=partials ; i0=B i1=HW i2=C i3=G i4=ldx i5=rows_per_chunk i6=nchunks
 int launch_gn_stats(const aed_op* op, hipStream_t s) {
     const int32_t* i = op->i;

@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--tstart", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batched", action="store_true", help="skip the extra timestep-batched-inversion timing")
+    ap.add_argument("--group", type=int, default=20, help="timesteps per U-Net call in the batched inversion")
     ap.add_argument("--profile-forward", action="store_true", help="only run U-Net forwards (for rocprofv3)")
     args = ap.parse_args()
 
@@ -117,7 +118,7 @@ def main():
         mel, _, _ = fn.mel_spectrogram(wave)                              # [1, 64, 1025]
         x0 = mel[0].T[:1024][None, None].contiguous()                    # [1,1,1024,64]
         return edit_clip(m, x0, src, tgt, neg, [3.0], [12.0], args.T, args.tstart, schedule=schedule,
-                         timestep_group=8)
+                         timestep_group=args.group)
 
     if args.profile_forward:
         ed = m.editor(256, 16)

@@ -144,3 +144,39 @@ def test_ddim_baseline_matches_oracle():
     torch.cuda.synchronize()
     assert rel(eng.to_nchw(wT).cpu(), wT_o) < 1e-4
     assert rel(eng.to_nchw(we).cpu(), we_o) < 1e-3
+
+
+def test_full_size_audioldm2_loop_both_schedules_vs_oracle():
+    """BASELINE config 2 shapes (AudioLDM2 U-Net, latent 8x256x16) at T=8/tstart=4: the reference step order
+    and the timestep-batched inversion land at the same distance from the CPU oracle (reference order)."""
+    T, tstart = 8, 4
+    fam = configs.FAMILIES["audioldm2"]
+    cfg = fam["unet"]
+    sd = weights.random_state_dict(weights.unet_param_shapes(cfg), seed=0)
+    g = torch.Generator().manual_seed(11)
+    mk = lambda L1: dict(encoder_hidden_states=torch.randn(1, 8, 768, generator=g),          # noqa: E731
+                         encoder_hidden_states_1=torch.randn(1, L1, 1024, generator=g),
+                         encoder_attention_mask_1=torch.ones(1, L1))
+    src, tgt, unc = mk(7), mk(9), mk(1)
+    to_c = lambda d: Conditioning(ehs0=d["encoder_hidden_states"], ehs1=d["encoder_hidden_states_1"],  # noqa: E731
+                                  mask1=d["encoder_attention_mask_1"])
+    sched = DDIMScheduler()
+    sched.set_timesteps(T)
+    osched = OracleDDIMScheduler()
+    osched.set_timesteps(T)
+    ow = oloops.OracleWrapper(osched, lambda x, t, c: ounet.unet_forward(
+        cfg, sd, x, t, **{k: v.expand(x.shape[0], *v.shape[1:]) for k, v in c.items()})[0])
+    x0 = torch.randn(1, 8, 256, 16, generator=g) * 0.8
+    xts0 = ow.sample_xts_from_x0(x0, T, generator=torch.Generator().manual_seed(1))
+    _, zs_o, xts_o = oloops.invert(ow, x0, src, unc, [3.0], T, eta=1.0, xts=xts0.clone())
+    w_o = oloops.edit(ow, xts_o, torch.tensor([tstart]), tgt, unc, [12.0], zs_o[:tstart], eta=1.0)
+    eng = EditEngine(cfg, sd, sched, DEV, 256, 16, "audioldm2")
+    errs = {}
+    for mode in ("sequential", "batched"):
+        zs, xts = eng.invert(x0, to_c(src), to_c(unc), [3.0], xts=xts0.unsqueeze(1), mode=mode, group=4)
+        w = eng.edit(xts, zs, tstart, to_c(tgt), to_c(unc), [12.0], eta=1.0)
+        torch.cuda.synchronize()
+        errs[mode] = (rel(eng.to_nchw(zs)[1:, 0].cpu(), zs_o[1:]), rel(eng.to_nchw(w).cpu(), w_o))
+    for mode, (ez, ew) in errs.items():
+        assert ez < 2e-3 and ew < 2e-3, (mode, ez, ew)
+    assert errs["batched"][1] < 3 * errs["sequential"][1] + 1e-5, errs

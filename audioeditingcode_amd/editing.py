@@ -82,6 +82,7 @@ class EditEngine:
         self._unets = {}
         self.state = torch.zeros(4, dtype=torch.int32, device=self.device)
         self.ts_dev = torch.zeros(scheduler.config.num_train_timesteps, dtype=torch.int64, device=self.device)
+        self._plans = {}        # loop plans: persistent buffers + tapes + captured graph, keyed by loop shape
 
     # ------------------------------------------------------------------ helpers
     def unet(self, B, L0=0, L1=0):
@@ -111,12 +112,12 @@ class EditEngine:
             return groups[0].ehs0.shape[1], max(g.ehs1.shape[1] for g in groups)
         return max(g.ehs0.shape[1] for g in groups), 0
 
-    def to_nhwc(self, x):
+    def to_nhwc(self, x, out=None):
         """[..., C, H, W] -> contiguous [..., H, W, C] on the device (native transpose kernel)."""
         lead = x.shape[:-3]
         C, H, W = x.shape[-3:]
         src = x.to(self.device, torch.float32).contiguous()
-        dst = torch.empty(*lead, H, W, C, device=self.device, dtype=torch.float32)
+        dst = out if out is not None else torch.empty(*lead, H, W, C, device=self.device, dtype=torch.float32)
         tp = Tape(self.device)
         tp.transpose(src, dst, Bt=max(1, math.prod(lead)), R=C, C=H * W)
         tp.run()
@@ -132,22 +133,28 @@ class EditEngine:
         tp.run()
         return dst
 
-    def _run_graph(self, body, steps, use_graph=True):
-        """Run `body()` `steps` times on the engine stream; captured once and replayed."""
+    def _run_graph(self, body, steps, use_graph=True, plan=None):
+        """Run `body()` `steps` times on the engine stream.  The step sequence is captured into a hipGraph
+        once per plan (same buffers => same graph for every later clip) and replayed."""
         cur = torch.cuda.current_stream(self.device)
         self.stream.wait_stream(cur)
         with torch.cuda.stream(self.stream):
             ev0 = torch.cuda.Event(enable_timing=True)
             ev1 = torch.cuda.Event(enable_timing=True)
             if use_graph and steps > 1:
-                g = Tape.graph_capture(body)
+                g = plan.get("graph") if plan is not None else None
+                if g is None:
+                    g = Tape.graph_capture(body)
+                    if plan is not None:
+                        plan["graph"] = g
                 ev0.record(self.stream)
                 for _ in range(steps):
                     Tape.graph_replay(g)
                 ev1.record(self.stream)
                 self._last_events = (ev0, ev1)
-                self.stream.synchronize()
-                L.check(L.lib().aed_graph_destroy(g), "aed_graph_destroy")
+                if plan is None:
+                    self.stream.synchronize()
+                    L.check(L.lib().aed_graph_destroy(g), "aed_graph_destroy")
             else:
                 ev0.record(self.stream)
                 for _ in range(steps):
@@ -199,58 +206,71 @@ class EditEngine:
         numel = n * self.C * self.H * self.W
         if xts is None:
             xts = self.sample_xts(x0, noise, generator)
-        xts = self.to_nhwc(xts)                                   # [T+1, n, H, W, C]
-        zs = torch.zeros((T, n, self.H, self.W, self.C), device=self.device, dtype=torch.float32)
         P = 0 if cond_src is None else cond_src.rows // n
         groups = [cond_uncond.repeat(n)] + ([cond_src] if P else [])
-        coef = coefficient_table(s, s.timesteps.cpu(), eta=eta, kind="ddpm").to(self.device)
-        self.ts_dev[:T] = s.timesteps.to(self.device)
         v_pred = int(s.config.prediction_type == "v_prediction")
-        cfgt = None if cfg_tensor is None else self.to_nhwc(cfg_tensor.reshape(P, n, self.C, self.H, self.W)).contiguous()
-        scalar = float(cfg_src[0]) if (cfg_tensor is None and P) else 1.0
-
         G = 1 if mode == "sequential" else max(1, min(group, T))
         while T % G:
             G -= 1
         rows_per_t = n * (1 + P)
         L0, L1 = self._ctx_lens(groups)
-        eng = self.unet(G * rows_per_t, L0, L1)
+        scalar = float(cfg_src[0]) if (cfg_tensor is None and P) else 1.0
+        key = ("invert", n, P, T, G, L0, L1, bool(numerical_fix), v_pred, cfg_tensor is not None, scalar)
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = self._plans[key] = dict(
+                xts=torch.empty((T + 1, n, self.H, self.W, self.C), device=self.device, dtype=torch.float32),
+                zs=torch.zeros((T, n, self.H, self.W, self.C), device=self.device, dtype=torch.float32),
+                coef=torch.zeros((T, L.COEF_STRIDE), device=self.device, dtype=torch.float32),
+                cfgt=(torch.empty((max(P, 1), n, self.H, self.W, self.C), device=self.device, dtype=torch.float32)
+                      if cfg_tensor is not None else None))
+            eng = plan["eng"] = self.unet(G * rows_per_t, L0, L1)
+            pre, post = Tape(self.device), Tape(self.device)
+            for g in range(G):
+                for blk in range(1 + P):
+                    dst = eng.x_in[(g * (1 + P) + blk) * n:(g * (1 + P) + blk + 1) * n]
+                    pre.copy2d(plan["xts"], dst, rows=1, cols=numel, ld_src=numel, ld_dst=numel, state=self.state,
+                               idx_off=T - g, idx_mul=-G, idx_stride=numel, name="x_in<-xts")
+            for g in range(G):
+                base = g * rows_per_t
+                eps_u = eng.eps[base:base + n]
+                eps_c = eng.eps[base + n:base + rows_per_t] if P else None
+                post.step(L.OP_INVERT_STEP, xts=plan["xts"], zs=plan["zs"], eps_u=eps_u, eps_c=eps_c,
+                          cfg=plan["cfgt"], coef=plan["coef"], state=self.state, out=None, numel=numel, P=max(P, 1),
+                          T=T, v_pred=v_pred, flag=int(numerical_fix), cfg_scalar=scalar, s_mul=G, s_off=g)
+            post.advance(self.state)
+            pre.finalize()
+            post.finalize()
+            plan["pre"], plan["post"] = pre, post
+        eng, pre, post = plan["eng"], plan["pre"], plan["post"]
+        xts = self.to_nhwc(xts, out=plan["xts"])                  # [T+1, n, H, W, C]
+        zs = plan["zs"]
+        plan["coef"].copy_(coefficient_table(s, s.timesteps.cpu(), eta=eta, kind="ddpm"))
+        self.ts_dev[:T] = s.timesteps.to(self.device)
+        if cfg_tensor is not None:
+            self.to_nhwc(cfg_tensor.reshape(P, n, self.C, self.H, self.W), out=plan["cfgt"])
         # batch rows: for g in G: [uncond x n | prompt_p x n ...]
         self._set_cond(eng, [c for _ in range(G) for c in groups])
-        pre, post = Tape(self.device), Tape(self.device)
-        for g in range(G):
-            for blk in range(1 + P):
-                dst = eng.x_in[(g * (1 + P) + blk) * n:(g * (1 + P) + blk + 1) * n]
-                pre.copy2d(xts, dst, rows=1, cols=numel, ld_src=numel, ld_dst=numel, state=self.state,
-                           idx_off=T - g, idx_mul=-G, idx_stride=numel, name="x_in<-xts")
         self._patch_time(eng, self.ts_dev, G, rows_per_t)
-        for g in range(G):
-            base = g * rows_per_t
-            eps_u = eng.eps[base:base + n]
-            eps_c = eng.eps[base + n:base + rows_per_t] if P else None
-            post.step(L.OP_INVERT_STEP, xts=xts, zs=zs, eps_u=eps_u, eps_c=eps_c, cfg=cfgt, coef=coef,
-                      state=self.state, out=None, numel=numel, P=max(P, 1), T=T, v_pred=v_pred,
-                      flag=int(numerical_fix), cfg_scalar=scalar, s_mul=G, s_off=g)
-        post.advance(self.state)
         self.state.zero_()
-
-        pre.finalize()
-        post.finalize()
 
         def body():
             pre.run()
             eng.tape.run()
             post.run()
-        self._run_graph(body, T // G, use_graph)
+        self._run_graph(body, T // G, use_graph, plan)
         zs[0].zero_()                                              # inversion_utils.py:131-133
-        return zs, xts
+        return zs, xts          # persistent buffers of this plan: valid until the next invert() of the same shape
 
     def _patch_time(self, eng, ts_dev, G, rows_per_t, offset=0):
         """Point the U-Net's time-embedding op at (table + offset) with G timesteps per call."""
         op = eng.tape.ops[eng.time_op]
         arr = eng.tape.finalize()
-        ridx = torch.arange(eng.B, dtype=torch.int32) // max(1, rows_per_t)
-        eng._row_tidx = ridx.to(self.device)
+        # cached: captured graphs keep pointing at these index tables
+        cache = eng.__dict__.setdefault("_row_tidx_cache", {})
+        if rows_per_t not in cache:
+            cache[rows_per_t] = (torch.arange(eng.B, dtype=torch.int32) // max(1, rows_per_t)).to(self.device)
+        eng._row_tidx = cache[rows_per_t]
         for o in (op, arr[eng.time_op]):
             o.p[1] = ts_dev.data_ptr() + 8 * offset
             o.p[2] = self.state.data_ptr()
@@ -270,35 +290,49 @@ class EditEngine:
         P = cond_tgt.rows // n
         groups = [cond_neg.repeat(n), cond_tgt]
         ts = s.timesteps.cpu()[T - Z:]
-        coef = coefficient_table(s, ts, eta=eta, kind=table_kind).to(self.device)
-        self.ts_dev[:T] = s.timesteps.to(self.device)
         v_pred = int(s.config.prediction_type == "v_prediction")
-        cfgt = None if cfg_tensor is None else self.to_nhwc(cfg_tensor.reshape(P, n, self.C, self.H, self.W)).contiguous()
         scalar = float(cfg_tar[0]) if cfg_tensor is None else 1.0
         L0, L1 = self._ctx_lens(groups)
-        eng = self.unet(n * (1 + P), L0, L1)
+        has_noise = int(eta > 0 and zs is not None)
+        key = ("edit", n, P, T, Z, L0, L1, v_pred, cfg_tensor is not None, scalar, has_noise, table_kind)
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = self._plans[key] = dict(
+                cur=torch.empty((n, self.H, self.W, self.C), device=self.device, dtype=torch.float32),
+                zs=torch.zeros((Z, n, self.H, self.W, self.C), device=self.device, dtype=torch.float32),
+                coef=torch.zeros((Z, L.COEF_STRIDE), device=self.device, dtype=torch.float32),
+                cfgt=(torch.empty((P, n, self.H, self.W, self.C), device=self.device, dtype=torch.float32)
+                      if cfg_tensor is not None else None))
+            eng = plan["eng"] = self.unet(n * (1 + P), L0, L1)
+            pre, post = Tape(self.device), Tape(self.device)
+            for blk in range(1 + P):
+                pre.copy2d(plan["cur"], eng.x_in[blk * n:(blk + 1) * n], rows=1, cols=numel, ld_src=numel,
+                           ld_dst=numel, name="x_in<-x_t")
+            post.step(L.OP_REVERSE_STEP, xts=plan["cur"], zs=plan["zs"] if has_noise else None, eps_u=eng.eps[:n],
+                      eps_c=eng.eps[n:], cfg=plan["cfgt"], coef=plan["coef"], state=self.state, out=plan["cur"],
+                      numel=numel, P=P, T=Z if has_noise else 0, v_pred=v_pred, flag=has_noise, cfg_scalar=scalar)
+            post.advance(self.state)
+            pre.finalize()
+            post.finalize()
+            plan["pre"], plan["post"] = pre, post
+        eng, pre, post, cur = plan["eng"], plan["pre"], plan["post"], plan["cur"]
+        cur.copy_(xts[Z])                                          # inversion_utils.py:203
+        if has_noise:
+            plan["zs"].copy_(zs[:Z])
+        plan["coef"].copy_(coefficient_table(s, ts, eta=eta, kind=table_kind))
+        self.ts_dev[:T] = s.timesteps.to(self.device)
+        if cfg_tensor is not None:
+            self.to_nhwc(cfg_tensor.reshape(P, n, self.C, self.H, self.W), out=plan["cfgt"])
         self._set_cond(eng, groups)
-        cur = xts[Z].clone()                                       # inversion_utils.py:203
-        zs_used = zs[:Z].contiguous() if zs is not None else None
-        pre, post = Tape(self.device), Tape(self.device)
-        for blk in range(1 + P):
-            pre.copy2d(cur, eng.x_in[blk * n:(blk + 1) * n], rows=1, cols=numel, ld_src=numel, ld_dst=numel,
-                       name="x_in<-x_t")
         self._patch_time(eng, self.ts_dev, 1, n * (1 + P), offset=T - Z)
-        post.step(L.OP_REVERSE_STEP, xts=cur, zs=zs_used, eps_u=eng.eps[:n], eps_c=eng.eps[n:], cfg=cfgt, coef=coef,
-                  state=self.state, out=cur, numel=numel, P=P, T=Z, v_pred=v_pred,
-                  flag=int(eta > 0 and zs_used is not None), cfg_scalar=scalar)
-        post.advance(self.state)
         self.state.zero_()
-
-        pre.finalize()
-        post.finalize()
 
         def body():
             pre.run()
             eng.tape.run()
             post.run()
-        self._run_graph(body, Z, use_graph)
+        self._run_graph(body, Z, use_graph, plan)
+        return cur.clone()
         return cur
 
     # ------------------------------------------------------------------ A16: DDIM baseline

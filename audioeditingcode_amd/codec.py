@@ -84,6 +84,7 @@ class STFTEngine:
                   out_act=L.ACT_LOGCLAMP, out_p=1e-5, name="stft.mel")
         tp.finalize()
 
+    @torch.inference_mode()
     def __call__(self, wav):
         """wav: [B, N] float tensor in [-1, 1] (asserted like stft.py:169-170)."""
         assert float(wav.min()) >= -1 and float(wav.max()) <= 1, "waveform outside [-1, 1]"
@@ -203,6 +204,7 @@ class VAEEncoder(_ConvNet):
         self.h, self.w = hh, ww
         tp.finalize()
 
+    @torch.inference_mode()
     def __call__(self, mel):
         self.x_in.copy_(mel.to(self.device, torch.float32).reshape(self.x_in.shape))
         self.tape.run()
@@ -243,6 +245,7 @@ class VAEDecoder(_ConvNet):
         self.mel = self.conv3("decoder.conv_out", a, B, hh, ww, ch, cfg.get("out_channels", 1))
         tp.finalize()
 
+    @torch.inference_mode()
     def __call__(self, z_nhwc):
         self.z_in.copy_(z_nhwc.reshape(self.z_in.shape))
         self.tape.run()
@@ -320,6 +323,7 @@ class VocoderEngine:
         self.L_out = Lc
         tp.finalize()
 
+    @torch.inference_mode()
     def __call__(self, mel):
         self.mel_in.copy_(mel.to(self.device, torch.float32).reshape(self.mel_in.shape))
         self.tape.run()

@@ -640,7 +640,7 @@ int launch_conv_gemm(const aed_op* op, hipStream_t s) {
         auto blocks = [&](int bm, int bn) { return (long)aed_cdiv(M, bm) * aed_cdiv(N, bn) * ks; };
         if (N <= 32) cfg = 5;
         else if (M <= 32) cfg = 6;
-        else if (blocks(128, 128) >= 2L * cus && N >= 128) cfg = 1;
+        else if (blocks(128, 128) >= (long)cus && N >= 128) cfg = 1;
         else if (blocks(128, 64) >= 2L * cus && N >= 64) cfg = 2;
         else cfg = 4;
         if (N < 64 && cfg != 5) cfg = 5;

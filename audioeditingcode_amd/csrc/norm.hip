@@ -166,6 +166,69 @@ __global__ __launch_bounds__(256) void gn_scale_shift_kernel(const float* __rest
         ab[(size_t)b * 2 * C + C + c] = beta[c] - (float)mean * a;
     }
 }
+// Single-launch GroupNorm(+SiLU) for the U-Net's small feature maps: one block per (group, batch item)
+// computes the statistics of its slice and normalises it in the same launch (the slice -- at most a few
+// hundred KB -- is re-read from L1/L2).  At U-Net batch 2 a GroupNorm is latency-bound, so one launch
+// instead of two is what matters; large maps (VAE) keep the two-pass streaming kernels above.
+__global__ __launch_bounds__(256) void gn_small_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ y, int HW,
+                                                        int C, int G, int ldx, int ldy, float eps, int act) {
+    __shared__ double rs[4], rss[4];
+    const int tid = threadIdx.x, g = blockIdx.x, b = blockIdx.y;
+    const int cpg = C / G, cpg4 = cpg >> 2;
+    const float* xb = x + (size_t)b * HW * ldx + g * cpg;
+    float* yb = y + (size_t)b * HW * ldy + g * cpg;
+    const int total = HW * cpg4;
+    float s = 0.f, ss = 0.f;
+    for (int e = tid; e < total; e += 256) {
+        const int row = e / cpg4, j = e - row * cpg4;
+        const float4 v = *reinterpret_cast<const float4*>(xb + (size_t)row * ldx + 4 * j);
+        s += (v.x + v.y) + (v.z + v.w);
+        ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+    double ds = (double)s, dss = (double)ss;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { ds += __shfl_xor(ds, o, 64); dss += __shfl_xor(dss, o, 64); }
+    if ((tid & 63) == 0) { rs[tid >> 6] = ds; rss[tid >> 6] = dss; }
+    __syncthreads();
+    ds = (rs[0] + rs[1]) + (rs[2] + rs[3]);
+    dss = (rss[0] + rss[1]) + (rss[2] + rss[3]);
+    const double n = (double)HW * (double)cpg;
+    const double dmean = ds / n;
+    double var = dss / n - dmean * dmean;
+    if (var < 0.0) var = 0.0;
+    const float mean = (float)dmean;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    for (int e = tid; e < total; e += 256) {
+        const int row = e / cpg4, j = e - row * cpg4;
+        float4 v = *reinterpret_cast<const float4*>(xb + (size_t)row * ldx + 4 * j);
+        const float4 ga = *reinterpret_cast<const float4*>(gamma + g * cpg + 4 * j);
+        const float4 be = *reinterpret_cast<const float4*>(beta + g * cpg + 4 * j);
+        v.x = (v.x - mean) * rstd * ga.x + be.x;
+        v.y = (v.y - mean) * rstd * ga.y + be.y;
+        v.z = (v.z - mean) * rstd * ga.z + be.z;
+        v.w = (v.w - mean) * rstd * ga.w + be.w;
+        if (act == AED_ACT_SILU) {
+            v.x = v.x / (1.0f + expf(-v.x));
+            v.y = v.y / (1.0f + expf(-v.y));
+            v.z = v.z / (1.0f + expf(-v.z));
+            v.w = v.w / (1.0f + expf(-v.w));
+        }
+        *reinterpret_cast<float4*>(yb + (size_t)row * ldy + 4 * j) = v;
+    }
+}
+// slots: p0=x p1=gamma p2=beta p3=y ; i0=B i1=HW i2=C i3=G i4=ldx i5=ldy i6=act ; f0=eps
+int launch_gn_small(const aed_op* op, hipStream_t s) {
+    const int32_t* i = op->i;
+    AED_REQUIRE(op->p[0] && op->p[1] && op->p[2] && op->p[3], "gn_small: null pointer");
+    AED_REQUIRE(i[2] % (4 * i[3]) == 0 && i[4] % 4 == 0 && i[5] % 4 == 0, "gn_small: C=%d G=%d", i[2], i[3]);
+    hipLaunchKernelGGL(gn_small_kernel, dim3(i[3], i[0]), dim3(256), 0, s, (const float*)op->p[0],
+                       (const float*)op->p[1], (const float*)op->p[2], (float*)op->p[3], i[1], i[2], i[3], i[4], i[5],
+                       op->f[0], i[6]);
+    AED_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 // slots: p0=x p1=gamma p2=beta p3=ab[B][2][C] ; i0=B i1=HW i2=C i3=G i4=ldx ; f0=eps
 int launch_gn_scale_shift(const aed_op* op, hipStream_t s) {
     const int32_t* i = op->i;

@@ -112,6 +112,7 @@ class EditEngine:
             return groups[0].ehs0.shape[1], max(g.ehs1.shape[1] for g in groups)
         return max(g.ehs0.shape[1] for g in groups), 0
 
+    @torch.inference_mode()
     def to_nhwc(self, x, out=None):
         """[..., C, H, W] -> contiguous [..., H, W, C] on the device (native transpose kernel)."""
         lead = x.shape[:-3]
@@ -123,6 +124,7 @@ class EditEngine:
         tp.run()
         return dst
 
+    @torch.inference_mode()
     def to_nchw(self, x):
         lead = x.shape[:-3]
         H, W, C = x.shape[-3:]
@@ -169,6 +171,7 @@ class EditEngine:
         return ev0.elapsed_time(ev1)
 
     # ------------------------------------------------------------------ A6: sample_xts_from_x0
+    @torch.inference_mode()
     def sample_xts(self, x0, noise=None, generator=None):
         """models.py:67-83.  x0 [n,C,H,W]; noise [T,n,C,H,W] (drawn here on the CPU generator in the
         reference's order -- ascending t, one randn per step -- when not given).  Returns NCHW xts
@@ -193,6 +196,7 @@ class EditEngine:
         return xts
 
     # ------------------------------------------------------------------ A7: forward inversion
+    @torch.inference_mode()
     def invert(self, x0, cond_src, cond_uncond, cfg_src, eta=1.0, numerical_fix=True, noise=None, generator=None,
                xts=None, cfg_tensor=None, mode="sequential", group=8, use_graph=True):
         """inversion_forward_process (inversion_utils.py:8-144) for n clips.
@@ -278,6 +282,7 @@ class EditEngine:
             o.i[5] = G
 
     # ------------------------------------------------------------------ A11: reverse / edit
+    @torch.inference_mode()
     def edit(self, xts, zs, tstart, cond_tgt, cond_neg, cfg_tar, eta=1.0, cfg_tensor=None, use_graph=True,
              table_kind="ddpm"):
         """inversion_reverse_process (inversion_utils.py:147-323) from x_{tstart}, noise maps zs[:tstart].
@@ -336,6 +341,7 @@ class EditEngine:
         return cur
 
     # ------------------------------------------------------------------ A16: DDIM baseline
+    @torch.inference_mode()
     def ddim_invert(self, w0, cond_src, cond_uncond, cfg_scale, skip=0, use_graph=True):
         """ddim_inversion (ddim_inversion.py:44-56): deterministic, ascending t.  w0 [n,C,H,W] -> [n,H,W,C]."""
         s = self.sched
@@ -370,6 +376,7 @@ class EditEngine:
         self._run_graph(body, steps, use_graph)
         return cur
 
+    @torch.inference_mode()
     def ddim_sample(self, xt, cond_tgt, cond_uncond, guidance_scale, skip=0, use_graph=True):
         """text2image_ldm_stable (ddim_inversion.py:59-84): scheduler.step(eta=0) from timesteps[skip:]."""
         s = self.sched

@@ -82,7 +82,7 @@ class Tape:
             cfg, bm, bn = 5, 128, 32
         elif M <= 32:
             cfg, bm, bn = 6, 32, 128
-        elif N >= 128 and blocks(128, 128) >= 2 * cus:
+        elif N >= 128 and blocks(128, 128) >= cus:
             cfg, bm, bn = 1, 128, 128
         elif N >= 64 and blocks(128, 64) >= 2 * cus:
             cfg, bm, bn = 2, 128, 64
@@ -159,6 +159,11 @@ class Tape:
     def groupnorm(self, x, gamma, beta, out, *, B, HW, C, G=32, eps=1e-5, act=0, name="gn"):
         ldx = x.stride(-2)
         ldy = out.stride(-2)
+        if HW * (C // G) <= 65536 and B * G >= 32 and B * HW * C <= (1 << 22):
+            # small map: one launch, one block per (group, batch item) -- latency, not bandwidth, is the cost
+            self._add(L.OP_GN_SMALL, [B, HW, C, G, ldx, ldy, act], [eps], [x, gamma, beta, out], name=name + ".gn1",
+                      nbytes=12 * B * HW * C)
+            return out
         # stats: <=32 coarse slabs per batch item (few partials to re-reduce);
         # apply: fine slabs for parallelism (~2 blocks per CU)
         s_rpc = max(4, math.ceil(HW / 32))

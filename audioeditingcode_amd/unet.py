@@ -399,6 +399,7 @@ class UNetEngine:
         self.ctx_tape.finalize()
 
     # ------------------------------------------------------------------ use
+    @torch.inference_mode()
     def set_conditioning(self, ehs0=None, ehs1=None, bias0=None, bias1=None, class_labels=None):
         """Copy conditioning (already laid out [B, L, dim]) into the engine and run the per-prompt
         precompute tape (cross-attention K/V projections, class embedding) -- once per prompt set."""
@@ -414,6 +415,7 @@ class UNetEngine:
         arr = self.tape.finalize()
         arr[self.time_op].i[4] = int(t)
 
+    @torch.inference_mode()
     def forward(self, first_half_only=False, second_half_only=False):
         if second_half_only:
             self.tape.run(self.mid_index, None)

@@ -39,6 +39,7 @@ struct CGParams {
     int IH, IW, OH, OW, Cin;
     int KH, KW, stride, pad_h, pad_w, dil_h, dil_w, up;
     int a_bs;
+    int vIH, vIW;            // virtual (nearest-upsampled) input grid actually convolved: <= IH<<up, IW<<up
     int o_mul, o_add, o_len, out_bs;
     int in_act, out_act, accumulate, ksplit;
     int rpb;                 // output rows per batch item = OH*OW
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(CGParams p) {
         wvalid[q] = n < p.N;
         wbase[q] = (unsigned)(wvalid[q] ? n : 0) * (unsigned)p.K + lcol;
     }
-    const int vIH = p.IH << p.up, vIW = p.IW << p.up;
+    const int vIH = p.vIH, vIW = p.vIW;
 
     // running (tap, channel) position of the NEXT chunk to prefetch (prefetch() is always called with
     // consecutive kc): no per-chunk integer divisions
@@ -457,7 +458,7 @@ __global__ __launch_bounds__(256) void conv_gemm_wsk_kernel(CGParams p) {
     const int oy = rr / p.OW, ox = rr - oy * p.OW;
     const int ay0 = oy * p.stride - p.pad_h, ax0 = ox * p.stride - p.pad_w;
     const unsigned abase = (unsigned)bidx * (unsigned)p.a_bs + 4 * fh;
-    const int vIH = p.IH << p.up, vIW = p.IW << p.up;
+    const int vIH = p.vIH, vIW = p.vIW;
     const int n = n0 + fi;
     const bool nvalid = n < p.N;
     const float* wrow = p.W + (size_t)(nvalid ? n : 0) * p.K + 4 * fh;
@@ -596,6 +597,18 @@ static int fill_params(const aed_op* op, CGParams& p, int bkt) {
     p.ln_mode = i[31]; p.ln_eps = op->f[3];
     p.rpb = p.OH * p.OW;
     p.nchunks = (p.K + bkt - 1) / bkt;
+    p.vIH = p.IH << p.up;
+    p.vIW = p.IW << p.up;
+    if (p.up) {
+        // nearest resize to an explicit target (diffusers' forward_upsample_size, models.py:186-188): the target is
+        // the next skip's size, 2*IH or 2*IH-1; floor(dst*IH/target) == dst>>1 for both, so only the grid bound changes
+        const int th = (p.OH - 1) * p.stride - 2 * p.pad_h + p.dil_h * (p.KH - 1) + 1;
+        const int tw = (p.OW - 1) * p.stride - 2 * p.pad_w + p.dil_w * (p.KW - 1) + 1;
+        if (th < p.vIH) p.vIH = th;
+        if (tw < p.vIW) p.vIW = tw;
+        AED_REQUIRE(p.vIH >= 2 * p.IH - 1 && p.vIW >= 2 * p.IW - 1, "conv_gemm: upsample target %dx%d too small for %dx%d",
+                    th, tw, p.IH, p.IW);
+    }
     AED_REQUIRE(p.A && p.W && p.C, "conv_gemm: null operand");
     AED_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "conv_gemm: bad shape M=%d N=%d K=%d", p.M, p.N, p.K);
     AED_REQUIRE(p.K == p.KH * p.KW * p.Cin, "conv_gemm: K=%d != KH*KW*Cin=%d", p.K, p.KH * p.KW * p.Cin);

@@ -233,10 +233,6 @@ class PipelineWrapper(torch.nn.Module):
                      encoder_attention_mask=None, replace_h_space=None, replace_skip_conns=None,
                      return_dict: bool = True, zero_out_resconns=None):
         B, C, H, W = sample.shape
-        up = 2 ** self.model.unet.num_upsamplers
-        if H % up or W % up:
-            raise NotImplementedError(f"latent {H}x{W} is not a multiple of {up}: forward_upsample_size path "
-                                      f"(models.py:186-188) is not built")
         cond, L0, L1 = self._cond_from_args(B, encoder_hidden_states, class_labels, encoder_attention_mask)
         eng = self._cached(("unet", B, H, W, L0, L1),
                            lambda: UNetEngine(self.family["unet"], self.unet_weights, self.device, B, H, W,

@@ -361,10 +361,7 @@ class UNetEngine:
             co = boc[lvl]
             for j in range(lpb + 1):
                 sk, sc, sh_, sw_ = skips.pop()
-                if (sh_, sw_) != (hh, ww):
-                    raise NotImplementedError(
-                        f"latent {H}x{W} is not a multiple of 2^{nb - 1}: the reference's forward_upsample_size "
-                        f"path (models.py:186-188, nearest resize to the skip's size) is not built yet")
+                assert (sh_, sw_) == (hh, ww), "skip / feature-map size mismatch"
                 cat = self.tmp("cat", B, hh, ww, ch + sc)
                 tp.copy2d(h, cat, rows=B * hh * ww, cols=ch, ld_src=h.stride(-2), ld_dst=ch + sc, name="cat.h")
                 tp.copy2d(sk, cat[..., ch:], rows=B * hh * ww, cols=sc, ld_src=sk.stride(-2), ld_dst=ch + sc,
@@ -376,11 +373,15 @@ class UNetEngine:
                     h = self._site(f"up_blocks.{i}", j * len(ctx_pb[lvl]), h, co, hh, ww, heads_pb[lvl], ctx_pb[lvl],
                                    groups)
             if i < nb - 1:
+                # nearest resize to the NEXT skip's size (= 2x, or 2x-1 when that level was odd: the reference's
+                # forward_upsample_size path, models.py:186-188 / :361-366), fused into the conv's A-loader
                 p = f"up_blocks.{i}.upsamplers.0.conv"
-                d = tp.alloc(B, 2 * hh, 2 * ww, co)
-                tp.conv(h, wd[p + ".weight"], wd[p + ".bias"], d, B=B, IH=hh, IW=ww, Cin=co, OH=2 * hh, OW=2 * ww,
+                th, tw = skips[-1][2], skips[-1][3]
+                assert th in (2 * hh, 2 * hh - 1) and tw in (2 * ww, 2 * ww - 1)
+                d = tp.alloc(B, th, tw, co)
+                tp.conv(h, wd[p + ".weight"], wd[p + ".bias"], d, B=B, IH=hh, IW=ww, Cin=co, OH=th, OW=tw,
                         N=co, KH=3, KW=3, pad_h=1, pad_w=1, up=1, name=p)
-                h, hh, ww = d, 2 * hh, 2 * ww
+                h, hh, ww = d, th, tw
 
         # ---- out
         self.eps = tp.alloc(B, hh, ww, cout)

@@ -208,7 +208,13 @@ def unet_forward(cfg, sd, sample, timestep, encoder_hidden_states=None, class_la
             if has_attn:
                 h = run_attn(f"up_blocks.{i}", j * len(ctx_pb[lvl]), h, ctx_pb[lvl], heads_pb[lvl])
         if i < nb - 1:
-            h = F.interpolate(h, scale_factor=2.0, mode="nearest")
+            # forward_upsample_size (models.py:186-188, :361-366): resize to the next skip's spatial size when the
+            # input is not a multiple of 2^levels, else plain 2x (diffusers Upsample2D output_size semantics)
+            tgt = skips[-1].shape[2:]
+            if tuple(tgt) == (2 * h.shape[2], 2 * h.shape[3]):
+                h = F.interpolate(h, scale_factor=2.0, mode="nearest")
+            else:
+                h = F.interpolate(h, size=tuple(tgt), mode="nearest")
             h = _conv(sd, f"up_blocks.{i}.upsamplers.0.conv", h)
 
     # 6. out

@@ -124,3 +124,21 @@ def test_step_method_api_matches_oracle_functions():
     assert m.get_noise_shape(xt, 50) == (50, 8, 32, 16) and m.get_sr() == 16000
     with pytest.raises(Exception):
         models.load_model("tiny/audioldm2", "cpu", 10)                        # no CPU fallback in the product
+
+
+def test_arbitrary_clip_length_end_to_end():
+    """1.41 s clip -> 144 mel frames -> latent 36x16 (not a multiple of 8): runs through the whole path."""
+    T = 6
+    m = models.load_model("tiny/audioldm2", DEV, T, seed=0)
+    x0, _, dur = load_audio((synthetic_clip(seconds=1.41, seed=2), 16000), m.get_fn_STFT(), device=DEV, stft=True)
+    assert x0.shape == (1, 1, 144, 64)
+    torch.manual_seed(1)
+    audio, orig, w_edit = edit_clip(m, x0, ["rain"], ["jazz"], [""], [3.0], [12.0], T, 4)
+    assert w_edit.shape == (1, 8, 36, 16) and torch.isfinite(audio).all() and audio.shape[1] == 144 * 160 + 32
+    ow = _oracle_wrapper(m, T)
+    w0 = ovae.vae_encode(m.family["vae"], m.state_dicts["vae"], x0.cpu())
+    xts0 = ow.sample_xts_from_x0(w0, T, generator=torch.Generator().manual_seed(1))
+    enc = lambda p, **k: tuple(None if t is None else t.cpu() for t in m.encode_text(p, **k))     # noqa: E731
+    _, zs_o, xts_o = oloops.invert(ow, w0, enc(["rain"]), enc([""]), [3.0], T, eta=1.0, xts=xts0)
+    w_o = oloops.edit(ow, xts_o, torch.tensor([4]), enc(["jazz"]), enc([""]), [12.0], zs_o[:4], eta=1.0)
+    assert rel(w_edit.cpu(), w_o) < 5e-3

@@ -210,3 +210,17 @@ def test_wave_split_k_conv3x3():
             IW=W, Cin=C, OH=H, OW=W, N=N, KH=3, KW=3, pad_h=1, pad_w=1, tile=7, ksplit=1)
     run(tp)
     assert (nchw(out.cpu()) - ref).abs().max() < 3e-5
+
+
+@pytest.mark.parametrize("H,W,th,tw", [(5, 2, 9, 4), (9, 4, 17, 7), (4, 3, 8, 6)])
+def test_conv_nearest_resize_to_explicit_size(H, W, th, tw):
+    """Upsample2D with output_size (forward_upsample_size path): nearest resize to 2x or 2x-1, then 3x3 conv."""
+    B, C, N = 2, 32, 64
+    x, w, b = rnd(B, C, H, W, seed=1), rnd(N, C, 3, 3, seed=2, scale=(C * 9) ** -0.5), rnd(N, seed=3)
+    ref = F.conv2d(F.interpolate(x, size=(th, tw), mode="nearest"), w, b, padding=1)
+    tp = Tape(DEV)
+    out = tp.alloc(B, th, tw, N)
+    tp.conv(nhwc(x).to(DEV), w.permute(0, 2, 3, 1).reshape(N, -1).contiguous().to(DEV), b.to(DEV), out, B=B, IH=H,
+            IW=W, Cin=C, OH=th, OW=tw, N=N, KH=3, KW=3, pad_h=1, pad_w=1, up=1)
+    run(tp)
+    assert (nchw(out.cpu()) - ref).abs().max() < 3e-5

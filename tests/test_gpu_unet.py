@@ -86,3 +86,11 @@ def test_full_audioldm2_unet_matches_oracle():
     rel = ((got - ref).norm() / ref.norm()).item()
     assert rel < 1e-4, rel
     assert abs(eng.tape.flops / 2 / 1e9 - 172.4) < 3.0, eng.tape.flops / 2 / 1e9     # 172.4 GF / sample
+
+
+def test_unet_with_sizes_not_multiple_of_8_uses_upsample_size_path():
+    """Latent 36x12 -> 18x6 -> 9x3 -> 5x2: odd levels force the reference's forward_upsample_size path."""
+    fam = configs.tiny_family("audioldm2")
+    got, ref, hs, ref_h, _ = _run_case(fam, B=2, H=36, W=12, L0=8, L1=5, t=301, seed=5)
+    assert ref_h.shape[-2:] == (5, 2)
+    assert (got - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item())

@@ -270,6 +270,30 @@ class PipelineWrapper(torch.nn.Module):
         return UNet2DConditionOutput(sample=out), h_space, extracted
 
 
+    def unet_forward_pair(self, sample_u, sample_c, timestep, cond_u: Conditioning, cond_c: Conditioning):
+        """CFG pair in ONE batched U-Net call: rows [sample_u | sample_c] with their own conditioning
+        (ragged contexts are padded with zero-weight keys).  Returns (eps_u, eps_c) NCHW."""
+        n, C, H, W = sample_u.shape
+        ed = self.editor(H, W)
+        groups = [cond_u.repeat(n), cond_c.repeat(n)]
+        L0, L1 = ed._ctx_lens(groups)
+        eng = ed.unet(2 * n, L0, L1)
+        ed._set_cond(eng, groups)
+        with torch.inference_mode():
+            eng.x_in[:n].copy_(sample_u.to(self.device, torch.float32).permute(0, 2, 3, 1))
+            eng.x_in[n:].copy_(sample_c.to(self.device, torch.float32).permute(0, 2, 3, 1))
+        op = eng.tape.ops[eng.time_op]
+        arr = eng.tape.finalize()
+        for o in (op, arr[eng.time_op]):        # immediate timestep (no device table) for this stand-alone call
+            o.p[1] = None
+            o.p[2] = None
+            o.p[4] = None
+            o.i[4] = int(timestep)
+        eng.forward()
+        eps = eng.eps.permute(0, 3, 1, 2).contiguous()
+        return eps[:n], eps[n:]
+
+
 # --------------------------------------------------------------------------------------------------
 def _prompt_generator(prompt, salt):
     return torch.Generator().manual_seed(zlib.crc32((salt + "|" + prompt).encode("utf-8")))

@@ -177,6 +177,57 @@ def gen_loops():
     print("step math ok")
 
 
+# --------------------------------------------------------------------------- pc drift
+def gen_pc():
+    UOut = install_stubs()
+    sys.path.insert(0, REF)
+    import models as ref_models
+    import pc_drift as ref_pc
+
+    class FakeRef(ref_models.PipelineWrapper):
+        def __init__(self, sched, T):
+            super().__init__(model_id="fake", device=torch.device("cpu"))
+            sched.set_timesteps(T)
+            self.model = SimpleNamespace(scheduler=sched, unet=SimpleNamespace(config=SimpleNamespace(in_channels=8)))
+
+        def unet_forward(self, sample, timestep, encoder_hidden_states=None, class_labels=None,
+                         encoder_attention_mask=None, **kw):
+            return UOut(sample=synthetic_unet(sample, timestep, class_labels)), None, None
+
+    T = 50
+    sched = OracleDDIMScheduler()
+    m = FakeRef(sched, T)
+    g = torch.Generator().manual_seed(21)
+    xt = torch.randn((1, 8, 16, 16), generator=g) * 0.8
+    latent = torch.randn((1, 8, 16, 16), generator=g)
+    t = sched.timesteps[30]
+    mk = lambda p: ref_pc.PromptEmbeddings(embedding_hidden_states=None, boolean_prompt_mask=None,   # noqa: E731
+                                           embedding_class_lables=torch.stack([prompt_vec(p)]))
+    unc, txt = mk(""), mk("a dog barking")
+    mask = torch.ones_like(xt)
+    mask[..., 12:] = 0
+    with torch.no_grad():
+        xtm1, x0_pred = ref_pc.forward_directional(m, xt, t, latent, unc, txt, 3.0, eta=1.0)
+        rec = {}
+        for n_ev, iters in ((1, 6), (3, 5)):
+            torch.manual_seed(100 + n_ev)
+            init = torch.randn((n_ev, 8, 16, 16))          # what randn_like(expanded xt) draws from this seed
+            torch.manual_seed(100 + n_ev)
+            ev, val, corr, nrm, _, _ = ref_pc.get_eigenvectors(m, xt, txt, unc, latent, mask, t, x0_pred * mask,
+                                                               const=1e-3, cfg_tar=3.0, iters=iters, eta=1.0,
+                                                               n_ev=n_ev)
+            rec.update({f"init{n_ev}": init.numpy(), f"eigvec{n_ev}": ev.numpy(),
+                        f"eigval{n_ev}": torch.as_tensor(val).reshape(-1).numpy(), f"iters{n_ev}": iters,
+                        f"norm{n_ev}": torch.stack([torch.as_tensor(v).reshape(-1) for v in nrm]).numpy()})
+        eigdata = {int(t): dict(eigvec=ev, eigval=torch.as_tensor(val).reshape(-1))}
+        drift = ref_pc.apply_drift(m, xtm1, x0_pred, t, sched.timesteps, T, eigdata, latent, torch.device("cpu"),
+                                   amount=2.0, eta=1.0, ev_nums=[1, 2])
+    np.savez_compressed(os.path.join(OUT, "pc_drift.npz"), xt=xt.numpy(), latent=latent.numpy(), t=int(t), T=T,
+                        mask=mask.numpy(), xtm1=xtm1.numpy(), x0_pred=x0_pred.numpy(), drift=drift.numpy(),
+                        alphas_cumprod=sched.alphas_cumprod.numpy(), **rec)
+    print("pc", float(np.abs(rec["eigval3"]).max()), tuple(drift.shape))
+
+
 # --------------------------------------------------------------------------- audio
 def _load_by_path(modname, path):
     spec = importlib.util.spec_from_file_location(modname, path)
@@ -352,7 +403,7 @@ if __name__ == "__main__":
     # each generator runs in a fresh interpreter when "all" (the stubs of one break another)
     if what == "all":
         import subprocess
-        for w in ("loops", "audio", "hifigan", "unet", "vae"):
+        for w in ("loops", "pc", "audio", "hifigan", "unet", "vae"):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), w])
     else:
-        {"loops": gen_loops, "audio": gen_audio, "hifigan": gen_hifigan, "unet": gen_unet, "vae": gen_vae}[what]()
+        {"loops": gen_loops, "pc": gen_pc, "audio": gen_audio, "hifigan": gen_hifigan, "unet": gen_unet, "vae": gen_vae}[what]()

@@ -211,3 +211,31 @@ def test_product_scheduler_and_coefficients_match_reference_scalars():
             np.testing.assert_array_equal(step_coefficients(s, int(g[f"t{i}"]), 1.0).numpy(), g[f"coef{i}"])
     else:
         np.testing.assert_allclose(s.alphas_cumprod.numpy(), g["alphas_cumprod"], rtol=2e-6)
+
+
+def test_pc_drift_oracle_matches_reference():
+    """forward_directional / get_eigenvectors / apply_drift vs the reference's pc_drift.py."""
+    from oracle import pc as opc
+    g = np.load(os.path.join(G, "pc_drift.npz"))
+    T = int(g["T"])
+    w = _wrapper(T)
+    w.model.scheduler.alphas_cumprod = torch.from_numpy(g["alphas_cumprod"])
+    w.model.scheduler.final_alpha_cumprod = w.model.scheduler.alphas_cumprod[0]
+    xt, latent, mask = (torch.from_numpy(g[k]) for k in ("xt", "latent", "mask"))
+    t = torch.tensor(int(g["t"]))
+    unc, txt = _cond([""]), _cond(["a dog barking"])
+    xtm1, x0p = opc.forward_directional(w, xt, t, latent, unc, txt, 3.0, eta=1.0)
+    np.testing.assert_allclose(xtm1.numpy(), g["xtm1"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(x0p.numpy(), g["x0_pred"], rtol=1e-5, atol=1e-6)
+    for n_ev in (1, 3):
+        ev, val, _, nrm = opc.get_eigenvectors(w, xt, txt.repeat(n_ev, 1), unc.repeat(n_ev, 1), latent, mask, t,
+                                               torch.from_numpy(g["x0_pred"]) * mask,
+                                               torch.from_numpy(g[f"init{n_ev}"]), const=1e-3, cfg_tar=3.0,
+                                               iters=int(g[f"iters{n_ev}"]), eta=1.0, n_ev=n_ev)
+        np.testing.assert_allclose(torch.as_tensor(val).reshape(-1).numpy(), g[f"eigval{n_ev}"], rtol=2e-3)
+        cos = (ev.reshape(n_ev, -1) * torch.from_numpy(g[f"eigvec{n_ev}"]).reshape(n_ev, -1)).sum(1)
+        assert (cos.abs() > 0.999).all(), cos
+    drift = opc.apply_drift(w, torch.from_numpy(g["xtm1"]), torch.from_numpy(g["x0_pred"]), t,
+                            torch.from_numpy(g["eigvec3"]), torch.from_numpy(g["eigval3"]), latent, amount=2.0,
+                            eta=1.0, ev_nums=(1, 2))
+    np.testing.assert_allclose(drift.numpy(), g["drift"], rtol=1e-5, atol=2e-6)

@@ -65,3 +65,31 @@ def test_power_iteration_and_drift_match_oracle():
     d_o = opc.apply_drift(ow, xtm1_o, x0p_o, t, ev_o, torch.as_tensor(val_o).reshape(-1), latent, amount=2.0, eta=1.0,
                           ev_nums=(1, 2))
     assert (d.cpu() - d_o).abs().max() < 1e-4
+
+
+def test_sdedit_matches_oracle_sampler():
+    """SDEdit baseline (main_run_sdedit.py:78-100) on the device loop vs add_noise + forward_directional on CPU."""
+    from audioeditingcode_amd.sdedit import sdedit
+    T, skip = 10, 4
+    m = models.load_model("tiny/audioldm2", DEV, T, seed=1)
+    cfg, sd = m.family["unet"], m.state_dicts["unet"]
+    osched = OracleDDIMScheduler()
+    osched.set_timesteps(T)
+
+    def unet_fn(x, t, cond):
+        hs, cl, mk = (v.cpu().expand(x.shape[0], *v.shape[1:]) for v in cond)
+        return ounet.unet_forward(cfg, sd, x, t, encoder_hidden_states=hs, encoder_hidden_states_1=cl,
+                                  encoder_attention_mask_1=mk)[0]
+    ow = oloops.OracleWrapper(osched, unet_fn)
+    g = torch.Generator().manual_seed(8)
+    w0 = torch.randn(1, 8, 32, 16, generator=g) * 0.7
+    noise = torch.randn(1, 8, 32, 16, generator=g)
+    ts = osched.timesteps[skip:]
+    latents = [torch.randn(1, 8, 32, 16, generator=g) for _ in ts]
+    got = sdedit(m, w0, ["jazz"], [""], 5.0, skip, eta=1.0, latents=latents, noise=noise)
+    xt = osched.add_noise(w0, noise, ts[:1].unsqueeze(0))
+    for it, t in enumerate(ts):
+        xt, _ = opc.forward_directional(ow, xt, t, latents[it], m.encode_text([""]), m.encode_text(["jazz"]), 5.0,
+                                        eta=1.0)
+    err = ((got.cpu() - xt).norm() / xt.norm()).item()
+    assert err < 1e-3, err

@@ -12,9 +12,10 @@
 // Arithmetic: v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain, 157 TF peak) -- the parity
 // configuration of the reference, which runs strict fp32 (code/utils.py:113-116).
 //
-// Tiling: 256 threads = 4 waves; block tile BM x BN, K-chunk BKT (64 when the channel count allows,
-// else 32) staged through LDS with a 4-float row pad (conflict-free ds_read_b128 fragment reads);
-// DEPTH chunks are kept in flight in registers.  Each lane reads 4 consecutive k per ds_read_b128;
+// Tiling: 256 threads = 4 waves; block tile BM x BN, K-chunk BKT staged through TWO LDS stages with a
+// 4-float row pad (conflict-free ds_read_b128 fragment reads): chunk k+1 is written to the other stage
+// while the MFMAs of chunk k run (one barrier per chunk), DEPTH further chunks are in flight in
+// registers, and the fragments of k-block kb+1 are read before the MFMAs of kb issue.  Each lane reads 4 consecutive k per ds_read_b128;
 // MFMA step s of a k-block uses k = {s, 4+s} (A and B agree, the sum over k is order-free).
 //
 // At the batch sizes of the edit loop (U-Net batch 2) most launches are a few microseconds of MFMA
@@ -23,7 +24,6 @@
 #include "aed_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-#define GN_MAXC 1280   // largest GroupNorm'ed channel count on the path (up-block concat 640+640)
 
 struct CGParams {
     const float* A;
@@ -45,8 +45,6 @@ struct CGParams {
     int rpb;                 // output rows per batch item = OH*OW
     int nchunks;             // ceil(K/BKT)
     float in_slope, out_p, out_div;
-    const float* gn_ab;      // fused GroupNorm: per batch item [2][Cin] = (scale a, shift d); x' = act(x*a + d)
-    int gn_act;
     int ln_mode;             // 1: A rows are LayerNorm inputs; W has gamma folded in, rowvec = sum_k W'[n,k], bias = W.beta (+bias)
     float ln_eps;
 };
@@ -74,21 +72,23 @@ __device__ __forceinline__ void store_out(const CGParams& p, int m, int n, float
     *dst = v;
 }
 
-template <int BM, int BN, int WROWS, int WCOLS, bool GENERIC, int DEPTH, int BKT>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(CGParams p) {
+// PLAIN: the A operand needs no transform (no loader activation, no LayerNorm statistics) -- the common case.
+// MINW: waves per SIMD the register allocation must leave room for (2 blocks per CU for the 128x128 tile).
+template <int BM, int BN, int WROWS, int WCOLS, bool GENERIC, int DEPTH, int BKT, bool PLAIN>
+__global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 1) void conv_gemm_kernel(CGParams p) {
     constexpr int WM = BM / WROWS, WN = BN / WCOLS;
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int LDS_LD = BKT + 4;
+    constexpr int STAGE = (BM + BN) * LDS_LD;      // one operand stage (A tile then W tile)
     constexpr int TPR = BKT / 4;            // loader threads per row (float4 each)
     constexpr int RPP = 256 / TPR;          // rows per loader pass
     constexpr int PA = BM / RPP, PB = BN / RPP;
+    constexpr int NKB = BKT / 8;
     static_assert(WROWS * WCOLS == 4, "4 waves");
     static_assert(TM >= 1 && TN >= 1 && PA >= 1 && PB >= 1, "tile");
 
-    __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * LDS_LD];
-    __shared__ __attribute__((aligned(16))) float gn_lds[GENERIC ? 4 : 2 * GN_MAXC];
-    float* As = lds;
-    float* Ws = lds + BM * LDS_LD;
+    // two operand stages: chunk k+1 is written while the MFMAs of chunk k run -> one barrier per chunk
+    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -137,7 +137,6 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(CGParams p) {
         wbase[q] = (unsigned)(wvalid[q] ? n : 0) * (unsigned)p.K + lcol;
     }
     const int vIH = p.vIH, vIW = p.vIW;
-
     // running (tap, channel) position of the NEXT chunk to prefetch (prefetch() is always called with
     // consecutive kc): no per-chunk integer divisions
     int pf_c0 = 0, pf_ty = 0, pf_tx = 0;
@@ -149,27 +148,16 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(CGParams p) {
         pf_tx = tap - pf_ty * p.KW;
     }
 
-    // fused GroupNorm (+SiLU): the block's rows belong to ONE batch item (host guarantees OH*OW % BM == 0);
-    // its per-channel scale/shift vectors are staged in LDS once and applied at the LDS write
-    if constexpr (!GENERIC) {
-        if (p.gn_ab) {
-            const float4* src = reinterpret_cast<const float4*>(p.gn_ab + (size_t)(m0 / p.rpb) * 2 * p.Cin);
-            for (int idx = tid; idx < p.Cin / 2; idx += 256) reinterpret_cast<float4*>(gn_lds)[idx] = src[idx];
-            __syncthreads();
-        }
-    }
-    int rc0[DEPTH];              // channel offset of each in-flight chunk (for the GroupNorm vectors)
     float4 rbuf_a[DEPTH][PA], rbuf_b[DEPTH][PB];
     float ln_s1[PA], ln_s2[PA];   // fused LayerNorm: running sum / sum of squares of this thread's A rows
 #pragma unroll
     for (int q = 0; q < PA; ++q) { ln_s1[q] = 0.f; ln_s2[q] = 0.f; }
     unsigned rmask[DEPTH];      // per stage: bit q set = A row q of that chunk is in-bounds (else zero padding)
 
-    auto prefetch = [&](int kc, float4 (&ra)[PA], float4 (&rb)[PB], unsigned& mask, int& cc0) {
-        const int k0 = kc * BKT;
+    auto prefetch = [&](int kc, float4 (&ra)[PA], float4 (&rb)[PB], unsigned& mask) {
+        const int k0 = min(kc, p.nchunks - 1) * BKT;      // dead prefetches past the end stay in bounds
         if constexpr (!GENERIC) {
             const int c0 = pf_c0;
-            cc0 = c0;
             const int dy = pf_ty * p.dil_h, dx = pf_tx * p.dil_w;
             pf_c0 += BKT;
             if (pf_c0 >= p.Cin) {
@@ -180,7 +168,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(CGParams p) {
 #pragma unroll
             for (int q = 0; q < PA; ++q) {
                 const int iy = ay0[q] + dy, ix = ax0[q] + dx;
-                const bool ok = avalid[q] && (unsigned)iy < (unsigned)vIH && (unsigned)ix < (unsigned)vIW;
+                const bool ok = avalid[q] & ((unsigned)iy < (unsigned)vIH) & ((unsigned)ix < (unsigned)vIW);
                 // clamped, always-valid address; the zero padding is applied at the LDS write so that the
                 // raw load stays in flight (nothing consumes it here)
                 const int cy = ok ? (iy >> p.up) : 0, cx = ok ? (ix >> p.up) : 0;
@@ -214,7 +202,6 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(CGParams p) {
                 ra[q] = make_float4(tmp[0], tmp[1], tmp[2], tmp[3]);
             }
             mask = 0xffffffffu;
-            cc0 = 0;
 #pragma unroll
             for (int q = 0; q < PB; ++q) {
                 float tmp[4];
@@ -228,45 +215,15 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(CGParams p) {
         }
     };
 
-    f32x16 acc[TM][TN];
+    // registers of one prefetched chunk -> an LDS stage (zero padding, loader transforms, LayerNorm statistics)
+    auto stage_write = [&](float* st, const float4 (&ra)[PA], const float4 (&rb)[PB], unsigned mask) {
+        float* As_ = st + lrow * LDS_LD + lcol;
+        float* Ws_ = st + (BM + lrow) * LDS_LD + lcol;
 #pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-    const int fi = lane & 31;        // fragment row (A: m, B: n)
-    const int fh = lane >> 5;        // k half
-    const float* a_frag = As + (wr * WM + fi) * LDS_LD + 4 * fh;
-    const float* b_frag = Ws + (wc * WN + fi) * LDS_LD + 4 * fh;
-
-    STAMP();
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d)
-        if (kc_begin + d < kc_end) prefetch(kc_begin + d, rbuf_a[d], rbuf_b[d], rmask[d], rc0[d]);
-    STAMP();
-    for (int kc0 = kc_begin; kc0 < kc_end; kc0 += DEPTH) {
-#pragma unroll
-        for (int d = 0; d < DEPTH; ++d) {
-            const int kc = kc0 + d;
-            if (kc >= kc_end) break;
-#pragma unroll
-            for (int q = 0; q < PA; ++q) {
-                float4 v = rbuf_a[d][q];
-                if constexpr (!GENERIC) {
-                    if (p.gn_ab) {
-                        const float4 ga = *reinterpret_cast<const float4*>(gn_lds + rc0[d] + lcol);
-                        const float4 gd = *reinterpret_cast<const float4*>(gn_lds + p.Cin + rc0[d] + lcol);
-                        v.x = v.x * ga.x + gd.x; v.y = v.y * ga.y + gd.y;
-                        v.z = v.z * ga.z + gd.z; v.w = v.w * ga.w + gd.w;
-                        if (p.gn_act) {
-                            v.x = __fdividef(v.x, 1.0f + __expf(-v.x)); v.y = __fdividef(v.y, 1.0f + __expf(-v.y));
-                            v.z = __fdividef(v.z, 1.0f + __expf(-v.z)); v.w = __fdividef(v.w, 1.0f + __expf(-v.w));
-                        }
-                    }
-                }
-                if (!((rmask[d] >> q) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = 0; q < PA; ++q) {
+            float4 v = ra[q];
+            if (!((mask >> q) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (!PLAIN) {
                 if (p.ln_mode) {
                     ln_s1[q] += (v.x + v.y) + (v.z + v.w);
                     ln_s2[q] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
@@ -277,36 +234,97 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(CGParams p) {
                     v.z = in_transform(v.z, p.in_act, p.in_slope);
                     v.w = in_transform(v.w, p.in_act, p.in_slope);
                 }
-                *reinterpret_cast<float4*>(As + (lrow + RPP * q) * LDS_LD + lcol) = v;
             }
+            *reinterpret_cast<float4*>(As_ + RPP * q * LDS_LD) = v;
+        }
 #pragma unroll
-            for (int q = 0; q < PB; ++q)
-                *reinterpret_cast<float4*>(Ws + (lrow + RPP * q) * LDS_LD + lcol) =
-                    wvalid[q] ? rbuf_b[d][q] : make_float4(0.f, 0.f, 0.f, 0.f);
-            __syncthreads();
-            STAMP();
-            if (kc + DEPTH < kc_end) prefetch(kc + DEPTH, rbuf_a[d], rbuf_b[d], rmask[d], rc0[d]);
+        for (int q = 0; q < PB; ++q)
+            *reinterpret_cast<float4*>(Ws_ + RPP * q * LDS_LD) = wvalid[q] ? rb[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+
+    f32x16 acc[TM][TN];
 #pragma unroll
-            for (int kb = 0; kb < BKT / 8; ++kb) {
-                float4 af[TM], bf[TN];
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int fi = lane & 31;        // fragment row (A: m, B: n)
+    const int fh = lane >> 5;        // k half
+    const int a_frag_off = (wr * WM + fi) * LDS_LD + 4 * fh;
+    const int b_frag_off = (BM + wc * WN + fi) * LDS_LD + 4 * fh;
+
+    // the MFMAs of one staged chunk; the fragments of k-block kb+1 are fetched before the MFMAs of kb issue
+    auto mfma_chunk = [&](const float* st) {
+        const float* a_frag = st + a_frag_off;
+        const float* b_frag = st + b_frag_off;
+        float4 af[2][TM], bf[2][TN];
+#pragma unroll
+        for (int a = 0; a < TM; ++a) af[0][a] = *reinterpret_cast<const float4*>(a_frag + a * 32 * LDS_LD);
+#pragma unroll
+        for (int b = 0; b < TN; ++b) bf[0][b] = *reinterpret_cast<const float4*>(b_frag + b * 32 * LDS_LD);
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            const int c = kb & 1, nx = c ^ 1;
+            if (kb + 1 < NKB) {
 #pragma unroll
                 for (int a = 0; a < TM; ++a)
-                    af[a] = *reinterpret_cast<const float4*>(a_frag + a * 32 * LDS_LD + kb * 8);
+                    af[nx][a] = *reinterpret_cast<const float4*>(a_frag + a * 32 * LDS_LD + (kb + 1) * 8);
 #pragma unroll
                 for (int b = 0; b < TN; ++b)
-                    bf[b] = *reinterpret_cast<const float4*>(b_frag + b * 32 * LDS_LD + kb * 8);
-#pragma unroll
-                for (int a = 0; a < TM; ++a)
-#pragma unroll
-                    for (int b = 0; b < TN; ++b) {
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].x, bf[b].x, acc[a][b], 0, 0, 0);
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].y, bf[b].y, acc[a][b], 0, 0, 0);
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].z, bf[b].z, acc[a][b], 0, 0, 0);
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].w, bf[b].w, acc[a][b], 0, 0, 0);
-                    }
+                    bf[nx][b] = *reinterpret_cast<const float4*>(b_frag + b * 32 * LDS_LD + (kb + 1) * 8);
             }
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][a].x, bf[c][b].x, acc[a][b], 0, 0, 0);
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][a].y, bf[c][b].y, acc[a][b], 0, 0, 0);
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][a].z, bf[c][b].z, acc[a][b], 0, 0, 0);
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][a].w, bf[c][b].w, acc[a][b], 0, 0, 0);
+        }
+    };
+
+    STAMP();
+    // every prefetch is issued unconditionally (chunks past the end read clamped addresses and are never staged):
+    // the number of loads in flight is then static and the compiler's s_waitcnt keeps the newer chunks in flight
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) prefetch(kc_begin + d, rbuf_a[d], rbuf_b[d], rmask[d]);
+    STAMP();
+    // chunk kc_begin -> stage 0; its register slot takes chunk kc_begin + DEPTH
+    stage_write(lds, rbuf_a[0], rbuf_b[0], rmask[0]);
+    prefetch(kc_begin + DEPTH, rbuf_a[0], rbuf_b[0], rmask[0]);
+    __syncthreads();
+    STAMP();
+    int cur = 0;
+    for (int kc0 = kc_begin; kc0 < kc_end; kc0 += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const int kc = kc0 + d;
+            if (kc >= kc_end) break;
+            // chunk kc+1 sits in register slot (d+1) % DEPTH: write it to the other stage, refill the slot
+            {
+                const int sl = (d + 1) % DEPTH;
+                if (kc + 1 < kc_end) stage_write(lds + (cur ^ 1) * STAGE, rbuf_a[sl], rbuf_b[sl], rmask[sl]);
+                prefetch(kc + 1 + DEPTH, rbuf_a[sl], rbuf_b[sl], rmask[sl]);
+            }
+            mfma_chunk(lds + cur * STAGE);
             __syncthreads();
             STAMP();
+            cur ^= 1;
         }
     }
 
@@ -432,11 +450,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(CGParams p) {
 // k-blocks in flight behind the MFMAs), the four partial tiles meet once in LDS, are summed in a fixed
 // order (deterministic) and every thread finishes 4 outputs with coalesced stores.  4x more blocks than
 // 64x64 tiles and a 4x shorter dependent MFMA chain per wave.
+// Measured and NOT adopted (round 1, s_memtime timelines, batch-2 U-Net forward 11.2 ms with this version):
+// deeper register prefetch (2-4 sets in flight: 11.5-17.7 ms, the lane=row loads are cache-line-request bound),
+// 8 waves per tile (13.8 ms), per-wave LDS staging with coalesced loads (12.1 ms), 4 accumulator chains (no change).
 template <int UNROLL>
 __global__ __launch_bounds__(256) void conv_gemm_wsk_kernel(CGParams p) {
     __shared__ float part[4][16][64];
     __shared__ float ln_part[4][32][2];
-    __shared__ __attribute__((aligned(16))) float gn_lds[2 * GN_MAXC];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fi = lane & 31, fh = lane >> 5;
     const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
@@ -469,11 +489,6 @@ __global__ __launch_bounds__(256) void conv_gemm_wsk_kernel(CGParams p) {
     int c0 = k0 - tap * p.Cin;
     int ty = tap / p.KW, tx = tap - ty * p.KW;
 
-    if (p.gn_ab) {     // fused GroupNorm: one batch item per block (OH*OW % 32 == 0)
-        const float4* src = reinterpret_cast<const float4*>(p.gn_ab + (size_t)(m0 / p.rpb) * 2 * p.Cin);
-        for (int idx = tid; idx < p.Cin / 2; idx += 256) reinterpret_cast<float4*>(gn_lds)[idx] = src[idx];
-        __syncthreads();
-    }
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -482,18 +497,16 @@ __global__ __launch_bounds__(256) void conv_gemm_wsk_kernel(CGParams p) {
     for (int kb = kb_begin; kb < kb_end; kb += UNROLL) {
         float4 av[UNROLL], wv[UNROLL];
         bool aok[UNROLL];
-        int ac0[UNROLL];
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             const bool live = kb + u < kb_end;
             const int iy = ay0 + ty * p.dil_h, ix = ax0 + tx * p.dil_w;
-            const bool ok = live && mvalid && (unsigned)iy < (unsigned)vIH && (unsigned)ix < (unsigned)vIW;
+            const bool ok = live & mvalid & ((unsigned)iy < (unsigned)vIH) & ((unsigned)ix < (unsigned)vIW);
             const int cy = ok ? (iy >> p.up) : 0, cx = ok ? (ix >> p.up) : 0;
             const unsigned off = abase + (unsigned)(cy * p.IW + cx) * (unsigned)p.lda + c0;
             av[u] = *reinterpret_cast<const float4*>(p.A + (ok ? off : 4u * fh));
             wv[u] = *reinterpret_cast<const float4*>(wrow + (live ? k0 : 0));
             aok[u] = ok;
-            ac0[u] = c0;
             if (!(live && nvalid)) wv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             k0 += 8;
             c0 += 8;
@@ -505,15 +518,6 @@ __global__ __launch_bounds__(256) void conv_gemm_wsk_kernel(CGParams p) {
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             float4 a = av[u];
-            if (p.gn_ab) {
-                const float4 ga = *reinterpret_cast<const float4*>(gn_lds + ac0[u] + 4 * fh);
-                const float4 gd = *reinterpret_cast<const float4*>(gn_lds + p.Cin + ac0[u] + 4 * fh);
-                a.x = a.x * ga.x + gd.x; a.y = a.y * ga.y + gd.y; a.z = a.z * ga.z + gd.z; a.w = a.w * ga.w + gd.w;
-                if (p.gn_act) {
-                    a.x = __fdividef(a.x, 1.0f + __expf(-a.x)); a.y = __fdividef(a.y, 1.0f + __expf(-a.y));
-                    a.z = __fdividef(a.z, 1.0f + __expf(-a.z)); a.w = __fdividef(a.w, 1.0f + __expf(-a.w));
-                }
-            }
             if (!aok[u]) a = make_float4(0.f, 0.f, 0.f, 0.f);
             if (p.ln_mode) {
                 ln_s1 += (a.x + a.y) + (a.z + a.w);
@@ -585,8 +589,6 @@ static int fill_params(const aed_op* op, CGParams& p, int bkt) {
     p.rowvec = (const float*)op->p[5];
     p.ws = (float*)op->p[6];
     p.dbg = (op->flags & 1) ? (long long*)op->p[7] : nullptr;
-    p.gn_ab = (op->flags & 2) ? (const float*)op->p[7] : nullptr;
-    p.gn_act = (op->flags >> 2) & 1;
     const int32_t* i = op->i;
     p.M = i[0]; p.N = i[1]; p.K = i[2]; p.lda = i[3]; p.ldc = i[4]; p.ldr = i[5]; p.ld_rv = i[6];
     p.IH = i[7]; p.IW = i[8]; p.OH = i[9]; p.OW = i[10]; p.Cin = i[11]; p.KH = i[12]; p.KW = i[13];
@@ -620,25 +622,28 @@ static int fill_params(const aed_op* op, CGParams& p, int bkt) {
     if (p.ksplit < 1) p.ksplit = 1;
     if (p.ksplit > p.nchunks) p.ksplit = p.nchunks;
     if (p.ksplit > 1) AED_REQUIRE(p.ws != nullptr, "conv_gemm: split-K needs a workspace");
-    if (p.gn_ab) AED_REQUIRE(p.Cin <= GN_MAXC && p.Cin % 4 == 0 && p.in_act == 0, "conv_gemm: fused GroupNorm Cin=%d", p.Cin);
     if (p.ln_mode)
         AED_REQUIRE(p.ksplit == 1 && p.KH * p.KW == 1 && p.rowvec && p.bias && p.in_act == 0,
                     "conv_gemm: fused LayerNorm needs a 1-tap, unsplit GEMM with folded weights");
     return 0;
 }
 
-template <int BM, int BN, int WR, int WC, int D32, int D64>
-static void launch_cfg(const CGParams& p, bool generic, bool bk64, hipStream_t s) {
+template <int BM, int BN, int WR, int WC, int DEPTH, int BKT>
+static void launch_cfg(const CGParams& p, bool plain, hipStream_t s) {
     dim3 grid(aed_cdiv(p.N, BN), aed_cdiv(p.M, BM), p.ksplit);
-    if (generic)
-        hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WR, WC, true, 1, 32>), grid, dim3(256), 0, s, p);
-    else if (bk64)
-        hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WR, WC, false, D64, 64>), grid, dim3(256), 0, s, p);
+    if (plain)
+        hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WR, WC, false, DEPTH, BKT, true>), grid, dim3(256), 0, s, p);
     else
-        hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WR, WC, false, D32, 32>), grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WR, WC, false, DEPTH, BKT, false>), grid, dim3(256), 0, s, p);
 }
 
-// tile_cfg: 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x128, 4 = 64x64, 5 = 128x32, 6 = 32x128
+template <int BM, int BN, int WR, int WC>
+static void launch_generic(const CGParams& p, hipStream_t s) {
+    dim3 grid(aed_cdiv(p.N, BN), aed_cdiv(p.M, BM), p.ksplit);
+    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WR, WC, true, 1, 32, false>), grid, dim3(256), 0, s, p);
+}
+
+// tile_cfg: 0 auto, 1 = 128x128, 2 = 128x64, 4 = 64x64, 5 = 128x32, 6 = 32x128, 7 = wave-split-K 32x32
 // i[30] = 1 forces the 32-wide K chunk (A/B testing)
 int launch_conv_gemm(const aed_op* op, hipStream_t s) {
     CGParams p;
@@ -647,6 +652,7 @@ int launch_conv_gemm(const aed_op* op, hipStream_t s) {
     const bool generic = (Cin % 32 != 0) || (i[3] % 4 != 0) || ((uintptr_t)op->p[0] % 16 != 0) ||
                          ((uintptr_t)op->p[1] % 16 != 0);
     int cfg = i[29];
+    if (cfg == 3) cfg = 2;
     if (cfg == 0) {
         const int cus = aed_num_cus();
         const int M = i[0], N = i[1], ks = i[28] > 1 ? i[28] : 1;
@@ -658,17 +664,29 @@ int launch_conv_gemm(const aed_op* op, hipStream_t s) {
         else cfg = 4;
         if (N < 64 && cfg != 5) cfg = 5;
     }
-    // 64-wide K chunks halve the barrier count; the 128x128 tile would need 70 KB of LDS, so it stays at 32
-    const bool bk64 = !generic && (Cin % 64 == 0) && i[30] != 1 && cfg != 1 && cfg != 7;
+    if (generic && (cfg == 1 || cfg == 2)) cfg = 4;     // the scalar-gather path only exists for the small tiles
+    // K chunk: 32 (two LDS stages of a 128x128 tile = 72 KB -> two blocks per CU); 64 for the 64x64 tile when the
+    // channel count allows (half the barriers, still two blocks per CU)
+    const bool bk64 = !generic && (Cin % 64 == 0) && i[30] != 1 && cfg == 4;
     int rc = fill_params(op, p, cfg == 7 ? 8 : (bk64 ? 64 : 32));
     if (rc) return rc;
+    const bool plain = p.in_act == 0 && p.ln_mode == 0;
     switch (cfg) {
-        case 1: launch_cfg<128, 128, 2, 2, 2, 1>(p, generic, bk64, s); break;
-        case 2: launch_cfg<128, 64, 2, 2, 3, 2>(p, generic, bk64, s); break;
-        case 3: launch_cfg<64, 128, 2, 2, 3, 2>(p, generic, bk64, s); break;
-        case 4: launch_cfg<64, 64, 2, 2, 4, 2>(p, generic, bk64, s); break;
-        case 5: launch_cfg<128, 32, 4, 1, 4, 2>(p, generic, bk64, s); break;
-        case 6: launch_cfg<32, 128, 1, 4, 4, 2>(p, generic, bk64, s); break;
+        case 1: launch_cfg<128, 128, 2, 2, 2, 32>(p, plain, s); break;
+        case 2: launch_cfg<128, 64, 2, 2, 2, 32>(p, plain, s); break;
+        case 4:
+            if (generic) launch_generic<64, 64, 2, 2>(p, s);
+            else if (bk64) launch_cfg<64, 64, 2, 2, 2, 64>(p, plain, s);
+            else launch_cfg<64, 64, 2, 2, 3, 32>(p, plain, s);
+            break;
+        case 5:
+            if (generic) launch_generic<128, 32, 4, 1>(p, s);
+            else launch_cfg<128, 32, 4, 1, 3, 32>(p, plain, s);
+            break;
+        case 6:
+            if (generic) launch_generic<32, 128, 1, 4>(p, s);
+            else launch_cfg<32, 128, 1, 4, 3, 32>(p, plain, s);
+            break;
         case 7: {
             AED_REQUIRE(!generic && p.Cin % 8 == 0, "conv_gemm: wave-split-K needs the vector path");
             dim3 grid(aed_cdiv(p.N, 32), aed_cdiv(p.M, 32), p.ksplit);

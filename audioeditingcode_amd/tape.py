@@ -10,12 +10,17 @@ Layout convention: activations are channels-last fp32 -- a [B,H,W,C] feature map
 """
 import ctypes
 import math
+import os
 
 import torch
 
 from . import _lib as L
 
 CU_COUNT = 256          # MI355X; tiling heuristics target this, overridable for tests
+
+
+# A/B switch for the K-chunk width of conv_gemm: 0 auto, 1 force 32, 2 allow 64 on the 128x128 tile too
+FORCE_BK = int(os.environ.get("AED_FORCE_BK", "0"))
 
 
 class Tape:
@@ -100,7 +105,7 @@ class Tape:
     def conv(self, x, w, bias, out, *, B, IH, IW, Cin, OH, OW, N, KH=1, KW=1, stride=1, pad_h=0, pad_w=0,
              dil_h=1, dil_w=1, up=0, lda=None, a_bs=None, res=None, rowvec=None, ld_rv=0, in_act=0, in_slope=0.0,
              out_act=0, out_p=0.0, accumulate=0, out_div=1.0, o_mul=1, o_add=0, o_len=None, out_bs=None,
-             ldc=None, ldr=None, ksplit=0, tile=0, ln_rowsum=None, ln_eps=1e-5, gn_ab=None, gn_act=0, name="conv"):
+             ldc=None, ldr=None, ksplit=0, tile=0, ln_rowsum=None, ln_eps=1e-5, name="conv"):
         """Implicit-GEMM conv (AED_OP_CONV_GEMM).  x: [B,IH,IW,>=Cin] view, w: [N, KH*KW*Cin]."""
         M = B * OH * OW
         K = KH * KW * Cin
@@ -115,16 +120,6 @@ class Tape:
         auto_tile, auto_split = self.pick_tile(M, N, K, vector_ok=vec_ok)
         tile = tile or auto_tile
         ksplit = ksplit or auto_split
-        flags = 0
-        if gn_ab is not None:
-            # fused GroupNorm(+SiLU) in the A-loader: every block must sit inside one batch item
-            assert vec_ok and in_act == 0 and Cin <= 1280
-            bm = self.TILE_BM[tile]
-            if (OH * OW) % bm:
-                tile = 7 if (OH * OW) % 32 == 0 and K <= 2560 else 4
-                assert (OH * OW) % self.TILE_BM[tile] == 0, "fused GroupNorm needs OH*OW to be a multiple of the tile height"
-                ksplit = 1 if tile == 7 else ksplit
-            flags = 2 | (4 if gn_act else 0)
         ln_mode = 0
         if ln_rowsum is not None:
             # fused LayerNorm: `w` carries gamma, `bias` = W.beta (+bias), `ln_rowsum`[n] = sum_k w[n,k]
@@ -133,10 +128,10 @@ class Tape:
             if tile == 7 and K > 1024:
                 tile = 4
         i = [M, N, K, lda, ldc, ldr or 0, ld_rv, IH, IW, OH, OW, Cin, KH, KW, stride, pad_h, pad_w, dil_h, dil_w, up,
-             a_bs, o_mul, o_add, o_len, out_bs, in_act, out_act, accumulate, ksplit, tile, 0, ln_mode]
+             a_bs, o_mul, o_add, o_len, out_bs, in_act, out_act, accumulate, ksplit, tile, FORCE_BK, ln_mode]
         idx = self._add(L.OP_CONV_GEMM, i, [in_slope, out_p, out_div, ln_eps],
-                        [x, w, bias, out, res, rowvec, None, gn_ab], name=name, flops=2 * M * N * K,
-                        nbytes=4 * (B * IH * IW * Cin + N * K + M * N), flags=flags)
+                        [x, w, bias, out, res, rowvec, None, None], name=name, flops=2 * M * N * K,
+                        nbytes=4 * (B * IH * IW * Cin + N * K + M * N))
         if ksplit > 1:
             self._ws_need = max(self._ws_need, ksplit * M * N)
             self._ws_ops.append(idx)
@@ -150,12 +145,6 @@ class Tape:
     TILE_BM = {1: 128, 2: 128, 3: 64, 4: 64, 5: 128, 6: 32, 7: 32}
 
     # ------------------------------------------------------------------ norms
-    def gn_scale_shift(self, x, gamma, beta, ab, *, B, HW, C, G=32, eps=1e-5, name="gn"):
-        """GroupNorm statistics -> per-(batch, channel) scale/shift [B,2,C] for a conv with gn_ab=..."""
-        self._add(L.OP_GN_SCALE_SHIFT, [B, HW, C, G, x.stride(-2)], [eps], [x, gamma, beta, ab],
-                  name=name + ".scale_shift", nbytes=4 * B * HW * C)
-        return ab
-
     def groupnorm(self, x, gamma, beta, out, *, B, HW, C, G=32, eps=1e-5, act=0, name="gn"):
         ldx = x.stride(-2)
         ldy = out.stride(-2)

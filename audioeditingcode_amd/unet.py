@@ -95,13 +95,12 @@ class PackedUNetWeights:
 
 class UNetEngine:
     def __init__(self, cfg, weights, device, batch, H, W, ctx_len0=0, ctx_len1=0, use_ehs=True,
-                 timesteps_dev=None, state_dev=None, fuse_ln=True, fuse_gn=False):
+                 timesteps_dev=None, state_dev=None, fuse_ln=True):
         self.cfg = cfg
         self.fuse_ln = fuse_ln
         # GroupNorm(+SiLU) inside the conv A-loader is implemented and parity-tested but OFF by default: measured
         # on MI355X it is a wash at U-Net batch 2 (11.53 vs 11.51 ms/forward) and 5 % slower at batch 32
         # (77.8 vs 73.8 ms): the loader's 9x-per-tap SiLU recompute costs more than the saved launch + round trip.
-        self.fuse_gn = fuse_gn
         self.device = torch.device(device)
         self.B, self.H, self.W = batch, H, W
         self.use_ehs = use_ehs
@@ -125,42 +124,25 @@ class UNetEngine:
     # ------------------------------------------------------------------ modules
     def _resnet(self, p, x, Cin, Cout, H, W, dest, groups, eps):
         tp, wd, B = self.tape, self.wd, self.B
-        fuse = self._can_fuse_gn(H * W, Cin) and self._can_fuse_gn(H * W, Cout)
         h = self.tmp("res_h", B, H, W, Cout)
         off = self.temb_off[p + ".time_emb_proj"]
-        if fuse:
-            # GroupNorm+SiLU applied inside the conv's A-loader: one small statistics launch, no normalised copy
-            ab1 = self.tmp("gn_ab", B, 2, Cin)
-            tp.gn_scale_shift(x, wd[p + ".norm1.weight"], wd[p + ".norm1.bias"], ab1, B=B, HW=H * W, C=Cin,
-                              G=groups, eps=eps, name=p + ".norm1")
-            a, kw1 = x, dict(gn_ab=ab1, gn_act=1)
-        else:
-            a, kw1 = self.tmp("gn_a", B, H, W, Cin), {}
-            tp.groupnorm(x, wd[p + ".norm1.weight"], wd[p + ".norm1.bias"], a, B=B, HW=H * W, C=Cin, G=groups,
-                         eps=eps, act=L.ACT_SILU, name=p + ".norm1")
+        a = self.tmp("gn_a", B, H, W, Cin)
+        tp.groupnorm(x, wd[p + ".norm1.weight"], wd[p + ".norm1.bias"], a, B=B, HW=H * W, C=Cin, G=groups,
+                     eps=eps, act=L.ACT_SILU, name=p + ".norm1")
         tp.conv(a, wd[p + ".conv1.weight"], wd[p + ".conv1.bias"], h, B=B, IH=H, IW=W, Cin=Cin, OH=H, OW=W, N=Cout,
                 KH=3, KW=3, pad_h=1, pad_w=1, rowvec=self.temb_all[:, off:off + Cout], ld_rv=self.temb_total,
-                name=p + ".conv1", **kw1)
-        if fuse:
-            ab2 = self.tmp("gn_ab2", B, 2, Cout)
-            tp.gn_scale_shift(h, wd[p + ".norm2.weight"], wd[p + ".norm2.bias"], ab2, B=B, HW=H * W, C=Cout,
-                              G=groups, eps=eps, name=p + ".norm2")
-            a2, kw2 = h, dict(gn_ab=ab2, gn_act=1)
-        else:
-            a2, kw2 = self.tmp("gn_a2", B, H, W, Cout), {}
-            tp.groupnorm(h, wd[p + ".norm2.weight"], wd[p + ".norm2.bias"], a2, B=B, HW=H * W, C=Cout, G=groups,
-                         eps=eps, act=L.ACT_SILU, name=p + ".norm2")
+                name=p + ".conv1")
+        a2 = self.tmp("gn_a2", B, H, W, Cout)
+        tp.groupnorm(h, wd[p + ".norm2.weight"], wd[p + ".norm2.bias"], a2, B=B, HW=H * W, C=Cout, G=groups,
+                     eps=eps, act=L.ACT_SILU, name=p + ".norm2")
         res = x
         if (p + ".conv_shortcut.weight") in wd:
             res = self.tmp("res_sc", B, H, W, Cout)
             tp.conv(x, wd[p + ".conv_shortcut.weight"], wd[p + ".conv_shortcut.bias"], res, B=B, IH=H, IW=W, Cin=Cin,
                     OH=H, OW=W, N=Cout, name=p + ".conv_shortcut")
         tp.conv(a2, wd[p + ".conv2.weight"], wd[p + ".conv2.bias"], dest, B=B, IH=H, IW=W, Cin=Cout, OH=H, OW=W,
-                N=Cout, KH=3, KW=3, pad_h=1, pad_w=1, res=res, name=p + ".conv2", **kw2)
+                N=Cout, KH=3, KW=3, pad_h=1, pad_w=1, res=res, name=p + ".conv2")
         return dest
-
-    def _can_fuse_gn(self, HW, C):
-        return self.fuse_gn and HW % 32 == 0 and C % 32 == 0 and C <= 1280
 
     def _ln_linear(self, x, pfx, plain_w, plain_b, out, M, K, N, ln, name):
         """Linear on LayerNorm(x).  Fused: raw x + gamma-folded weights + row statistics gathered inside the
@@ -196,17 +178,10 @@ class UNetEngine:
         N = H * W
         M = B * N
         t0 = self.tmp("t_0", M, C)
-        if self._can_fuse_gn(N, C):
-            ab = self.tmp("gn_ab", B, 2, C)
-            tp.gn_scale_shift(x, wd[p + ".norm.weight"], wd[p + ".norm.bias"], ab, B=B, HW=N, C=C, G=groups, eps=1e-6,
-                              name=p + ".norm")
-            tp.conv(x, wd[p + ".proj_in.weight"], wd[p + ".proj_in.bias"], t0, B=B, IH=N, IW=1, Cin=C, OH=N, OW=1, N=C,
-                    gn_ab=ab, gn_act=0, name=p + ".proj_in")
-        else:
-            n = self.tmp("t_n", M, C)
-            tp.groupnorm(x, wd[p + ".norm.weight"], wd[p + ".norm.bias"], n, B=B, HW=N, C=C, G=groups, eps=1e-6,
-                         name=p + ".norm")
-            tp.linear(n, wd[p + ".proj_in.weight"], wd[p + ".proj_in.bias"], t0, M=M, K=C, N=C, name=p + ".proj_in")
+        n = self.tmp("t_n", M, C)
+        tp.groupnorm(x, wd[p + ".norm.weight"], wd[p + ".norm.bias"], n, B=B, HW=N, C=C, G=groups, eps=1e-6,
+                     name=p + ".norm")
+        tp.linear(n, wd[p + ".proj_in.weight"], wd[p + ".proj_in.bias"], t0, M=M, K=C, N=C, name=p + ".proj_in")
         b = p + ".transformer_blocks.0"
         ln = self.tmp("t_l", M, C)
         o = self.tmp("t_o", M, C)
@@ -385,17 +360,11 @@ class UNetEngine:
 
         # ---- out
         self.eps = tp.alloc(B, hh, ww, cout)
-        if self._can_fuse_gn(hh * ww, ch) and (hh * ww) % 128 == 0:
-            ab = self.tmp("gn_ab", B, 2, ch)
-            tp.gn_scale_shift(h, wd["conv_norm_out.weight"], wd["conv_norm_out.bias"], ab, B=B, HW=hh * ww, C=ch,
-                              G=groups, eps=eps, name="conv_norm_out")
-            a, kwo = h, dict(gn_ab=ab, gn_act=1)
-        else:
-            a, kwo = self.tmp("gn_a", B, hh, ww, ch), {}
-            tp.groupnorm(h, wd["conv_norm_out.weight"], wd["conv_norm_out.bias"], a, B=B, HW=hh * ww, C=ch, G=groups,
-                         eps=eps, act=L.ACT_SILU, name="conv_norm_out")
+        a = self.tmp("gn_a", B, hh, ww, ch)
+        tp.groupnorm(h, wd["conv_norm_out.weight"], wd["conv_norm_out.bias"], a, B=B, HW=hh * ww, C=ch, G=groups,
+                     eps=eps, act=L.ACT_SILU, name="conv_norm_out")
         tp.conv(a, wd["conv_out.weight"], wd["conv_out.bias"], self.eps, B=B, IH=hh, IW=ww, Cin=ch, OH=hh, OW=ww,
-                N=cout, KH=3, KW=3, pad_h=1, pad_w=1, name="conv_out", **kwo)
+                N=cout, KH=3, KW=3, pad_h=1, pad_w=1, name="conv_out")
         tp.finalize()
         self.ctx_tape.finalize()
 

@@ -182,8 +182,8 @@ def main():
             calls = {2: args.tstart + (args.T if args.schedule == "sequential" else 0)}
             if args.schedule == "batched":
                 calls[2 * args.group] = calls.get(2 * args.group, 0) + args.T // args.group
-            if B not in calls or not calls[B]:
-                continue
+            if B not in calls or not calls[B] or f"unet_batch_{B}" in detail:
+                continue        # one engine per batch size (context lengths differ, launch shapes do not)
             with torch.inference_mode():
                 ed.state.zero_()        # the time-embedding op indexes the timestep table with the loop counter
             torch.cuda.synchronize()

@@ -57,7 +57,7 @@ enum aed_opcode {
     AED_OP_NCHW_TO_NHWC = 18, /* boundary layout change                                        */
     AED_OP_NHWC_TO_NCHW = 19,
     AED_OP_SPLITK_REDUCE = 20,
-    AED_OP_GN_SCALE_SHIFT = 21, /* GroupNorm stats -> per-channel (scale, shift) for the fused conv loader   */
+    AED_OP_GN_SCALE_SHIFT = 21, /* GroupNorm stats -> per-(batch,channel) scale/shift vectors [B,2,C]         */
     AED_OP_GN_SMALL = 22,     /* single-launch GroupNorm(+SiLU) for small feature maps (K4)       */
     AED_OP_COUNT
 };

@@ -56,29 +56,6 @@ def test_tiny_unet_matches_oracle(kind, use_ehs):
     assert (got - ref).abs().max().item() < 2e-4 * max(1.0, scale), ((got - ref).abs().max().item(), scale)
 
 
-def test_fused_groupnorm_variant_matches_oracle():
-    """The GroupNorm-in-loader path (off by default, see unet.UNetEngine) stays parity-green."""
-    fam = configs.tiny_family("audioldm2")
-    cfg = fam["unet"]
-    sd = weights.random_state_dict(weights.unet_param_shapes(cfg), seed=3)
-    g = torch.Generator().manual_seed(4)
-    x = torch.randn(2, 8, 64, 16, generator=g)
-    e0, e1 = torch.randn(2, 8, 48, generator=g), torch.randn(2, 5, 64, generator=g)
-    outs = []
-    for fg in (True, False):
-        eng = UNetEngine(cfg, sd, DEV, 2, 64, 16, ctx_len0=8, ctx_len1=5, fuse_gn=fg)
-        eng.set_conditioning(ehs0=e0, ehs1=e1, bias1=torch.zeros(2, 5))
-        eng.x_in.copy_(x.permute(0, 2, 3, 1))
-        eng.set_timestep(301)
-        eng.forward()
-        torch.cuda.synchronize()
-        outs.append(eng.eps.cpu().permute(0, 3, 1, 2))
-    ref, _, _ = ounet.unet_forward(cfg, sd, x, torch.tensor(301), encoder_hidden_states=e0,
-                                   encoder_hidden_states_1=e1, encoder_attention_mask_1=torch.ones(2, 5))
-    for o in outs:
-        assert (o - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item())
-
-
 def test_full_audioldm2_unet_matches_oracle():
     """BASELINE config 2 shape: AudioLDM2 U-Net, latent 8x256x16, cond+uncond batched (B=2)."""
     fam = configs.FAMILIES["audioldm2"]

@@ -94,8 +94,21 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 1) void conv_gemm
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wr = wave / WCOLS, wc = wave % WCOLS;
-    const int m0 = blockIdx.y * BM;
-    const int n0 = blockIdx.x * BN;
+    // XCD-aware tile order.  The dispatcher places workgroup b on XCD b % 8 (observed; a speed assumption only), and
+    // each XCD has its own L2: with the plain order the N-tiles that share an A row panel land on 8 different L2s and
+    // the panel is fetched 8 times (rocprofv3 FETCH_SIZE: 4-8x the algorithmic bytes, profiles/r01b_pmc_forward_B40.md).
+    // Bijective remap (any grid size): XCD x gets a contiguous range of tile ids, n fastest.
+    int tile_x = blockIdx.x, tile_y = blockIdx.y;
+    if (gridDim.z == 1) {
+        const unsigned nx = gridDim.x, nwg = nx * gridDim.y;
+        const unsigned orig = blockIdx.y * nx + blockIdx.x;
+        const unsigned xcd = orig & 7u, q = nwg >> 3, r = nwg & 7u;
+        const unsigned id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+        tile_y = (int)(id / nx);
+        tile_x = (int)(id - (unsigned)tile_y * nx);
+    }
+    const int m0 = tile_y * BM;
+    const int n0 = tile_x * BN;
     const bool dbg_on = p.dbg && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
     int dbg_n = 0;
 #define STAMP() do { if (dbg_on && dbg_n < 30) p.dbg[dbg_n++] = __builtin_amdgcn_s_memtime(); } while (0)

@@ -201,8 +201,19 @@ def main():
                                              conv_gemm_tflops=fl / (tt * 1e-3) / 1e12, forward_ms=sum(ms),
                                              algorithmic_gflop=eng.tape.flops / 1e9)
         achieved = tot_fl / (tot_ms * 1e-3) / 1e12
+        # HBM-side traffic per conv_gemm launch comes from the committed rocprofv3 --pmc passes (counter passes
+        # serialise every dispatch and cannot run inside a timed bench); null when the summary is absent
+        traffic = traffic_note = None
+        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01b_pmc_forward_B40.json")
+        if os.path.exists(pmc_path):
+            with open(pmc_path) as f:
+                pmc = json.load(f)
+            traffic = pmc["measured_bytes_per_launch"]
+            traffic_note = (f"bytes per launch, {pmc['counters']}; {pmc['kernel']}; algorithmic "
+                            f"{pmc['algorithmic_bytes_per_launch']:.3g} B per launch; {pmc['source']} ({pmc['binary']})")
         roof = dict(bound="mfma", achieved=achieved, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
-                    frac=achieved / PEAK_FP32_MFMA_TFLOPS, traffic=None, kernel="conv_gemm_kernel (+wsk variant)",
+                    frac=achieved / PEAK_FP32_MFMA_TFLOPS, traffic=traffic, traffic_note=traffic_note,
+                    kernel="conv_gemm_kernel (+wsk variant)",
                     launches_per_clip=n_launch, avg_launch_us=1e3 * tot_ms / n_launch, by_batch=detail,
                     clip_unet_tflop=per_clip_flops / 1e12,
                     unet_loop_tflops=per_clip_flops / (dt / args.steps) / 1e12,

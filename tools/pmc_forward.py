@@ -1,0 +1,24 @@
+#!/usr/bin/env python
+"""One AudioLDM2 U-Net forward at the two batch shapes of the bench (2*G and 2), for rocprofv3 --pmc passes:
+    rocprofv3 --pmc FETCH_SIZE -d out -o f --output-format csv -- python tools/pmc_forward.py 40 2
+Counter passes serialise every dispatch (~10 ms each), so this runs exactly one forward per batch size."""
+import sys
+
+import torch
+
+from audioeditingcode_amd import configs, weights
+from audioeditingcode_amd.unet import PackedUNetWeights, UNetEngine
+
+fam = configs.FAMILIES["audioldm2"]
+sd = weights.random_state_dict(weights.unet_param_shapes(fam["unet"]), seed=0)
+pw = PackedUNetWeights(sd, "cuda:0")
+g = torch.Generator().manual_seed(1)
+for B in [int(a) for a in sys.argv[1:]] or [40, 2]:
+    eng = UNetEngine(fam["unet"], pw, "cuda:0", B, 256, 16, ctx_len0=8, ctx_len1=16)
+    eng.set_conditioning(ehs0=torch.randn(B, 8, 768, generator=g), ehs1=torch.randn(B, 16, 1024, generator=g),
+                         bias1=torch.zeros(B, 16))
+    eng.x_in.copy_(torch.randn(B, 256, 16, 8, generator=g))
+    eng.set_timestep(500)
+    eng.forward()
+    torch.cuda.synchronize()
+    print("forward done", B, flush=True)

@@ -8,7 +8,7 @@ torchvision, torchaudio, librosa, wandb, soundfile, progressbar); name-only stub
 modules are injected exactly as SURVEY.md 8(c)/Appendix B describes.  What each
 fixture pins is listed in tests/golden/README.md.
 
-Usage:  python oracle/make_golden.py [loops|audio|hifigan|unet|vae|all]
+Usage:  python oracle/make_golden.py [loops|pc|pc_cli|audio|hifigan|unet|vae|all]
 """
 import importlib.util
 import os
@@ -228,6 +228,119 @@ def gen_pc():
     print("pc", float(np.abs(rec["eigval3"]).max()), tuple(drift.shape))
 
 
+
+# --------------------------------------------------------------------------- PC extract / apply CLIs
+def gen_pc_cli():
+    """Run the reference's OWN scripts main_pc_extract_inv.py and main_pc_apply_drift.py end to end with a synthetic
+    eps-model (load_model / load_audio / plotting / wandb / torchaudio replaced by stand-ins; the one line that
+    names the device, f"cuda:{args.device_num}", is replaced by "cpu" in memory before exec -- nothing is stored)."""
+    import glob
+    import tempfile
+    from unittest import mock
+    UOut = install_stubs()
+    sys.modules["wandb"] = mock.MagicMock()
+    sys.modules["torchaudio"] = mock.MagicMock()
+    sys.path.insert(0, REF)
+    import models as ref_models
+    import utils as ref_utils
+
+    class FakeRef(ref_models.PipelineWrapper):
+        get_variance = ref_models.AudioLDM2Wrapper.get_variance
+        get_alpha_prod_t_prev = ref_models.AudioLDM2Wrapper.get_alpha_prod_t_prev
+
+        def __init__(self, T):
+            super().__init__(model_id="fake", device=torch.device("cpu"))
+            sched = OracleDDIMScheduler()
+            sched.set_timesteps(T)
+            self.model = SimpleNamespace(scheduler=sched, unet=SimpleNamespace(config=SimpleNamespace(in_channels=8)))
+
+        def encode_text(self, prompts, **kw):
+            return None, torch.stack([prompt_vec(p) for p in prompts]), None
+
+        def unet_forward(self, sample, timestep, encoder_hidden_states=None, class_labels=None,
+                         encoder_attention_mask=None, **kw):
+            return UOut(sample=synthetic_unet(sample, timestep, class_labels)), None, None
+
+        def get_fn_STFT(self):
+            return None
+
+        def vae_encode(self, x):
+            return x
+
+        def vae_decode(self, x):
+            return x
+
+        def decode_to_mel(self, x):
+            return torch.zeros(len(x), 16)
+
+    T = 12
+    g = torch.Generator().manual_seed(33)
+    w0 = torch.randn((1, 8, 16, 16), generator=g) * 0.7
+    ref_models.load_model = lambda *a, **k: FakeRef(T)
+    ref_utils.load_audio = lambda *a, **k: w0.clone()
+    ref_utils.plot_corrs = lambda *a, **k: None
+    real_load = torch.load
+
+    def run_script(name, argv):
+        src = open(os.path.join(REF, name)).read()
+        assert 'f"cuda:{args.device_num}"' in src
+        src = src.replace('f"cuda:{args.device_num}"', '"cpu"')
+        glb = {"__name__": "__main__", "__file__": os.path.join(REF, name)}
+        old_argv = sys.argv
+        sys.argv = [name] + argv
+        try:
+            with mock.patch("torch.cuda.set_device"), mock.patch("torch.cuda.empty_cache"), \
+                    mock.patch("torch.load", lambda f, *a, **k: real_load(f, map_location="cpu", weights_only=False)), \
+                    mock.patch("matplotlib.pyplot.imsave"), mock.patch("torch.use_deterministic_algorithms"):
+                exec(compile(src, name, "exec"), glb)
+        finally:
+            sys.argv = old_argv
+        return glb
+
+    rec = {"w0": w0.numpy(), "T": T}
+    with tempfile.TemporaryDirectory() as tmp:
+        for tag, swap in (("a", "0.8"), ("b", "-2.0")):        # b: corr <= 2 always -> every PC sign is flipped
+            out_dir = os.path.join(tmp, tag)
+            run_script("main_pc_extract_inv.py",
+                       ["--init_aud", "synth.wav", "--num_diffusion_steps", str(T), "--source_prompt", "a dog barking",
+                        "--drift_start", "8", "--drift_end", "4", "--n_evs", "2", "--iters", "4", "-s", "5",
+                        "--patch", "2", "12", "--corr_to_swap", swap, "--results_path", out_dir, "--wandb_disable"])
+            pts = glob.glob(os.path.join(out_dir, "**", "*.pt"), recursive=True)
+            assert len(pts) == 1, pts
+            ck = real_load(pts[0], map_location="cpu", weights_only=False)
+            ts = sorted(ck["eigdata"].keys(), reverse=True)
+            rec[f"{tag}_ts"] = np.array(ts)
+            rec[f"{tag}_eigvec"] = np.stack([ck["eigdata"][t]["eigvec"].numpy() for t in ts])
+            rec[f"{tag}_eigval"] = np.stack([ck["eigdata"][t]["eigval"].numpy() for t in ts])
+            rec[f"{tag}_it"] = np.array([ck["eigdata"][t]["it"] for t in ts])
+            rec[f"{tag}_norm_factor"] = np.array([float(ck["eigdata"][t]["norm_factor"]) for t in ts])
+            rec[f"{tag}_corrs"] = np.stack([c.numpy() for c in ck["corrs"]])
+            rec[f"{tag}_xts"] = np.concatenate([x.numpy() for x in ck["xts"]])
+            rec[f"{tag}_latents"] = np.concatenate([x.numpy() for x in ck["latents"]])
+            if tag == "a":
+                keys = sorted(ck.keys())
+                rec["ckpt_keys"] = np.array(keys)
+                rec["eigdata_keys"] = np.array(sorted(ck["eigdata"][ts[0]].keys()))
+                rec["args_fields"] = np.array(sorted(vars(ck["args"]).keys()))
+                evals = {t: ck["eigdata"][t]["eigval"].numpy() for t in ts}
+                ev_path = os.path.join(tmp, "eigvals.pt")
+                torch.save(evals, ev_path)
+                # the reference's apply script reads extraction_args.target_prompt, which its extractor never writes
+                ck["args"].target_prompt = ck["args"].source_prompt
+                torch.save(ck, pts[0])
+                base = ["--extraction_path", pts[0], "--drift_start", "8", "--drift_end", "4", "--amount", "2.0",
+                        "--evals_pt", ev_path, "-s", "9", "--wandb_disable"]
+                glb = run_script("main_pc_apply_drift.py", base + ["--evs", "1", "2"])
+                rec["apply_sep"] = glb["xt"].detach().numpy()
+                glb = run_script("main_pc_apply_drift.py", base + ["--evs", "1"])
+                rec["apply_single"] = glb["xt"].detach().numpy()
+                glb = run_script("main_pc_apply_drift.py", base + ["--evs", "1", "2", "--combine_evs", "--fix_alpha", "0.3",
+                                                                  "--fade_length", "2.0"])
+                rec["apply_comb_fix"] = glb["xt"].detach().numpy()
+    np.savez_compressed(os.path.join(OUT, "pc_cli.npz"), **rec)
+    print("pc_cli", rec["a_ts"], rec["a_eigval"][0], rec["apply_sep"].shape, rec["apply_comb_fix"].shape)
+
+
 # --------------------------------------------------------------------------- audio
 def _load_by_path(modname, path):
     spec = importlib.util.spec_from_file_location(modname, path)
@@ -403,7 +516,7 @@ if __name__ == "__main__":
     # each generator runs in a fresh interpreter when "all" (the stubs of one break another)
     if what == "all":
         import subprocess
-        for w in ("loops", "pc", "audio", "hifigan", "unet", "vae"):
+        for w in ("loops", "pc", "pc_cli", "audio", "hifigan", "unet", "vae"):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), w])
     else:
-        {"loops": gen_loops, "pc": gen_pc, "audio": gen_audio, "hifigan": gen_hifigan, "unet": gen_unet, "vae": gen_vae}[what]()
+        {"loops": gen_loops, "pc": gen_pc, "pc_cli": gen_pc_cli, "audio": gen_audio, "hifigan": gen_hifigan, "unet": gen_unet, "vae": gen_vae}[what]()

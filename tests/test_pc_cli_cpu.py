@@ -1,0 +1,205 @@
+"""the host loops of main_pc_extract_inv / main_pc_apply_drift against fixtures produced by the
+reference's OWN scripts (tests/golden/pc_cli.npz, oracle/make_golden.py pc_cli).
+
+No GPU: the loops are host orchestration over the wrapper API, so they are driven here with a stub wrapper (the
+oracle's synthetic eps-model) and oracle implementations of the per-step functions -- the test double, not the
+product.  What is checked is the product's control flow: drift window, PC sign continuity, checkpoint layout,
+per-PC batching, fix_alpha mask / fades, evals override; `apply_drift` itself
+is the product's (pc_drift.apply_drift is device-agnostic torch math)."""
+import os
+from argparse import Namespace
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from audioeditingcode_amd import main_pc_apply_drift as papply
+from audioeditingcode_amd import main_pc_extract_inv as pext
+from audioeditingcode_amd import pc_drift as ppc
+from oracle import loops as oloops
+from oracle import pc as opc
+from oracle.scheduler import OracleDDIMScheduler
+from oracle.synth import prompt_vec, synthetic_unet
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _stub_wrapper(T):
+    s = OracleDDIMScheduler()
+    s.set_timesteps(T)
+    return oloops.OracleWrapper(s, synthetic_unet)
+
+
+def _fns():
+    """The reference-API callables the loops take, implemented on the oracle (CPU)."""
+    def get_text_embeddings(tp, tn, w):
+        cond = lambda ps: torch.stack([prompt_vec(str(p)) for p in ps])      # noqa: E731
+        return None, cond(tp), cond(tn)
+
+    def inversion_forward_process(w, x0, etas=None, prompts=None, cfg_scales=None, prog_bar=False,
+                                  num_inference_steps=50, numerical_fix=False):
+        cond_src = torch.stack([prompt_vec(str(p)) for p in prompts])
+        xt, zs, xts = oloops.invert(w, x0, cond_src, torch.stack([prompt_vec("")]), cfg_scales, num_inference_steps,
+                                    eta=etas, numerical_fix=numerical_fix)
+        return xt, zs, xts, None
+
+    def forward_directional(w, xt, t, latent, uncond, text, cfg_tar, eta=1, double_precision=False):
+        return opc.forward_directional(w, xt, t, latent, uncond, text, cfg_tar, eta=eta)
+
+    def get_eigenvectors(w, xt, text, uncond, latent, mask, t, x0_pred, pc_mode, const, cfg_tar, iters, dp, eta, n_ev):
+        init = torch.randn_like(xt.repeat(n_ev, 1, 1, 1))       # the reference's randn_like(expanded xt) draw
+        ev, val, in_corr, in_norm = opc.get_eigenvectors(w, xt, text, uncond, latent, mask, t, x0_pred, init,
+                                                         const=const, cfg_tar=cfg_tar, iters=iters, eta=eta, n_ev=n_ev)
+        return ev, val, in_corr, in_norm, {}, {}
+
+    return SimpleNamespace(get_text_embeddings=get_text_embeddings, inversion_forward_process=inversion_forward_process,
+                           forward_directional=forward_directional, get_eigenvectors=get_eigenvectors,
+                           apply_drift=ppc.apply_drift, PCStreamChoice=ppc.PCStreamChoice)
+
+
+def _extract_args(T, corr_to_swap):
+    a = Namespace(seed=5, cfg_tar=3, model_id="fake/fake", init_aud="synth.wav", num_diffusion_steps=T,
+                  source_prompt=["a dog barking"], target_neg_prompt=[""], corr_to_swap=corr_to_swap, drift_start=8,
+                  drift_end=4, results_path="unused", const=1e-3, n_evs=2, patch=[2, 12], iters=4, dry=False)
+    return pext.finish_args(a)
+
+
+def _run_extract(g, tag, corr_to_swap):
+    T = int(g["T"])
+    w = _stub_wrapper(T)
+    torch.manual_seed(5)                       # set_reproducability(args.seed) of the script
+    return w, pext.extract_pcs(w, torch.from_numpy(g["w0"]), _extract_args(T, corr_to_swap), fns=_fns())
+
+
+def test_extraction_loop_matches_reference_script():
+    g = np.load(os.path.join(G, "pc_cli.npz"))
+    for tag, swap in (("a", 0.8), ("b", -2.0)):
+        _, ck = _run_extract(g, tag, swap)
+        ts = sorted(ck["eigdata"].keys(), reverse=True)
+        assert ts == list(g[f"{tag}_ts"])                                   # drift window 8 -> 4 of T=12
+        assert [ck["eigdata"][t]["it"] for t in ts] == list(g[f"{tag}_it"])
+        np.testing.assert_allclose(np.concatenate([x.numpy() for x in ck["latents"]]), g[f"{tag}_latents"],
+                                   rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(np.concatenate([x.numpy() for x in ck["xts"]]), g[f"{tag}_xts"], rtol=1e-5,
+                                   atol=2e-6)
+        for i, t in enumerate(ts):
+            e = ck["eigdata"][t]
+            np.testing.assert_allclose(e["eigval"].numpy(), g[f"{tag}_eigval"][i], rtol=2e-3)
+            cos = (e["eigvec"].reshape(2, -1) * torch.from_numpy(g[f"{tag}_eigvec"][i]).reshape(2, -1)).sum(1)
+            assert (cos > 0.999).all(), (tag, t, cos)                       # sign included: the swap logic ran
+            np.testing.assert_allclose(float(e["norm_factor"]), g[f"{tag}_norm_factor"][i], rtol=1e-6)
+            assert e["ts"] == int(g["T"]) - e["it"]
+        np.testing.assert_allclose(torch.stack(ck["corrs"]).numpy(), g[f"{tag}_corrs"], atol=2e-3)
+    # case b flips every PC at every step after the first: its vectors are the negated/alternating ones of case a
+    assert not np.allclose(g["a_eigvec"][1], g["b_eigvec"][1])
+
+
+def test_checkpoint_layout_is_the_reference_layout(tmp_path):
+    g = np.load(os.path.join(G, "pc_cli.npz"))
+    _, ck = _run_extract(g, "a", 0.8)
+    path = str(tmp_path / "ext")
+    pext.save_extraction(ck, path)
+    back = torch.load(path + ".pt", map_location="cpu", weights_only=False)
+    assert sorted(back.keys()) == list(g["ckpt_keys"])
+    t0 = max(back["eigdata"].keys())
+    assert sorted(back["eigdata"][t0].keys()) == list(g["eigdata_keys"])
+    ours = set(vars(back["args"]).keys())
+    missing = set(g["args_fields"]) - ours - {"wandb_name", "wandb_group", "wandb_disable", "image_name_png", "device_num"}
+    assert not missing, missing                  # every field the reference's apply script may read is recorded
+
+
+def _apply(g, ck, w, **over):
+    T = int(g["T"])
+    evals = {int(t): ck["eigdata"][int(t)]["eigval"].numpy() for t in ck["eigdata"]}
+    a = Namespace(drift_start=8, drift_end=4, amount=2.0, use_specific_ts_pc=None, fix_alpha=None, fade_length=0.0,
+                  evs=[1], combine_evs=False, evals_pt=evals, rand_v=False, shift_x0_for_np=True, sub_iters=None)
+    for k, v in over.items():
+        setattr(a, k, v)
+    load = {k: ck[k] for k in ("eigdata", "args", "corrs", "in_corrs", "latents", "in_norms", "xts")}
+    return papply.apply_pcs(w, load, a, torch.device("cpu"), fns=_fns())
+
+
+def test_apply_loop_matches_reference_script():
+    g = np.load(os.path.join(G, "pc_cli.npz"))
+    w, ck = _run_extract(g, "a", 0.8)
+    # feed the reference's own extraction so that only the apply loop is under test
+    ts = list(g["a_ts"])
+    for i, t in enumerate(ts):
+        ck["eigdata"][int(t)]["eigvec"] = torch.from_numpy(g["a_eigvec"][i])
+        ck["eigdata"][int(t)]["eigval"] = torch.from_numpy(g["a_eigval"][i])
+    ck["latents"] = [torch.from_numpy(x)[None] for x in g["a_latents"]]
+    ck["xts"] = [torch.from_numpy(x)[None] for x in g["a_xts"]]
+    out = _apply(g, ck, w, evs=[1, 2])
+    np.testing.assert_allclose(out.numpy(), g["apply_sep"], rtol=1e-4, atol=2e-5)
+    out = _apply(g, ck, w, evs=[1])              # batch stays 1 on every step
+    np.testing.assert_allclose(out.numpy(), g["apply_single"], rtol=1e-4, atol=2e-5)
+    out = _apply(g, ck, w, evs=[1, 2], combine_evs=True, fix_alpha=0.3, fade_length=2.0)
+    np.testing.assert_allclose(out.numpy(), g["apply_comb_fix"], rtol=1e-4, atol=2e-5)
+
+
+def test_drift_mask_fades():
+    m = papply.drift_mask(torch.zeros(1, 2, 16, 4), [4, 10], 2)
+    col = m[0, 0, :, 0]
+    assert col[:2].eq(0).all() and col[4:10].eq(1).all() and col[12:].eq(0).all()
+    np.testing.assert_allclose(col[2:4].numpy(), [0.0, 1.0])
+    np.testing.assert_allclose(col[10:12].numpy(), [1.0, 0.0])
+    assert papply.drift_mask(torch.zeros(1, 2, 16, 4), None, 0).eq(1).all()
+
+
+class _DoubleWrapper:
+    """Stand-in for the native wrapper: same members pc_drift / the loops touch, U-Net pair = synthetic eps-model.
+    Everything else on the path under test is PRODUCT code: pc_drift.{forward_directional,get_eigenvectors,
+    apply_drift}, scheduler.DDIMScheduler.step, utils.get_text_embeddings, the two host loops."""
+    kind = "audioldm"
+
+    def __init__(self, T):
+        from audioeditingcode_amd.scheduler import DDIMScheduler
+        s = DDIMScheduler()
+        s.set_timesteps(T)
+        self.model = SimpleNamespace(scheduler=s)
+        self.device = torch.device("cpu")
+
+    def encode_text(self, prompts, **kw):
+        return None, torch.stack([prompt_vec(str(p)) for p in prompts]), None
+
+    def get_sigma(self, t):
+        return torch.sqrt(1.0 / self.model.scheduler.alphas_cumprod - 1)[t]
+
+    def unet_forward_pair(self, x_u, x_c, t, cond_u, cond_c):
+        return synthetic_unet(x_u, t, cond_u.class_labels), synthetic_unet(x_c, t, cond_c.class_labels)
+
+
+def test_product_pc_functions_and_loops_reproduce_reference_scripts():
+    """extract -> save -> load -> apply with the product's own pc_drift functions, scheduler and loops; only the U-Net
+    pair (stand-in above) and the inversion (oracle loop on the same tables) are doubles."""
+    g = np.load(os.path.join(G, "pc_cli.npz"))
+    T = int(g["T"])
+    w = _DoubleWrapper(T)
+    ow = _stub_wrapper(T)
+    if not np.array_equal(ow.model.scheduler.alphas_cumprod.numpy(), w.model.scheduler.alphas_cumprod.numpy()):
+        ow.model.scheduler.alphas_cumprod = w.model.scheduler.alphas_cumprod.clone()
+    fns = pext._default_fns()
+    fns.inversion_forward_process = lambda m, x0, **kw: _fns().inversion_forward_process(ow, x0, **kw)
+    torch.manual_seed(5)
+    ck = pext.extract_pcs(w, torch.from_numpy(g["w0"]), _extract_args(T, 0.8), fns=fns)
+    ts = list(g["a_ts"])
+    assert sorted(ck["eigdata"].keys(), reverse=True) == ts
+    np.testing.assert_allclose(np.concatenate([x.numpy() for x in ck["xts"]]), g["a_xts"], rtol=1e-5, atol=2e-6)
+    for i, t in enumerate(ts):
+        e = ck["eigdata"][int(t)]
+        np.testing.assert_allclose(e["eigval"].numpy(), g["a_eigval"][i], rtol=2e-3)
+        cos = (e["eigvec"].reshape(2, -1) * torch.from_numpy(g["a_eigvec"][i]).reshape(2, -1)).sum(1)
+        assert (cos > 0.999).all(), (t, cos)
+    afns = papply._default_fns()
+    evals = {int(t): g["a_eigval"][i] for i, t in enumerate(ts)}
+    for i, t in enumerate(ts):                      # reference extraction in, so only the apply path is compared
+        ck["eigdata"][int(t)]["eigvec"] = torch.from_numpy(g["a_eigvec"][i])
+        ck["eigdata"][int(t)]["eigval"] = torch.from_numpy(g["a_eigval"][i])
+    a = Namespace(drift_start=8, drift_end=4, amount=2.0, use_specific_ts_pc=None, fix_alpha=None, fade_length=0.0,
+                  evs=[1, 2], combine_evs=False, evals_pt=evals, rand_v=False, shift_x0_for_np=True, sub_iters=None)
+    load = {k: ck[k] for k in ("eigdata", "args", "corrs", "in_corrs", "latents", "in_norms", "xts")}
+    out = papply.apply_pcs(w, load, a, torch.device("cpu"), fns=afns)
+    np.testing.assert_allclose(out.numpy(), g["apply_sep"], rtol=1e-4, atol=3e-5)
+    a.evs, a.combine_evs, a.fix_alpha, a.fade_length = [1, 2], True, 0.3, 2.0
+    out = papply.apply_pcs(w, load, a, torch.device("cpu"), fns=afns)
+    np.testing.assert_allclose(out.numpy(), g["apply_comb_fix"], rtol=1e-4, atol=3e-5)

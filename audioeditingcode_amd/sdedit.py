@@ -25,7 +25,10 @@ def sdedit(ldm_stable, w0: torch.Tensor, target_prompt: List[str], target_neg_pr
     ts = sched.timesteps[skip:]
     Z = len(ts)
     if latents is None:
-        latents = [torch.randn(w0.shape) * sched.init_noise_sigma for _ in range(Z)]
+        # the reference's draw order (main_run_sdedit.py:79-92): one latent per scheduler timestep plus one, sliced
+        # to the remaining steps, THEN the add_noise draw -- on the CPU generator like every draw of this path
+        T = len(sched.timesteps)
+        latents = [torch.randn(w0.shape) * sched.init_noise_sigma for _ in range(T + 1)][skip + 1:]
     if noise is None:
         noise = torch.randn(w0.shape)
     xt = sched.add_noise(w0.to(ldm_stable.device), noise.to(ldm_stable.device), ts[:1].unsqueeze(0))

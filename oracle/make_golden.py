@@ -252,7 +252,9 @@ def gen_pc_cli():
             super().__init__(model_id="fake", device=torch.device("cpu"))
             sched = OracleDDIMScheduler()
             sched.set_timesteps(T)
-            self.model = SimpleNamespace(scheduler=sched, unet=SimpleNamespace(config=SimpleNamespace(in_channels=8)))
+            self.model = SimpleNamespace(scheduler=sched, unet=SimpleNamespace(config=SimpleNamespace(in_channels=8)),
+                                         vocoder=SimpleNamespace(config=SimpleNamespace(model_in_dim=64)),
+                                         vae_scale_factor=4)
 
         def encode_text(self, prompts, **kw):
             return None, torch.stack([prompt_vec(p) for p in prompts]), None
@@ -337,6 +339,13 @@ def gen_pc_cli():
                 glb = run_script("main_pc_apply_drift.py", base + ["--evs", "1", "2", "--combine_evs", "--fix_alpha", "0.3",
                                                                   "--fade_length", "2.0"])
                 rec["apply_comb_fix"] = glb["xt"].detach().numpy()
+        # SDEdit baseline script on the same synthetic model
+        glb = run_script("main_run_sdedit.py",
+                         ["--init_aud", "synth.wav", "--num_diffusion_steps", str(T), "--target_prompt", "a cat meowing",
+                          "--tstart", "7", "--cfg_tar", "5", "-s", "11", "--results_path", os.path.join(tmp, "sd"),
+                          "--wandb_disable"])
+        rec["sdedit_xt"] = glb["xt"].detach().numpy()
+        rec["sdedit_tstart"] = 7
     np.savez_compressed(os.path.join(OUT, "pc_cli.npz"), **rec)
     print("pc_cli", rec["a_ts"], rec["a_eigval"][0], rec["apply_sep"].shape, rec["apply_comb_fix"].shape)
 

@@ -83,3 +83,19 @@ def apply_drift(w, xt_m1, x0_pred, t, eigvec, eigval, latent, amount=1.0, eta=1.
     if eta > 0:
         xt_m1 = xt_m1 + std * latent
     return xt_m1
+
+
+def sdedit_loop(w, w0, cond_text, cond_uncond, cfg_tar, skip, eta=1.0):
+    """SDEdit baseline (main_run_sdedit.py:78-100): draws len(timesteps)+1 latents, THEN the add_noise noise, from the
+    global torch RNG in the reference's order; noises w0 to timesteps[skip] and samples down with
+    forward_directional."""
+    s = w.model.scheduler
+    ts = s.timesteps
+    latents = [torch.randn(w0.shape, dtype=w0.dtype) * s.init_noise_sigma for _ in range(len(ts) + 1)]
+    ts = ts[skip:]
+    latents = latents[skip + 1:]
+    noise = torch.randn_like(w0)
+    xt = s.add_noise(w0, noise, ts[:1].unsqueeze(0))
+    for it, t in enumerate(ts):
+        xt, _ = forward_directional(w, xt, t, latents[it], cond_uncond, cond_text, cfg_tar, eta=eta)
+    return xt

@@ -142,3 +142,9 @@ def test_arbitrary_clip_length_end_to_end():
     _, zs_o, xts_o = oloops.invert(ow, w0, enc(["rain"]), enc([""]), [3.0], T, eta=1.0, xts=xts0)
     w_o = oloops.edit(ow, xts_o, torch.tensor([4]), enc(["jazz"]), enc([""]), [12.0], zs_o[:4], eta=1.0)
     assert rel(w_edit.cpu(), w_o) < 5e-3
+
+
+def test_graft_entry_smoke():
+    """The driver's smoke(): one tiny clip through the wrapper API, checked against the oracle."""
+    import __graft_entry__
+    __graft_entry__.smoke()

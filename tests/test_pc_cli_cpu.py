@@ -203,3 +203,16 @@ def test_product_pc_functions_and_loops_reproduce_reference_scripts():
     a.evs, a.combine_evs, a.fix_alpha, a.fade_length = [1, 2], True, 0.3, 2.0
     out = papply.apply_pcs(w, load, a, torch.device("cpu"), fns=afns)
     np.testing.assert_allclose(out.numpy(), g["apply_comb_fix"], rtol=1e-4, atol=3e-5)
+
+
+def test_sdedit_oracle_loop_matches_reference_script():
+    """SURVEY 8f row 3: the oracle's SDEdit loop (the checker of tests/test_gpu_pc.py::test_sdedit_*) against the
+    reference's own main_run_sdedit.py, incl. the order of the RNG draws."""
+    g = np.load(os.path.join(G, "pc_cli.npz"))
+    T = int(g["T"])
+    w = _stub_wrapper(T)
+    cond = lambda ps: torch.stack([prompt_vec(str(p)) for p in ps])      # noqa: E731
+    torch.manual_seed(11)
+    xt = opc.sdedit_loop(w, torch.from_numpy(g["w0"]), cond(["a cat meowing"]), cond([""]), 5.0,
+                         skip=T - int(g["sdedit_tstart"]), eta=1.0)
+    np.testing.assert_allclose(xt.numpy(), g["sdedit_xt"], rtol=1e-5, atol=2e-6)

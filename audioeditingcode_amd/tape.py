@@ -21,6 +21,8 @@ CU_COUNT = 256          # MI355X; tiling heuristics target this, overridable for
 
 # A/B switch for the K-chunk width of conv_gemm: 0 auto, 1 force 32, 2 allow 64 on the 128x128 tile too
 FORCE_BK = int(os.environ.get("AED_FORCE_BK", "0"))
+# attention kernel variant (see Tape.attention); 0 = the measured default
+ATTN_VARIANT = int(os.environ.get("AED_ATTN_VARIANT", "0"))
 
 
 class Tape:
@@ -174,8 +176,11 @@ class Tape:
 
     # ------------------------------------------------------------------ attention & friends
     def attention(self, q, k, v, out, *, B, H, Nq, Nk, D, ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, scale,
-                  bias=None, ld_bias=0, name="attn"):
-        self._add(L.OP_ATTENTION, [B, H, Nq, Nk, D, ldq, ldk, ldv, ldo, ld_bias, bsq, bsk, bsv, bso], [scale],
+                  bias=None, ld_bias=0, variant=None, name="attn"):
+        """variant: 0 auto (split-KV kernel when Nk > 64), 1 single-pass kernel, 2 opt-in second-generation split-KV
+        kernel (batched/prefetched staging, DPP row reductions; default comes from AED_ATTN_VARIANT)."""
+        variant = ATTN_VARIANT if variant is None else variant
+        self._add(L.OP_ATTENTION, [B, H, Nq, Nk, D, ldq, ldk, ldv, ldo, ld_bias, bsq, bsk, bsv, bso, variant], [scale],
                   [q, k, v, bias, out], name=name, flops=4 * B * H * Nq * Nk * D,
                   nbytes=4 * B * H * D * (2 * Nq + 2 * Nk))
         return out

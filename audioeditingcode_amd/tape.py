@@ -23,6 +23,7 @@ CU_COUNT = 256          # MI355X; tiling heuristics target this, overridable for
 FORCE_BK = int(os.environ.get("AED_FORCE_BK", "0"))
 # attention kernel variant (see Tape.attention); 0 = the measured default
 ATTN_VARIANT = int(os.environ.get("AED_ATTN_VARIANT", "0"))
+GN_VARIANT = int(os.environ.get("AED_GN_VARIANT", "0"))          # single-launch GroupNorm kernel generation
 
 
 class Tape:
@@ -147,12 +148,14 @@ class Tape:
     TILE_BM = {1: 128, 2: 128, 3: 64, 4: 64, 5: 128, 6: 32, 7: 32}
 
     # ------------------------------------------------------------------ norms
-    def groupnorm(self, x, gamma, beta, out, *, B, HW, C, G=32, eps=1e-5, act=0, name="gn"):
+    def groupnorm(self, x, gamma, beta, out, *, B, HW, C, G=32, eps=1e-5, act=0, variant=None, name="gn"):
         ldx = x.stride(-2)
         ldy = out.stride(-2)
+        variant = GN_VARIANT if variant is None else variant
         if HW * (C // G) <= 65536 and B * G >= 32 and B * HW * C <= (1 << 22):
             # small map: one launch, one block per (group, batch item) -- latency, not bandwidth, is the cost
-            self._add(L.OP_GN_SMALL, [B, HW, C, G, ldx, ldy, act], [eps], [x, gamma, beta, out], name=name + ".gn1",
+            # (variant 1 = opt-in second-generation kernel with batched loads, see norm.hip)
+            self._add(L.OP_GN_SMALL, [B, HW, C, G, ldx, ldy, act, variant], [eps], [x, gamma, beta, out], name=name + ".gn1",
                       nbytes=12 * B * HW * C)
             return out
         # stats: <=32 coarse slabs per batch item (few partials to re-reduce);

@@ -2,11 +2,18 @@
 import math
 
 import numpy as np
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
+
+# Kernels written from the ISA of their predecessors after round 1's GPU budget was spent: they have never run on
+# hardware, so their tests only run on request (AED_EXPERIMENTAL=1) -- a device fault would take the whole session down.
+EXPERIMENTAL = pytest.mark.skipif(os.environ.get("AED_EXPERIMENTAL") != "1",
+                                  reason="unmeasured opt-in kernel: set AED_EXPERIMENTAL=1 to run")
 
 from audioeditingcode_amd import _lib as L          # noqa: E402
 from audioeditingcode_amd.tape import Tape          # noqa: E402
@@ -94,8 +101,7 @@ def test_groupnorm(C, G, HW, B, act):
     _groupnorm_case(C, G, HW, B, act, variant=0)
 
 
-@pytest.mark.xfail(strict=False, reason="opt-in second-generation single-launch GroupNorm (AED_GN_VARIANT=1): written from the "
-                   "first kernel's ISA after round 1's GPU budget was spent; its first hardware run is round 2")
+@EXPERIMENTAL          # opt-in second-generation single-launch GroupNorm (AED_GN_VARIANT=1)
 @pytest.mark.parametrize("C,G,HW,B,act", [(128, 32, 4096, 2, 1), (384, 32, 256, 2, 0), (640, 32, 64, 3, 1),
                                           (32, 8, 100, 2, 1), (256, 32, 1000, 2, 0)])
 def test_groupnorm_variant1(C, G, HW, B, act):
@@ -138,8 +144,7 @@ def test_attention(B, H, Nq, Nk, D, masked):
     _attention_case(B, H, Nq, Nk, D, masked, variant=0)
 
 
-@pytest.mark.xfail(strict=False, reason="opt-in second-generation split-KV attention kernel (AED_ATTN_VARIANT=2): written "
-                   "from the first kernel's ISA after round 1's GPU budget was spent; its first hardware run is round 2")
+@EXPERIMENTAL          # opt-in second-generation split-KV attention kernel (AED_ATTN_VARIANT=2)
 @pytest.mark.parametrize("B,H,Nq,Nk,D,masked", [(2, 8, 1024, 1024, 32, False), (2, 8, 256, 256, 48, False),
                                                  (1, 2, 70, 130, 64, True), (1, 2, 40, 200, 16, False),
                                                  (1, 1, 33, 97, 80, True)])

@@ -76,7 +76,7 @@ class Tape:
     # ------------------------------------------------------------------ conv / linear
     @staticmethod
     def pick_tile(M, N, K, cus=None, vector_ok=True):
-        """Tile / split-K choice, from the per-shape microbenchmarks of round 1 (scratch: mb_gemm):
+        """Tile / split-K choice, from the per-shape microbenchmarks of round 1 (tools/gemm_sweep.py):
         small M*N with short K -> wave-split-K kernel (cfg 7, 32x32 tile per block, no reduce launch);
         otherwise the LDS-staged kernel with the largest tile that still fills the chip, split-K
         (deterministic slab reduce) when the grid would be < 1 block per CU."""

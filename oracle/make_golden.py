@@ -349,6 +349,28 @@ def gen_pc_cli():
     np.savez_compressed(os.path.join(OUT, "pc_cli.npz"), **rec)
     print("pc_cli", rec["a_ts"], rec["a_eigval"][0], rec["apply_sep"].shape, rec["apply_comb_fix"].shape)
 
+    # ---- the headline script itself, main_run.py (SURVEY 8a A1-A17 glue: tstart / skip handling, zs slicing, cfg lists,
+    # multi-prompt segments with unequal tstart, the DDIM mode), same harness
+    FakeRef.get_sr = lambda self: 16000
+    ref_utils.load_audio = lambda *a, **k: (w0.clone(), 16000, 10.0)
+    mr = {"w0": w0.numpy(), "T": T}
+    with tempfile.TemporaryDirectory() as tmp:
+        base = ["--init_aud", "synth.wav", "--model_id", "cvssp/audioldm2", "--num_diffusion_steps", str(T),
+                "--results_path", tmp]
+        glb = run_script("main_run.py", base + ["--source_prompt", "a dog barking", "--target_prompt", "a cat meowing",
+                                                "--tstart", "7", "--cfg_src", "3", "--cfg_tar", "12", "-s", "21"])
+        mr["a_w_edit"], mr["a_zs"], mr["a_wts"] = glb["w0"].numpy(), glb["zs"].numpy(), glb["wts"].numpy()
+        glb = run_script("main_run.py", base + ["--source_prompt", "rain", "--target_prompt", "jazz", "rock",
+                                                "--tstart", "7", "5", "--cfg_src", "3", "--cfg_tar", "12", "8",
+                                                "--cutoff_points", "0.5", "--fix_alpha", "0.2", "-s", "22"])
+        mr["b_w_edit"] = glb["w0"].numpy()
+        glb = run_script("main_run.py", base + ["--source_prompt", "a dog barking", "--target_prompt", "a cat meowing",
+                                                "--tstart", "9", "--cfg_src", "3", "--cfg_tar", "12", "--mode", "ddim",
+                                                "-s", "23"])
+        mr["c_w_edit"], mr["c_wT"] = glb["w0"].numpy(), glb["wT"].numpy()
+    np.savez_compressed(os.path.join(OUT, "main_run.npz"), **mr)
+    print("main_run", [tuple(mr[k].shape) for k in ("a_w_edit", "b_w_edit", "c_w_edit")])
+
 
 # --------------------------------------------------------------------------- audio
 def _load_by_path(modname, path):

@@ -239,3 +239,35 @@ def test_pc_drift_oracle_matches_reference():
                             torch.from_numpy(g["eigvec3"]), torch.from_numpy(g["eigval3"]), latent, amount=2.0,
                             eta=1.0, ev_nums=(1, 2))
     np.testing.assert_allclose(drift.numpy(), g["drift"], rtol=1e-5, atol=2e-6)
+
+
+def test_oracle_reproduces_the_reference_main_run_script():
+    """tests/golden/main_run.npz holds outputs of the reference's OWN code/main_run.py run end to end on the synthetic
+    model (oracle/make_golden.py pc_cli): single prompt, two target prompts with unequal tstart + cutoff + fix_alpha,
+    and --mode ddim.  The oracle loops must retrace the script's glue (tstart/skip handling, zs slicing, cfg lists)."""
+    g = np.load(os.path.join(G, "main_run.npz"))
+    T = int(g["T"])
+    w0 = torch.from_numpy(g["w0"])
+    tol = dict(rtol=2e-5, atol=2e-6)
+    # a: -s 21, source "a dog barking" cfg 3 -> target "a cat meowing" cfg 12, tstart 7
+    w = _wrapper(T)
+    torch.manual_seed(21)
+    _, zs, xts = oloops.invert(w, w0, _cond(["a dog barking"]), _cond([""]), [3.0], T, eta=1.0)
+    np.testing.assert_allclose(zs.numpy(), g["a_zs"], **tol)
+    np.testing.assert_allclose(xts.numpy(), g["a_wts"], **tol)
+    we = oloops.edit(w, xts, torch.tensor([7], dtype=torch.int), _cond(["a cat meowing"]), _cond([""]), [12.0], zs[:7],
+                     eta=1.0, fix_alpha=0.1)
+    np.testing.assert_allclose(we.numpy(), g["a_w_edit"], **tol)
+    # b: -s 22, two target segments (cutoff 0.5) with tstart 7 and 5, cfg 12 / 8, fix_alpha 0.2
+    w = _wrapper(T)
+    torch.manual_seed(22)
+    _, zs, xts = oloops.invert(w, w0, _cond(["rain"]), _cond([""]), [3.0], T, eta=1.0)
+    we = oloops.edit(w, xts, torch.tensor([7, 5], dtype=torch.int), _cond(["jazz", "rock"]), _cond([""]), [12.0, 8.0],
+                     zs[:7], eta=1.0, n_prompts=2, cutoff_points=[0.5], fix_alpha=0.2)
+    np.testing.assert_allclose(we.numpy(), g["b_w_edit"], **tol)
+    # c: --mode ddim, tstart 9 -> skip 3
+    w = _wrapper(T)
+    wT = oloops.ddim_invert(w, w0, _cond(["a dog barking"]), _cond([""]), 3.0, T, 3)
+    np.testing.assert_allclose(wT.numpy(), g["c_wT"], **tol)
+    we = oloops.ddim_sample(w, wT, _cond(["a cat meowing"]), _cond([""]), 12.0, skip=3)
+    np.testing.assert_allclose(we.numpy(), g["c_w_edit"], **tol)

@@ -374,7 +374,8 @@ __global__ __launch_bounds__(256) void attention_split_kernel(AttnParams p) {
 //   * softmax reductions: __shfl_xor(.., 16) compiles to ds_bpermute_b32 (32 per round, each a ~100-cycle LDS
 //     round trip with its own wait).  The 16 key columns of a score row are exactly one DPP row, so the
 //     reductions are 4 DPP-modified VALU ops each (quad_perm xor 1, xor 2, row_half_mirror, row_mirror); every
-//     lane of the row ends with the bit-identical result (commutative pairings only).
+//     lane of the row ends with the bit-identical result (commutative pairings only);
+//   * XCD-aware block order (all query tiles of a head share one L2).
 template <int CTRL>
 __device__ __forceinline__ float dpp_move(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
@@ -410,8 +411,20 @@ __global__ __launch_bounds__(256) void attention_split2_kernel(AttnParams p) {
     const int lane = tid & 63, wave = tid >> 6;
     const int qg = wave & 1, kh = wave >> 1;
     const int fi = lane & 15, fh = lane >> 4;
-    const int b = blockIdx.z, head = blockIdx.y;
-    const int q0 = blockIdx.x * 32 + qg * 16;
+    // XCD-aware order (the dispatcher puts workgroup id w on XCD w % 8, each XCD has a private L2): the query tiles of
+    // one (batch, head) are consecutive ids, i.e. spread over all 8 L2s, and each re-fetches that head's K/V (PMC on
+    // the first kernel: 5.7x the algorithmic bytes).  Bijective remap: XCD x gets a contiguous range of tile ids.
+    int qt, head, b;
+    {
+        const unsigned nx = gridDim.x, ny = gridDim.y, nwg = nx * ny * gridDim.z;
+        const unsigned orig = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
+        const unsigned xcd = orig & 7u, q = nwg >> 3, r = nwg & 7u;
+        const unsigned id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+        qt = (int)(id % nx);
+        head = (int)((id / nx) % ny);
+        b = (int)(id / (nx * ny));
+    }
+    const int q0 = qt * 32 + qg * 16;
     const int hoff = head * D;
 
     const float* Q = p.q + (size_t)b * p.bsq + hoff;

@@ -618,7 +618,7 @@ static int launch_split(const AttnParams& p, int B, bool v2, hipStream_t s) {
 
 // slots: p0=q p1=k p2=v p3=bias(or null) p4=out
 //        i0=B i1=H i2=Nq i3=Nk i4=D i5=ldq i6=ldk i7=ldv i8=ldo i9=ld_bias
-//        i10=bsq i11=bsk i12=bsv i13=bso (elements) ; f0=scale
+//        i10=bsq i11=bsk i12=bsv i13=bso (elements) i14=variant (0 auto, 1 single-pass, 2 opt-in split v2) ; f0=scale
 int launch_attention(const aed_op* op, hipStream_t s) {
     const int32_t* i = op->i;
     AttnParams p;

@@ -47,25 +47,43 @@ def forward_directional(ldm_stable, xt: torch.Tensor, timestep: torch.Tensor, la
                         uncond_emb: PromptEmbeddings, text_emb: PromptEmbeddings, cfg_tar, eta: float = 1,
                         eigvecs=0, amount: float = 0, double_precision: bool = False,
                         mode: PCStreamChoice = PCStreamChoice.BOTH):
+    """One classifier-free-guided scheduler step from `xt` displaced by amount*eigvecs*sqrt(abar_t) on the chosen
+    stream(s) (pc_drift.py:29-93).  The uncond and cond rows go through the U-Net as ONE batch.
+    Returns (x_{t-1}, x0_hat)."""
     if double_precision:
         raise NotImplementedError("double_precision=True: the native path is fp32")
     sched = ldm_stable.model.scheduler
     with torch.no_grad():
-        inp = xt + amount * eigvecs * torch.sqrt(sched.alphas_cumprod[int(timestep)])
-    n = len(xt)
-    def needs(e):
-        return any(v is not None and len(v) == 1 for v in e)
-    if n > 1 and needs(uncond_emb):
-        uncond_emb = _expand_emb(uncond_emb, n)
-    if n > 1 and needs(text_emb):
-        text_emb = _expand_emb(text_emb, n)
-    x_u = inp if mode in (PCStreamChoice.BOTH, PCStreamChoice.UNCOND) else xt
-    x_c = inp if mode in (PCStreamChoice.BOTH, PCStreamChoice.TEXT) else xt
-    eps_u, eps_c = ldm_stable.unet_forward_pair(x_u, x_c, timestep, _to_cond(ldm_stable, uncond_emb),
-                                                _to_cond(ldm_stable, text_emb))
-    noise_pred = eps_u + cfg_tar * (eps_c - eps_u)
-    res = sched.step(noise_pred, timestep, inp, eta=eta, variance_noise=latent)
-    return res.prev_sample, res.pred_original_sample
+        displaced = xt + amount * eigvecs * torch.sqrt(sched.alphas_cumprod[int(timestep)])
+    rows = len(xt)
+    if rows > 1:                              # one embedding row per sample (batched PCs)
+        single = lambda e: any(v is not None and len(v) == 1 for v in e)      # noqa: E731
+        uncond_emb = _expand_emb(uncond_emb, rows) if single(uncond_emb) else uncond_emb
+        text_emb = _expand_emb(text_emb, rows) if single(text_emb) else text_emb
+    on_uncond = mode in (PCStreamChoice.BOTH, PCStreamChoice.UNCOND)
+    on_text = mode in (PCStreamChoice.BOTH, PCStreamChoice.TEXT)
+    eps_u, eps_c = ldm_stable.unet_forward_pair(displaced if on_uncond else xt, displaced if on_text else xt, timestep,
+                                                _to_cond(ldm_stable, uncond_emb), _to_cond(ldm_stable, text_emb))
+    step = sched.step(eps_u + cfg_tar * (eps_c - eps_u), timestep, displaced, eta=eta, variance_noise=latent)
+    return step.prev_sample, step.pred_original_sample
+
+
+# ---------------------------------------------------------------------------------------------- subspace iteration
+def _masked_lengths(v: torch.Tensor, mask: torch.Tensor, k: int) -> torch.Tensor:
+    """Euclidean length of each of the k directions over the masked region (mask is shared by all directions)."""
+    if k > 1:
+        return v[:, mask[0].to(torch.bool)].norm(dim=1)
+    return v[mask.to(torch.bool)].norm()
+
+
+def _orthonormal_rows(dirs: torch.Tensor) -> torch.Tensor:
+    """Re-orthonormalise k directions [k, ...] with a thin QR of the (numel x k) matrix; sign convention: the product
+    of R's diagonal is kept positive (pc_drift.py:162-169)."""
+    k = dirs.shape[0]
+    q, r = torch.linalg.qr(dirs.reshape(k, -1).T, mode="reduced")
+    if torch.prod(torch.linalg.diagonal(r)) < 0:
+        q = -q
+    return (q / q.norm(dim=0)).T.reshape(dirs.shape)
 
 
 def get_eigenvectors(ldm_stable, xt: torch.Tensor, text_emb: PromptEmbeddings, uncond_emb: PromptEmbeddings,
@@ -73,44 +91,56 @@ def get_eigenvectors(ldm_stable, xt: torch.Tensor, text_emb: PromptEmbeddings, u
                      pc_mode: PCStreamChoice = PCStreamChoice.BOTH, const: float = 1e-3, cfg_tar: float = 3,
                      iters: int = 50, double_precision: bool = False, eta: float = 1, n_ev: int = 1,
                      init_eigvecs: Optional[torch.Tensor] = None) -> Tuple:
-    """Subspace iteration on the posterior-mean Jacobian by finite differences.  `init_eigvecs` (optional, not in
-    the reference signature) replaces the randn_like draw so a run can be reproduced across devices."""
-    if n_ev > 1:
-        x0_pred = expand_for_evs(x0_pred, n_ev)
-        xt = expand_for_evs(xt, n_ev)
-        uncond_emb, text_emb = _expand_emb(uncond_emb, n_ev), _expand_emb(text_emb, n_ev)
-    eigvecs = (torch.randn_like(xt) if init_eigvecs is None else init_eigvecs.to(xt.device)) * mask * const
-    prev_ev = eigvecs.detach().clone()
+    """Leading `n_ev` principal components of the posterior covariance at timestep t (pc_drift.py:96-198): block power
+    iteration on the Jacobian of x0_hat, applied by finite differences of step `const`.  All n_ev directions -- and
+    their uncond + cond evaluations -- are ONE U-Net batch per iteration.  `init_eigvecs` (not in the reference
+    signature) replaces the randn_like draw so a run can be reproduced across devices.
+    Returns (eigvecs, eigvals, in_corr, in_norm, interm_eigvecs, interm_eigvals)."""
+    k = n_ev
+    if k > 1:
+        xt, x0_pred = expand_for_evs(xt, k), expand_for_evs(x0_pred, k)
+        uncond_emb, text_emb = _expand_emb(uncond_emb, k), _expand_emb(text_emb, k)
+    tail = [1] * (xt.dim() - 1)
+    to_eigval = ldm_stable.get_sigma(int(t)) ** 2 / const        # |J d| / const * sigma_t^2
+    start = torch.randn_like(xt) if init_eigvecs is None else init_eigvecs.to(xt.device)
+    probe = start * mask * const
+    previous = probe.detach().clone()
     in_corr, in_norm, interm_eigvecs, interm_eigvals = [], [], {}, {}
-    sigma2 = ldm_stable.get_sigma(int(t)) ** 2
+    unit = lengths = None
     with torch.no_grad():
-        for i in range(iters):
-            _, unmasked = forward_directional(ldm_stable, xt, t, latents, uncond_emb, text_emb, cfg_tar, eta=eta,
-                                              eigvecs=eigvecs, amount=1, mode=pc_mode)
-            Ab = unmasked * mask - x0_pred
-            if n_ev > 1:
-                perm = {4: (1, 2, 3, 0), 3: (1, 2, 0), 2: (1, 0)}[len(xt.shape)]
-                norm_of_Ab = Ab[:, mask[0].to(torch.bool)].norm(dim=1)
-                eigvecs = (Ab / norm_of_Ab.reshape(n_ev, *[1] * (len(xt.shape) - 1))) * mask
-                Q, R = torch.linalg.qr(eigvecs.permute(*perm).reshape(-1, n_ev), mode="reduced")
-                if torch.prod(torch.linalg.diagonal(R)) < 0:
-                    Q = Q * -1
-                eigvecs = (Q / Q.norm(dim=0)).T.reshape(Ab.shape)
-                _, order = (norm_of_Ab / const * sigma2).reshape(n_ev).sort(descending=True, stable=True)
-                eigvecs = eigvecs[order, ...]
+        for it in range(iters):
+            _, x0_moved = forward_directional(ldm_stable, xt, t, latents, uncond_emb, text_emb, cfg_tar, eta=eta,
+                                              eigvecs=probe, amount=1, mode=pc_mode)
+            jd = x0_moved * mask - x0_pred                      # J . probe (masked)
+            lengths = _masked_lengths(jd, mask, k)
+            if k > 1:
+                unit = _orthonormal_rows((jd / lengths.reshape(k, *tail)) * mask)
+                unit = unit[(lengths * to_eigval).reshape(k).sort(descending=True, stable=True)[1], ...]
             else:
-                norm_of_Ab = Ab[mask.to(torch.bool)].norm()
-                eigvecs = (Ab / norm_of_Ab) * mask
-            if i > 0:
-                in_corr.append((prev_ev.reshape(n_ev, -1) @ eigvecs.reshape(n_ev, -1).T).diag())
-            in_norm.append(norm_of_Ab)
-            prev_ev = eigvecs.detach().clone()
-            if not (i % 10) and i > 15:
-                interm_eigvecs[i] = eigvecs
-                interm_eigvals[i] = norm_of_Ab / const * sigma2
-            eigvecs = eigvecs * const
-    eigval = norm_of_Ab / const * sigma2
-    return eigvecs / const, eigval, in_corr, in_norm, interm_eigvecs, interm_eigvals
+                unit = (jd / lengths) * mask
+            if it > 0:
+                in_corr.append((previous.reshape(k, -1) @ unit.reshape(k, -1).T).diag())
+            in_norm.append(lengths)
+            previous = unit.detach().clone()
+            if it > 15 and it % 10 == 0:
+                interm_eigvecs[it] = unit
+                interm_eigvals[it] = lengths * to_eigval
+            probe = unit * const                                # keep the finite difference in its linear regime
+    return probe / const, lengths * to_eigval, in_corr, in_norm, interm_eigvecs, interm_eigvals
+
+
+# ---------------------------------------------------------------------------------------------- applying a drift
+def _stored_pc(eigdata, t, timesteps, num_diff_steps, use_specific_ts_pc, sub_iters, evals, device):
+    """Direction(s) and eigenvalue(s) to use at timestep t: vectors may come from another timestep
+    (`use_specific_ts_pc`) or an intermediate iterate (`sub_iters`), values from an external table (`evals`)."""
+    vec_t = int(t) if use_specific_ts_pc is None else int(timesteps[num_diff_steps - use_specific_ts_pc])
+    if sub_iters is not None:
+        if evals is not None:
+            raise ValueError("evals should be None if sub_iters is not None")
+        return (eigdata[vec_t]["interm_eigvecs"][sub_iters].to(device),
+                eigdata[int(t)]["interm_eigvals"][sub_iters].to(device))
+    vals = eigdata[int(t)]["eigval"].to(device) if evals is None else torch.from_numpy(evals[int(t)]).to(device)
+    return eigdata[vec_t]["eigvec"].to(device), vals
 
 
 def apply_drift(ldm_stable, xt_m1: torch.Tensor, x0_pred: torch.Tensor, t: torch.Tensor, timesteps: torch.Tensor,
@@ -118,29 +148,23 @@ def apply_drift(ldm_stable, xt_m1: torch.Tensor, x0_pred: torch.Tensor, t: torch
                 device: torch.device, use_shifted_x0_for_noisepred: bool = True,
                 use_specific_ts_pc: Optional[int] = None, amount: float = 1, sub_iters: Optional[int] = None,
                 eta: float = 1, ev_nums: List[int] = [1], evals: Optional[Dict[int, torch.Tensor]] = None):
-    use_t = int(t) if use_specific_ts_pc is None else int(timesteps[num_diff_steps - use_specific_ts_pc])
-    eigvec = eigdata[use_t]["eigvec"].to(device)
-    eigval = eigdata[int(t)]["eigval"].to(device) if evals is None else torch.from_numpy(evals[int(t)]).to(device)
-    if sub_iters is not None:
-        if evals is not None:
-            raise ValueError("evals should be None if sub_iters is not None")
-        eigvec = eigdata[use_t]["interm_eigvecs"][sub_iters].to(device)
-        eigval = eigdata[int(t)]["interm_eigvals"][sub_iters].to(device)
-    shift_by = 0
-    for ev_num in ev_nums:
-        shift_by = shift_by + amount * (eigval[ev_num - 1].unsqueeze(0).sqrt() * eigvec[ev_num - 1].unsqueeze(0))
-    x0_drift = x0_pred.clone() + shift_by
+    """Move x0_hat by amount * sum_e sqrt(lambda_e) v_e and rebuild x_{t-1} around it (pc_drift.py:201-278): strip the
+    step's noise term, recover the direction term implied by (x_{t-1}, x0_hat), optionally correct it for the moved
+    x0, and recompose."""
+    vecs, vals = _stored_pc(eigdata, t, timesteps, num_diff_steps, use_specific_ts_pc, sub_iters, evals, device)
+    shift = 0
+    for e in ev_nums:
+        shift = shift + amount * (vals[e - 1].unsqueeze(0).sqrt() * vecs[e - 1].unsqueeze(0))
     sched = ldm_stable.model.scheduler
     prev_t = int(t) - sched.config.num_train_timesteps // sched.num_inference_steps
     std = float(eta * sched._get_variance(int(t), prev_t) ** 0.5)
-    a_prev = float(sched.alphas_cumprod[prev_t] if prev_t >= 0 else sched.final_alpha_cumprod)
-    a_t = float(sched.alphas_cumprod[int(t)])
-    if eta > 0:
-        xt_m1 = xt_m1 - std * latent
-    pred_eps = (xt_m1 - a_prev ** 0.5 * x0_pred) / ((1 - a_prev - std ** 2) ** 0.5)
+    abar_prev = float(sched.alphas_cumprod[prev_t] if prev_t >= 0 else sched.final_alpha_cumprod)
+    abar_t = float(sched.alphas_cumprod[int(t)])
+    dir_scale = (1 - abar_prev - std ** 2) ** 0.5
+    moved_x0 = x0_pred.clone() + shift
+    mean = xt_m1 - std * latent if eta > 0 else xt_m1
+    eps_hat = (mean - abar_prev ** 0.5 * x0_pred) / dir_scale
     if use_shifted_x0_for_noisepred:
-        pred_eps = pred_eps - (a_t ** 0.5) / ((1 - a_t) ** 0.5) * shift_by
-    xt_m1 = a_prev ** 0.5 * x0_drift + (1 - a_prev - std ** 2) ** 0.5 * pred_eps
-    if eta > 0:
-        xt_m1 = xt_m1 + std * latent
-    return xt_m1
+        eps_hat = eps_hat - (abar_t ** 0.5) / ((1 - abar_t) ** 0.5) * shift
+    out = abar_prev ** 0.5 * moved_x0 + dir_scale * eps_hat
+    return out + std * latent if eta > 0 else out

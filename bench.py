@@ -206,11 +206,15 @@ def main():
         traffic = traffic_note = None
         pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01b_pmc_forward_B40.json")
         if os.path.exists(pmc_path):
-            with open(pmc_path) as f:
-                pmc = json.load(f)
-            traffic = pmc["measured_bytes_per_launch"]
-            traffic_note = (f"bytes per launch, {pmc['counters']}; {pmc['kernel']}; algorithmic "
-                            f"{pmc['algorithmic_bytes_per_launch']:.3g} B per launch; {pmc['source']} ({pmc['binary']})")
+            try:
+                with open(pmc_path) as f:
+                    pmc = json.load(f)
+                traffic = pmc["measured_bytes_per_launch"]
+                traffic_note = (f"bytes per launch, {pmc['counters']}; {pmc['kernel']}; algorithmic "
+                                f"{pmc['algorithmic_bytes_per_launch']:.3g} B per launch; {pmc['source']} "
+                                f"({pmc['binary']})")
+            except (OSError, KeyError, ValueError) as e:
+                log(f"PMC summary unreadable: {e!r}")
         roof = dict(bound="mfma", achieved=achieved, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
                     frac=achieved / PEAK_FP32_MFMA_TFLOPS, traffic=traffic, traffic_note=traffic_note,
                     kernel="conv_gemm_kernel (+wsk variant)",
@@ -222,7 +226,10 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # many-core hosts (the MI355X box has 256) make torch's CPU kernels slower, not faster, on these
         # small tensors: use at most 32 threads and report that number as `cores`
-        base = cpu_baseline(fam, m.state_dicts, min(os.cpu_count() or 1, 32))
+        try:
+            base = cpu_baseline(fam, m.state_dicts, min(os.cpu_count() or 1, 32))
+        except Exception as e:          # the headline line must survive a failure of the reported-only baseline leg
+            log(f"cpu_baseline failed: {e!r}")
 
     if rank == 0:
         out = {"metric": "edited-clips/sec (200-step inv+edit, 10 s@16 kHz)", "value": value,

@@ -1,0 +1,338 @@
+"""CPU interpreter for `aed_op` tapes.
+
+TEST INFRASTRUCTURE (see oracle/__init__.py): an independent, plain-torch statement of what every opcode of
+include/aed.h means, executed over tapes that the product's builders (unet.UNetEngine, codec.*, editing.EditEngine)
+lay out on device="cpu".  It lets the `-m "not gpu"` suite check the product's HOST logic -- graph wiring, weight
+packing, LayerNorm folding, skip/concat strides, device-indexed loops, timestep batching -- against the oracle and
+the reference fixtures without a GPU.  It is never imported by the product; kernels are still only proven by the
+`-m gpu` tests.  Slot meanings follow the "// slots:" comments next to each launcher in audioeditingcode_amd/csrc.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+ACT_NONE, ACT_SILU, ACT_LEAKY, ACT_TANH, ACT_LOGCLAMP = range(5)
+
+
+def _view(ptr, n, ctype=ctypes.c_float, dtype=np.float32):
+    """Writable torch view of n elements of raw CPU memory at `ptr`."""
+    if not ptr or n <= 0:
+        return None
+    buf = (ctype * int(n)).from_address(int(ptr))
+    return torch.from_numpy(np.frombuffer(buf, dtype=dtype))
+
+
+def _f32(ptr, n):
+    return _view(ptr, n)
+
+
+def _act(v, code, p):
+    if code == ACT_SILU:
+        return v / (1.0 + torch.exp(-v))
+    if code == ACT_LEAKY:
+        return torch.where(v > 0, v, v * p)
+    if code == ACT_TANH:
+        return torch.tanh(v)
+    if code == ACT_LOGCLAMP:
+        return torch.log(torch.clamp(v, min=p))
+    return v
+
+
+def _state0(op_ptr):
+    s = _view(op_ptr, 1, ctypes.c_int32, np.int32)
+    return 0 if s is None else int(s[0])
+
+
+# ------------------------------------------------------------------------------------------------- conv / linear
+def conv_gemm(op):
+    i, f, p = op.i, op.f, op.p
+    (M, N, K, lda, ldc, ldr, ld_rv, IH, IW, OH, OW, Cin, KH, KW, stride, pad_h, pad_w, dil_h, dil_w, up, a_bs, o_mul,
+     o_add, o_len, out_bs, in_act, out_act, accumulate) = [int(i[k]) for k in range(28)]
+    ln_mode = int(i[31])
+    in_slope, out_p, out_div, ln_eps = float(f[0]), float(f[1]), float(f[2]), float(f[3])
+    rpb = OH * OW
+    nb = M // rpb
+    vIH, vIW = IH << up, IW << up
+    if up:
+        vIH = min(vIH, (OH - 1) * stride - 2 * pad_h + dil_h * (KH - 1) + 1)
+        vIW = min(vIW, (OW - 1) * stride - 2 * pad_w + dil_w * (KW - 1) + 1)
+    m = torch.arange(M)
+    b, r = m // rpb, m % rpb
+    oy, ox = r // OW, r % OW
+    taps = torch.arange(KH * KW)
+    ty, tx = taps // KW, taps % KW
+    iy = (oy * stride - pad_h)[:, None] + (ty * dil_h)[None, :]                # [M, taps]
+    ix = (ox * stride - pad_w)[:, None] + (tx * dil_w)[None, :]
+    ok = (iy >= 0) & (iy < vIH) & (ix >= 0) & (ix < vIW)
+    cy, cx = torch.where(ok, iy >> up, 0), torch.where(ok, ix >> up, 0)
+    pix = b[:, None] * a_bs + (cy * IW + cx) * lda                              # element offset of channel 0
+    n_a = int(pix.max()) + Cin
+    a_flat = _f32(p[0], n_a)
+    off = pix[:, :, None] + torch.arange(Cin)[None, None, :]                    # [M, taps, Cin]
+    A = torch.where(ok[:, :, None], a_flat[off.reshape(-1)].reshape(off.shape), torch.zeros(())).reshape(M, K)
+    if ln_mode:
+        mean = A.sum(1) / K
+        var = torch.clamp((A * A).sum(1) / K - mean * mean, min=0.0)
+        rstd = 1.0 / torch.sqrt(var + ln_eps)
+    if in_act:
+        A = _act(A, in_act, in_slope)
+    W = _f32(p[1], N * K).reshape(N, K)
+    acc = A.double() @ W.double().T                                             # independent of the MFMA k-order
+    bias = _f32(p[2], N)
+    if ln_mode:
+        sn = _f32(p[5], N)
+        val = rstd.double()[:, None] * (acc - mean.double()[:, None] * sn.double()[None, :]) + bias.double()[None, :]
+    else:
+        val = acc if bias is None else acc + bias.double()[None, :]
+        if p[5]:
+            rv = _f32(p[5], (nb - 1) * ld_rv + N)
+            val = val + rv[(b[:, None] * ld_rv + torch.arange(N)[None, :])].double()
+    o = r * o_mul + o_add
+    okr = (o >= 0) & (o < o_len)
+    row = b * out_bs + torch.clamp(o, 0, o_len - 1)
+    cols = torch.arange(N)[None, :]
+    if p[4]:
+        res = _f32(p[4], int(row.max()) * ldr + N)
+        val = val + res[(row[:, None] * ldr + cols)].double()
+    val = _act(val.float(), out_act, out_p)
+    n_c = int(row.max()) * ldc + N
+    C = _f32(p[3], n_c)
+    idx = (row[:, None] * ldc + cols)
+    if accumulate == 1:
+        val = val + C[idx]
+    elif accumulate == 2:
+        val = (C[idx] + val) / out_div
+    sel = okr.nonzero().reshape(-1)
+    C[idx[sel].reshape(-1)] = val[sel].reshape(-1)
+
+
+# ------------------------------------------------------------------------------------------------- norms
+def _group_norm(x, gamma, beta, B, HW, C, G, ldx, eps):
+    xs = x[: (B * HW - 1) * ldx + C].as_strided((B, HW, C), (HW * ldx, ldx, 1)).double()
+    g = xs.reshape(B, HW, G, C // G)
+    mean = g.mean(dim=(1, 3), keepdim=True)
+    var = g.var(dim=(1, 3), unbiased=False, keepdim=True)
+    y = ((g - mean) / torch.sqrt(var + eps)).reshape(B, HW, C)
+    return (y * gamma.double() + beta.double()).float()
+
+
+def _store_rows(y_flat, vals, ld):
+    B, HW, C = vals.shape
+    y_flat[: (B * HW - 1) * ld + C].as_strided((B, HW, C), (HW * ld, ld, 1)).copy_(vals)
+
+
+def gn_stats(op):          # the partial sums are consumed only by gn_apply, which recomputes them here
+    return
+
+
+def gn_apply(op):
+    i, p = op.i, op.p
+    B, HW, C, G, ldx, act, ldy = int(i[0]), int(i[1]), int(i[2]), int(i[3]), int(i[4]), int(i[7]), int(i[8])
+    x = _f32(p[0], (B * HW - 1) * ldx + C)
+    y = _group_norm(x, _f32(p[2], C), _f32(p[3], C), B, HW, C, G, ldx, float(op.f[0]))
+    _store_rows(_f32(p[4], (B * HW - 1) * ldy + C), _act(y, act, 0.0), ldy)
+
+
+def gn_small(op):
+    i, p = op.i, op.p
+    B, HW, C, G, ldx, ldy, act = [int(i[k]) for k in range(7)]
+    x = _f32(p[0], (B * HW - 1) * ldx + C)
+    y = _group_norm(x, _f32(p[1], C), _f32(p[2], C), B, HW, C, G, ldx, float(op.f[0]))
+    _store_rows(_f32(p[3], (B * HW - 1) * ldy + C), _act(y, act, 0.0), ldy)
+
+
+def gn_scale_shift(op):
+    i, p = op.i, op.p
+    B, HW, C, G, ldx = [int(i[k]) for k in range(5)]
+    x = _f32(p[0], (B * HW - 1) * ldx + C)[: (B * HW - 1) * ldx + C].as_strided((B, HW, C), (HW * ldx, ldx, 1)).double()
+    g = x.reshape(B, HW, G, C // G)
+    mean = g.mean(dim=(1, 3))
+    rstd = 1.0 / torch.sqrt(g.var(dim=(1, 3), unbiased=False) + float(op.f[0]))          # [B, G]
+    a = rstd.repeat_interleave(C // G, 1) * _f32(p[1], C).double()
+    d = _f32(p[2], C).double() - mean.repeat_interleave(C // G, 1) * a
+    _f32(p[3], B * 2 * C).reshape(B, 2, C).copy_(torch.stack([a, d], 1).float())
+
+
+def layernorm(op):
+    i, p = op.i, op.p
+    M, C, ldx, ldy = [int(i[k]) for k in range(4)]
+    x = _f32(p[0], (M - 1) * ldx + C).as_strided((M, C), (ldx, 1)).double()
+    y = torch.nn.functional.layer_norm(x, (C,), _f32(p[1], C).double(), _f32(p[2], C).double(), float(op.f[0]))
+    _f32(p[3], (M - 1) * ldy + C).as_strided((M, C), (ldy, 1)).copy_(y.float())
+
+
+# ------------------------------------------------------------------------------------------------- attention etc.
+def attention(op):
+    i, p = op.i, op.p
+    B, H, Nq, Nk, D, ldq, ldk, ldv, ldo, ld_bias, bsq, bsk, bsv, bso = [int(i[k]) for k in range(14)]
+    C = H * D
+
+    def mat(ptr, n_rows, ld, bs):
+        flat = _f32(ptr, (B - 1) * bs + (n_rows - 1) * ld + C)
+        return flat.as_strided((B, n_rows, H, D), (bs, ld, D, 1))
+    q, k, v = mat(p[0], Nq, ldq, bsq).double(), mat(p[1], Nk, ldk, bsk).double(), mat(p[2], Nk, ldv, bsv).double()
+    s = torch.einsum("bqhd,bkhd->bhqk", q, k) * float(op.f[0])
+    if p[3]:
+        bias = _f32(p[3], (B - 1) * ld_bias + Nk).as_strided((B, Nk), (ld_bias, 1)).double()
+        s = s + bias[:, None, None, :]
+    o = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(s, -1), v)
+    mat(p[4], Nq, ldo, bso).copy_(o.float())
+
+
+def geglu(op):
+    i, p = op.i, op.p
+    M, Dff, ldh, ldo = [int(i[k]) for k in range(4)]
+    h = _f32(p[0], (M - 1) * ldh + 2 * Dff).as_strided((M, 2 * Dff), (ldh, 1))
+    a, g = h[:, :Dff], h[:, Dff:]
+    out = a * (0.5 * g * (1.0 + torch.erf(g * 0.70710678118654752440)))
+    _f32(p[1], (M - 1) * ldo + Dff).as_strided((M, Dff), (ldo, 1)).copy_(out)
+
+
+def copy2d(op):
+    i, p = op.i, op.p
+    rows, cols, lds, ldd, idx_off, idx_mul, idx_stride = [int(i[k]) for k in range(7)]
+    shift = (idx_off + idx_mul * _state0(p[2])) * idx_stride if p[2] else 0
+    src = _f32(int(p[0]) + 4 * shift, (rows - 1) * lds + cols).as_strided((rows, cols), (lds, 1))
+    _f32(p[1], (rows - 1) * ldd + cols).as_strided((rows, cols), (ldd, 1)).copy_(src.clone())
+
+
+def time_embed(op):
+    i, p = op.i, op.p
+    B, dim, flip, ld, t_imm, tgroup = [int(i[k]) for k in range(6)]
+    tgroup = max(1, tgroup)
+    half = dim // 2
+    s = _state0(p[2]) if p[2] else 0
+    if p[1]:
+        tidx = _view(p[4], B, ctypes.c_int32, np.int32) if p[4] else torch.zeros(B, dtype=torch.int32)
+        table = _view(p[1], s * tgroup + int(tidx.max()) + 1, ctypes.c_int64, np.int64)
+        t = table[s * tgroup + tidx.long()].float()
+    else:
+        t = torch.full((B,), float(t_imm))
+    if p[3]:
+        fr = _f32(p[3], half)
+    else:
+        fr = torch.exp(-math.log(float(op.f[1])) * torch.arange(half, dtype=torch.float32) / (half - float(op.f[0])))
+    arg = t[:, None] * fr[None, :]
+    sv, cv = torch.sin(arg), torch.cos(arg)
+    out = _f32(p[0], (B - 1) * ld + dim).as_strided((B, dim), (ld, 1))
+    out.copy_(torch.cat([cv, sv], 1) if flip else torch.cat([sv, cv], 1))
+
+
+def softmax_rows(op):
+    i, p = op.i, op.p
+    rows, cols, ldx, ldy = [int(i[k]) for k in range(4)]
+    x = _f32(p[0], (rows - 1) * ldx + cols).as_strided((rows, cols), (ldx, 1)).double() * float(op.f[0])
+    _f32(p[1], (rows - 1) * ldy + cols).as_strided((rows, cols), (ldy, 1)).copy_(torch.softmax(x, -1).float())
+
+
+def transpose(op):
+    i, p = op.i, op.p
+    Bt, R, C, lds, ldd, bss, bsd = [int(i[k]) for k in range(7)]
+    src = _f32(p[0], (Bt - 1) * bss + (R - 1) * lds + C).as_strided((Bt, R, C), (bss, lds, 1))
+    _f32(p[1], (Bt - 1) * bsd + (C - 1) * ldd + R).as_strided((Bt, C, R), (bsd, ldd, 1)).copy_(src.transpose(1, 2))
+
+
+def axpby(op):
+    n = (int(op.i[0]) & 0xFFFFFFFF) | ((int(op.i[1]) & 0xFFFFFFFF) << 32)
+    a, b = float(op.f[0]), float(op.f[1])
+    x, y = _f32(op.p[0], n), _f32(op.p[1], n)
+    y.copy_(a * x if b == 0.0 else a * x + b * y)
+
+
+# ------------------------------------------------------------------------------------------------- step math (K1)
+def _step_common(op):
+    i, f, p = op.i, op.f, op.p
+    numel = (int(i[0]) & 0xFFFFFFFF) | ((int(i[1]) & 0xFFFFFFFF) << 32)
+    P, T, s_imm, v_pred, flag = int(i[2]), int(i[3]), int(i[4]), int(i[5]), int(i[6])
+    s_mul, s_off = (int(i[7]) if int(i[7]) > 0 else 1), int(i[8])
+    s = _state0(p[6]) * s_mul + s_off if p[6] else s_imm
+    c = _f32(int(p[5]) + 4 * 8 * s, 8) if p[5] else torch.tensor([float(f[1 + k]) for k in range(5)])
+    eps_u = _f32(p[2], numel)
+    eps = eps_u
+    if p[3]:
+        eps_c = _f32(p[3], P * numel).reshape(P, numel)
+        acc = None
+        for j in range(P):
+            g = _f32(p[4], P * numel).reshape(P, numel)[j] if p[4] else float(f[0])
+            term = g * (eps_c[j] - eps_u)
+            acc = term if acc is None else acc + term
+        eps = eps_u + acc
+    return numel, T, s, v_pred, flag, c, eps
+
+
+def _x0_dir(x, eps, c, v_pred):
+    if not v_pred:
+        return (x - c[0] * eps) / c[1], eps
+    return c[1] * x - c[0] * eps, c[1] * eps + c[0] * x
+
+
+def invert_step(op):
+    numel, T, s, v_pred, fix, c, eps = _step_common(op)
+    idx = T - s - 1
+    base = int(op.p[0])
+    xt = _f32(base + 4 * (idx + 1) * numel, numel)
+    xtm1 = _f32(base + 4 * idx * numel, numel)
+    z = _f32(int(op.p[1]) + 4 * idx * numel, numel)
+    x0, d = _x0_dir(xt, eps, c, v_pred)
+    mu = c[2] * x0 + c[3] * d
+    zz = (xtm1 - mu) / c[4]
+    z.copy_(zz)
+    if fix:
+        xtm1.copy_(mu + c[4] * zz)
+    if op.p[7]:
+        _f32(op.p[7], numel).copy_(eps)
+
+
+def reverse_step(op):
+    numel, T, s, v_pred, has_noise, c, eps = _step_common(op)
+    xt = _f32(op.p[0], numel)
+    x0, d = _x0_dir(xt, eps, c, v_pred)
+    prev = c[2] * x0 + c[3] * d
+    if has_noise:
+        z = _f32(int(op.p[1]) + 4 * (T - s - 1) * numel, numel) if T > 0 else _f32(op.p[1], numel)
+        prev = prev + c[4] * z
+    _f32(op.p[7], numel).copy_(prev)
+
+
+def advance(op):
+    st = _view(op.p[0], 1, ctypes.c_int32, np.int32)
+    st[0] += int(op.i[0]) if int(op.i[0]) else 1
+
+
+# ------------------------------------------------------------------------------------------------- STFT helpers
+def reflect_pad(op):
+    B, N, pad, ldd = [int(op.i[k]) for k in range(4)]
+    src = _f32(op.p[0], B * N).reshape(B, N)
+    j = torch.arange(N + 2 * pad) - pad
+    j = torch.where(j < 0, -j, j)
+    j = torch.where(j >= N, 2 * (N - 1) - j, j)
+    _f32(op.p[1], (B - 1) * ldd + N + 2 * pad).as_strided((B, N + 2 * pad), (ldd, 1)).copy_(src[:, j])
+
+
+def magnitude(op):
+    F, cut, ldf, ldm = [int(op.i[k]) for k in range(4)]
+    ft = _f32(op.p[0], (F - 1) * ldf + 2 * cut).as_strided((F, 2 * cut), (ldf, 1))
+    mag = _f32(op.p[1], F * ldm).reshape(F, ldm)
+    mag.zero_()
+    mag[:, :cut] = torch.sqrt(ft[:, :cut] ** 2 + ft[:, cut:] ** 2)
+
+
+def nop(op):
+    return
+
+
+DISPATCH = {0: nop, 1: conv_gemm, 2: gn_stats, 3: gn_apply, 4: layernorm, 5: attention, 6: geglu, 7: copy2d,
+            8: time_embed, 9: softmax_rows, 10: transpose, 11: axpby, 12: invert_step, 13: reverse_step,
+            14: reverse_step, 15: advance, 16: reflect_pad, 17: magnitude, 18: transpose, 19: transpose, 20: nop,
+            21: gn_scale_shift, 22: gn_small}
+
+
+def run_tape(tape, start=0, end=None):
+    """Drop-in for Tape.run on a tape built with device="cpu"."""
+    tape.finalize()
+    end = len(tape.ops) if end is None else end
+    with torch.no_grad():
+        for op in tape.ops[start:end]:
+            DISPATCH[int(op.code)](op)

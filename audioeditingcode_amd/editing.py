@@ -384,3 +384,19 @@ class EditEngine:
         xts_like = xt.unsqueeze(0).expand(T - skip + 1, *xt.shape)
         return self.edit(xts_like, None, T - skip, cond_tgt, cond_uncond, [guidance_scale], eta=0.0,
                          use_graph=use_graph, table_kind="ddim_prev")
+
+    # ------------------------------------------------------------------ n clips, latent in -> edited latent out
+    @torch.inference_mode()
+    def edit_latents(self, x0, cond_src, cond_uncond, cond_tgt, cond_neg, cfg_src, cfg_tar, tstart, eta=1.0,
+                     schedule="sequential", group=8, noise=None, generator=None):
+        """Inversion + edit of n independent clips as ONE U-Net batch per step (BASELINE config 3: 8 clips per GPU):
+        x0 [n,C,H,W]; every Conditioning has 1 row (shared by the clips) or n rows (per clip); cond_src may be None
+        (empty source prompt).  x_t noise is drawn per timestep for all clips at once on the CPU generator.
+        Returns the edited latents [n,C,H,W] on the device."""
+        n = x0.shape[0]
+        rep = lambda c: None if c is None else c.repeat(n)                  # noqa: E731  (1 row -> n rows)
+        xts0 = self.sample_xts(x0, noise, generator)
+        zs, xts = self.invert(x0, rep(cond_src), cond_uncond, cfg_src, eta=eta, numerical_fix=True, xts=xts0,
+                              mode=schedule, group=group)
+        w = self.edit(xts, zs, int(tstart), rep(cond_tgt), cond_neg, cfg_tar, eta=eta)
+        return self.to_nchw(w)

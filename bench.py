@@ -83,6 +83,9 @@ def main():
     ap.add_argument("--schedule", default="batched", choices=["batched", "sequential"],
                     help="headline schedule of the forward inversion (the other one is timed as an extra)")
     ap.add_argument("--profile-forward", action="store_true", help="only run U-Net forwards (for rocprofv3)")
+    ap.add_argument("--clips-per-gpu", type=int, default=1,
+                    help="independent clips edited together per step and GPU (BASELINE configs[2]: 8; default: the "
+                         "headline configs[1] shape, 1)")
     args = ap.parse_args()
 
     from audioeditingcode_amd import configs, dist as adist, models, weights
@@ -122,6 +125,28 @@ def main():
         return edit_clip(m, x0, src, tgt, neg, [3.0], [12.0], args.T, args.tstart, schedule=schedule,
                          timestep_group=args.group)
 
+    NC = max(1, args.clips_per_gpu)
+
+    def run_clips(waves, schedule):
+        """NC clips as one U-Net batch per step (EditEngine.edit_latents); codec per clip."""
+        from audioeditingcode_amd.ddm_inversion.inversion_utils import conditioning_from_text
+        x0s, w0s = [], []
+        for wave in waves:
+            mel, _, _ = fn.mel_spectrogram(wave)
+            x0s.append(mel[0].T[:1024][None, None].contiguous())
+            w0s.append(m.vae_encode(x0s[-1]))
+        w0 = torch.cat(w0s, 0)
+        ed_ = m.editor(w0.shape[-2], w0.shape[-1])
+        c = {k: conditioning_from_text(m, m.encode_text(p, negative=neg_flag))
+             for k, p, neg_flag in (("src", src, False), ("tgt", tgt, False), ("unc", [""], True), ("neg", neg, True))}
+        w = ed_.edit_latents(w0, c["src"], c["unc"], c["tgt"], c["neg"], [3.0], [12.0], args.tstart, schedule=schedule,
+                             group=max(1, args.group // NC))
+        for i in range(len(waves)):
+            x0_dec = m.vae_decode(w[i:i + 1])
+            m.decode_to_mel(x0_dec if x0_dec.dim() == 4 else x0_dec[None])
+            m.decode_to_mel(x0s[i])
+        return w
+
     if args.profile_forward:
         ed = m.editor(256, 16)
         torch.manual_seed(0)
@@ -131,18 +156,20 @@ def main():
         return
 
     def timed(schedule, K, W):
+        def step(seed, waves_):
+            torch.manual_seed(seed)
+            if NC == 1:
+                return run_clip(waves_[0], schedule)[2]
+            return run_clips(waves_, schedule)
         for i in range(W):
-            torch.manual_seed(1000 + i)
-            run_clip(clip_wave(rank * 1000 + i), schedule)
-        waves = [clip_wave(rank * 1000 + 100 + i) for i in range(K)]
+            step(1000 + i, [clip_wave(rank * 100000 + i * NC + j) for j in range(NC)])
+        waves = [[clip_wave(rank * 100000 + 5000 + i * NC + j) for j in range(NC)] for i in range(K)]
         lat = []
         torch.cuda.synchronize()
         adist.barrier()
         t0 = time.perf_counter()
         for i in range(K):
-            torch.manual_seed(2000 + i)
-            _, _, w_edit = run_clip(waves[i], schedule)
-            lat.append(w_edit)
+            lat.append(step(2000 + i, waves[i]))
         local_lat = torch.cat(lat, 0)
         gathered = adist.gather_to_rank0(local_lat)
         torch.cuda.synchronize()
@@ -156,14 +183,14 @@ def main():
     # models.py:67-83).  The reference's one-timestep-at-a-time order is timed too and reported beside it.
     log(f"model ready ({m.weights_source}); timing {args.steps} clip(s) after {args.warmup} warm-up")
     dt, gathered = timed(args.schedule, args.steps, args.warmup)
-    value = world * args.steps / dt
+    value = world * NC * args.steps / dt
     log(f"{args.schedule}: {dt / args.steps:.3f} s/clip")
     extra = {}
     if not args.no_batched:
         other = "sequential" if args.schedule == "batched" else "batched"
         dto, _ = timed(other, args.steps, 1)
         key = "reference_order" if other == "sequential" else "batched_inversion"
-        extra[f"value_{key}"] = world * args.steps / dto
+        extra[f"value_{key}"] = world * NC * args.steps / dto
         extra[f"ms_per_step_{key}"] = 1e3 * dto / args.steps
         log(f"{other}: {dto / args.steps:.3f} s/clip")
 
@@ -179,9 +206,12 @@ def main():
         detail = {}
         per_clip_flops = 0.0
         for (B, _, _), eng in ed._unets.items():
-            calls = {2: args.tstart + (args.T if args.schedule == "sequential" else 0)}
+            calls = {2 * NC: args.tstart + (args.T if args.schedule == "sequential" else 0)}
             if args.schedule == "batched":
-                calls[2 * args.group] = calls.get(2 * args.group, 0) + args.T // args.group
+                G = max(1, min(args.group // NC if NC > 1 else args.group, args.T))
+                while args.T % G:
+                    G -= 1
+                calls[2 * G * NC] = calls.get(2 * G * NC, 0) + args.T // G
             if B not in calls or not calls[B] or f"unet_batch_{B}" in detail:
                 continue        # one engine per batch size (context lengths differ, launch shapes do not)
             with torch.inference_mode():
@@ -237,11 +267,11 @@ def main():
                "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"AudioLDM2 ({args.model_id}, 346.9M-param U-Net, seeded-random weights) "
-                                      f"text-based edit, T={args.T}, tstart={args.tstart}, cfg 3/12, 1 clip of 10 s "
+                                      f"text-based edit, T={args.T}, tstart={args.tstart}, cfg 3/12, {NC} clip(s) of 10 s "
                                       f"@16 kHz per GPU per step; forward inversion schedule: {args.schedule}"
                                       + (f" ({args.group} timesteps per U-Net call)" if args.schedule == "batched" else
                                          " (reference order)"),
-                          "clips_per_gpu_per_step": 1, "parallelism": f"clip-dp{world}",
+                          "clips_per_gpu_per_step": NC, "parallelism": f"clip-dp{world}",
                           "weights_broadcast_s": t_bcast if world > 1 else 0.0,
                           "gathered_latents": None if gathered is None else [list(g.shape) for g in gathered][:2]},
                "roofline": roof, "cpu_baseline": base}

@@ -237,3 +237,24 @@ def test_unet_odd_latent_size_on_cpu():
     ref, _, _ = ounet.unet_forward(cfg, sd, x, torch.tensor(77), encoder_hidden_states=e0, encoder_hidden_states_1=e1,
                                    encoder_attention_mask_1=torch.ones(B, 3))
     assert (eng.eps.permute(0, 3, 1, 2) - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
+
+
+def test_edit_latents_batch_equals_per_clip_runs_on_cpu(cpu_loops):
+    """EditEngine.edit_latents (n clips, one U-Net batch per step; the bench's --clips-per-gpu path): clip i of a
+    batch of 2 equals the single-clip run on the same noise, for both inversion schedules."""
+    T, tstart = 6, 4
+    eng, ow, conds, to_c, x0 = _loop_setup("audioldm2", T)
+    g = torch.Generator().manual_seed(9)
+    x0b = torch.cat([x0, torch.randn(1, 8, LH, LW, generator=g) * 0.8])
+    noise = torch.randn(T, 2, 8, LH, LW, generator=torch.Generator().manual_seed(4))
+    args = (to_c(conds["src"]), to_c(conds["unc"]), to_c(conds["tgt"]), to_c(conds["unc"]), [3.0], [12.0], tstart)
+    for schedule, group in (("sequential", 1), ("batched", 3)):
+        both = eng.edit_latents(x0b, *args, schedule=schedule, group=group, noise=noise).clone()
+        for i in range(2):
+            one = eng.edit_latents(x0b[i:i + 1], *args, schedule=schedule, group=group, noise=noise[:, i:i + 1])
+            assert rel(both[i:i + 1], one) < 1e-4, (schedule, i, rel(both[i:i + 1], one))
+    # and the whole thing against the oracle loops for clip 0
+    xts0 = torch.cat([x0b[:1][None], eng.sample_xts(x0b[:1], noise=noise[:, :1])[1:]])[:, 0]
+    _, zs_o, xts_o = oloops.invert(ow, x0b[:1], conds["src"], conds["unc"], [3.0], T, eta=1.0, xts=xts0.clone())
+    w_o = oloops.edit(ow, xts_o, torch.tensor([tstart]), conds["tgt"], conds["unc"], [12.0], zs_o[:tstart], eta=1.0)
+    assert rel(both[:1], w_o) < 2e-3

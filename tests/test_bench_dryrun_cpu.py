@@ -1,0 +1,120 @@
+"""bench.py's control flow executed on CPU with every GPU-facing piece mocked (model, engines, streams): guards the
+driver-facing contract -- ONE JSON line with the required keys, both inversion schedules, the roofline and traffic
+legs, --clips-per-gpu -- against run-time errors that would otherwise only show up on the GPU box."""
+import contextlib
+import io
+import json
+import os
+import sys
+from unittest import mock
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench                                                     # noqa: E402
+from audioeditingcode_amd import main_run, models               # noqa: E402
+
+
+class _Tape:
+    flops = 3.4e11
+    meta = [dict(code=1, flops=1e9, name="x.conv1"), dict(code=22, flops=0, name="gn")]
+
+    def profile(self):
+        return [0.01, 0.005]
+
+
+class _Eng:
+    tape = _Tape()
+
+
+class _Ed:
+    def __init__(self, batches):
+        self._unets = {(b, 8, 16): _Eng() for b in batches}
+        self._unets[(batches[0], 8, 9)] = _Eng()            # a second engine of the same batch size (other context length)
+        self.state = torch.zeros(4, dtype=torch.int32)
+
+    def edit_latents(self, w0, *a, **k):
+        return torch.zeros(w0.shape[0], 8, 256, 16)
+
+
+class _STFT:
+    def mel_spectrogram(self, w):
+        return torch.zeros(1, 64, 1025), None, None
+
+
+class _Model:
+    weights_source, state_dicts, kind = "mock", {}, "audioldm2"
+
+    def __init__(self, batches):
+        self._ed = _Ed(batches)
+
+    def get_fn_STFT(self):
+        return _STFT()
+
+    def editor(self, H, W):
+        return self._ed
+
+    def vae_encode(self, x):
+        return torch.zeros(1, 8, 256, 16)
+
+    def vae_decode(self, w):
+        return torch.zeros(1, 1, 1024, 64)
+
+    def decode_to_mel(self, x):
+        return torch.zeros(1, 16)
+
+    def encode_text(self, p, negative=False):
+        return torch.zeros(1, 8, 768), torch.zeros(1, 4, 1024), torch.ones(1, 4)
+
+
+class _Stream:
+    def __init__(self, *a, **k):
+        pass
+
+
+@contextlib.contextmanager
+def _stream_ctx(s):
+    yield
+
+
+def _run(argv, batches):
+    with mock.patch.object(sys, "argv", ["bench.py", *argv]), mock.patch("torch.cuda.set_device"), \
+            mock.patch("torch.cuda.synchronize"), mock.patch("torch.cuda.Stream", _Stream), \
+            mock.patch("torch.cuda.stream", _stream_ctx), \
+            mock.patch.object(models, "load_model", lambda *a, **k: _Model(batches)), \
+            mock.patch.object(main_run, "edit_clip", lambda m, x0, *a, **k: (None, None, torch.zeros(1, 8, 256, 16))), \
+            mock.patch("audioeditingcode_amd.weights.random_state_dict", lambda *a, **k: {}), \
+            mock.patch("torch.Tensor.to", lambda self, *a, **k: self), mock.patch("torch.device", lambda *a, **k: "cpu"):
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            bench.main()
+    lines = [ln for ln in buf.getvalue().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines                                    # exactly ONE line on stdout
+    return json.loads(lines[0])
+
+
+REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
+
+
+def test_default_line_has_the_contract_keys():
+    out = _run(["--steps", "2", "--warmup", "1", "--no-cpu-baseline"], [2, 40])
+    assert all(k in out for k in REQUIRED)
+    assert out["n_gpus"] == 1 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["dtype"] == "f32" and out["vs_baseline"] is None and out["higher_is_better"] is True
+    assert "workload" in out["config"] and out["config"]["clips_per_gpu_per_step"] == 1
+    r = out["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert set(r["by_batch"]) == {"unet_batch_2", "unet_batch_40"}          # one engine per batch size
+    assert r["launches_per_clip"] == 100 * 1 + 10 * 1                       # tstart edit forwards + T/G inversion forwards
+    assert r["traffic"] is None or r["traffic"] > 0
+    assert "value_reference_order" in out
+
+
+def test_sequential_schedule_and_multi_clip_mode():
+    out = _run(["--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--schedule", "sequential"], [2, 40])
+    assert "value_batched_inversion" in out and "reference order" in out["config"]["workload"]
+    out = _run(["--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--clips-per-gpu", "2"], [4, 40])
+    assert out["config"]["clips_per_gpu_per_step"] == 2 and out["config"]["gathered_latents"] == [[2, 8, 256, 16]]
+    assert set(out["roofline"]["by_batch"]) == {"unet_batch_4", "unet_batch_40"}

@@ -59,9 +59,7 @@ class PipelineWrapper(torch.nn.Module):
         self.device = torch.device(device)
         self.double_precision = double_precision
         self.token = token
-        if self.device.type != "cuda":
-            raise L.AedError(f"device={device}: the product path needs an MI355X (HIP); there is no CPU fallback. "
-                             f"The CPU restatement lives in oracle/ and is test infrastructure only.")
+        self._require_device()
         L.lib()                                                       # fail loudly if libaed.so is missing
         self.family = configs.get_family(model_id)
         self.kind = self.family["ctx"]["kind"]
@@ -94,6 +92,13 @@ class PipelineWrapper(torch.nn.Module):
             vae_scale_factor=2 ** (len(vcfg["block_out_channels"]) - 1))
         self._engines = {}
         self._editors = {}
+
+    def _require_device(self) -> None:
+        """The product runs on HIP only.  (The CPU test suite subclasses the wrapper and overrides this hook to execute
+        the wrapper's HOST logic on tapes interpreted by oracle/tape_interp.py; nothing in the product does.)"""
+        if self.device.type != "cuda":
+            raise L.AedError(f"device={self.device}: the product path needs an MI355X (HIP); there is no CPU fallback. "
+                             f"The CPU restatement lives in oracle/ and is test infrastructure only.")
 
     # ------------------------------------------------------------------ engine caches
     def _cached(self, key, make):

@@ -336,3 +336,39 @@ def run_tape(tape, start=0, end=None):
     with torch.no_grad():
         for op in tape.ops[start:end]:
             DISPATCH[int(op.code)](op)
+
+
+# ------------------------------------------------------------------------------------------------- C-ABI stand-ins
+class FakeLib:
+    """Stand-in for the ctypes handle of libaed.so in CPU tests: the path-level entry points of include/aed.h that the
+    wrapper calls directly (not through a tape), stated in plain torch over raw CPU pointers."""
+
+    @staticmethod
+    def _ptr(v):
+        return v.value if isinstance(v, ctypes.c_void_p) else v
+
+    def aed_get_zs_from_xts(self, xt, xtm1, eps_u, eps_c, cfg, cfg_scalar, n_prompts, coef_host, v_pred, fix, z,
+                            noise_pred_out, numel, stream):
+        c = torch.tensor([float(coef_host[k]) for k in range(5)])
+        x, xm1, eps = _f32(xt, numel), _f32(xtm1, numel), _f32(eps_u, numel)
+        assert not eps_c, "the wrapper passes the combined prediction"
+        x0, d = _x0_dir(x, eps, c, v_pred)
+        mu = c[2] * x0 + c[3] * d
+        zz = (xm1 - mu) / c[4]
+        _f32(z, numel).copy_(zz)
+        if fix:
+            xm1.copy_(mu + c[4] * zz)
+        return 0
+
+    def aed_reverse_step_with_custom_noise(self, xt, eps_u, eps_c, cfg, cfg_scalar, n_prompts, coef_host, v_pred, z,
+                                           prev_out, numel, stream):
+        c = torch.tensor([float(coef_host[k]) for k in range(5)])
+        x0, d = _x0_dir(_f32(xt, numel), _f32(eps_u, numel), c, v_pred)
+        prev = c[2] * x0 + c[3] * d
+        if z:
+            prev = prev + c[4] * _f32(z, numel)
+        _f32(prev_out, numel).copy_(prev)
+        return 0
+
+    def aed_last_error(self):
+        return b""

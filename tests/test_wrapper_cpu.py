@@ -141,3 +141,125 @@ def test_pc_functions_on_the_real_wrapper_on_cpu(cpu_stack):
     cos = (ev.reshape(2, -1) * ev_o.reshape(2, -1)).sum(1)
     assert (cos > 0.99).all(), cos
     assert rel(val, val_o) < 2e-2
+
+
+class _CpuAudioLDM(models.AudioLDMWrapper):
+    def _require_device(self):
+        pass
+
+
+class _CpuTango(models.TangoWrapper):
+    def _require_device(self):
+        pass
+
+
+def _model_of(cls, model_id, T):
+    m = cls(model_id=model_id, device="cpu", seed=0)
+    m.load_scheduler()
+    m.model.scheduler.set_timesteps(T, device=None)
+    return m
+
+
+def _oracle_wrapper_for(m, T):
+    cfg, sd = m.family["unet"], m.state_dicts["unet"]
+    osched = OracleDDIMScheduler()
+    osched.set_timesteps(T)
+    kind = m.kind
+
+    def unet_fn(x, t, cond):
+        hs, cl, mk = (None if v is None else v.expand(x.shape[0], *v.shape[1:]) for v in cond)
+        if kind == "audioldm2":
+            kw = dict(encoder_hidden_states=hs, encoder_hidden_states_1=cl, encoder_attention_mask_1=mk)
+        elif kind == "audioldm":
+            kw = dict(class_labels=cl)
+        else:
+            kw = dict(encoder_hidden_states=hs, encoder_attention_mask=mk)
+        return ounet.unet_forward(cfg, sd, x, t, **kw)[0]
+    return oloops.OracleWrapper(osched, unet_fn)
+
+
+@pytest.mark.parametrize("cls,model_id", [(_CpuAudioLDM, "tiny/audioldm"), (_CpuTango, "tiny/tango")])
+def test_other_families_invert_and_edit_on_cpu(cpu_stack, cls, model_id):
+    from audioeditingcode_amd.ddm_inversion import inversion_forward_process, inversion_reverse_process
+    T, tstart = 4, 3
+    m = _model_of(cls, model_id, T)
+    ow = _oracle_wrapper_for(m, T)
+    w0 = torch.randn(1, 8, 16, 16, generator=torch.Generator().manual_seed(2)) * 0.7
+    torch.manual_seed(6)
+    _, zs, wts, _ = inversion_forward_process(m, w0, etas=1.0, prompts=["rain"], cfg_scales=[3.0],
+                                              num_inference_steps=T, numerical_fix=True)
+    w, _ = inversion_reverse_process(m, xT=wts, tstart=torch.tensor([tstart]), etas=1.0, prompts=["jazz"],
+                                     neg_prompts=[""], cfg_scales=[9.0], zs=zs[:tstart])
+    xts0 = ow.sample_xts_from_x0(w0, T, generator=torch.Generator().manual_seed(6))
+    _, zs_o, xts_o = oloops.invert(ow, w0, m.encode_text(["rain"]), m.encode_text([""]), [3.0], T, xts=xts0)
+    w_o = oloops.edit(ow, xts_o, torch.tensor([tstart]), m.encode_text(["jazz"]), m.encode_text([""]), [9.0],
+                      zs_o[:tstart], eta=1.0)
+    assert rel(wts[1:], xts_o[1:]) < 1e-5 and rel(w, w_o) < 2e-3, (rel(wts[1:], xts_o[1:]), rel(w, w_o))
+
+
+def test_ddim_mode_and_sdedit_on_cpu(cpu_stack):
+    from audioeditingcode_amd.sdedit import sdedit
+    T = 5
+    m = _model(T)
+    ow = _oracle_wrapper(m, T)
+    x0, _, _ = load_audio((synthetic_clip(seconds=0.64, seed=3), 16000), m.get_fn_STFT(), device="cpu", stft=True)
+    _, _, w_ddim = edit_clip(m, x0, ["a dog barking"], ["a cat meowing"], [""], [3.0], [7.0], T, 4, mode="ddim")
+    w0 = ovae.vae_encode(m.family["vae"], m.state_dicts["vae"], x0)
+    wT = oloops.ddim_invert(ow, w0, m.encode_text(["a dog barking"]), m.encode_text([""]), 3.0, T, 1)
+    w_o = oloops.ddim_sample(ow, wT, m.encode_text(["a cat meowing"]), m.encode_text([""]), 7.0, skip=1)
+    assert rel(w_ddim, w_o) < 2e-3, rel(w_ddim, w_o)
+    # SDEdit: default draws in the reference's order (torch global RNG), checked against the oracle loop pinned to
+    # the reference's main_run_sdedit.py
+    torch.manual_seed(11)
+    got = sdedit(m, w0, ["jazz"], [""], 5.0, skip=2, eta=1.0)
+    torch.manual_seed(11)
+    ref = opc.sdedit_loop(ow, w0, m.encode_text(["jazz"]), m.encode_text([""]), 5.0, skip=2, eta=1.0)
+    assert rel(got, ref) < 2e-3, rel(got, ref)
+
+
+def test_two_prompt_segments_equal_and_unequal_tstart_on_cpu(cpu_stack):
+    """Multi-prompt editing: equal tstart runs on the device-resident loop with per-element cfg tensors, unequal tstart
+    on the host-driven hook path with the trajectory blend -- both against the oracle."""
+    from audioeditingcode_amd.ddm_inversion import inversion_forward_process, inversion_reverse_process
+    T = 6
+    m = _model(T)
+    ow = _oracle_wrapper(m, T)
+    w0 = torch.randn(1, 8, 32, 16, generator=torch.Generator().manual_seed(4)) * 0.7
+    torch.manual_seed(8)
+    _, zs, wts, _ = inversion_forward_process(m, w0, etas=1.0, prompts=["rain"], cfg_scales=[3.0],
+                                              num_inference_steps=T, numerical_fix=True)
+    xts0 = ow.sample_xts_from_x0(w0, T, generator=torch.Generator().manual_seed(8))
+    _, zs_o, xts_o = oloops.invert(ow, w0, m.encode_text(["rain"]), m.encode_text([""]), [3.0], T, xts=xts0)
+    tgt = m.encode_text(["jazz", "rock"])
+    for tstart in ([4, 4], [4, 3]):
+        w, _ = inversion_reverse_process(m, xT=wts, tstart=torch.tensor(tstart), fix_alpha=0.2, etas=1.0,
+                                         prompts=["jazz", "rock"], neg_prompts=[""], cfg_scales=[9.0, 6.0],
+                                         zs=zs[:max(tstart)], cutoff_points=[0.5])
+        w_o = oloops.edit(ow, xts_o, torch.tensor(tstart), tgt, m.encode_text([""]), [9.0, 6.0], zs_o[:max(tstart)],
+                          eta=1.0, n_prompts=2, cutoff_points=[0.5], fix_alpha=0.2)
+        assert rel(w, w_o) < 2e-3, (tstart, rel(w, w_o))
+
+
+def test_pc_extract_and_apply_on_the_product_stack_on_cpu(cpu_stack):
+    """main_pc_extract_inv.extract_pcs + main_pc_apply_drift.apply_pcs with their DEFAULT functions (product inversion,
+    pc_drift on the native wrapper API): runs end to end, window / layout / finiteness; the arithmetic of each piece is
+    pinned elsewhere (pc_cli.npz, test_pc_functions_on_the_real_wrapper_on_cpu)."""
+    from argparse import Namespace
+    from audioeditingcode_amd import main_pc_apply_drift as papply, main_pc_extract_inv as pext
+    T = 5
+    m = _model(T)
+    w0 = torch.randn(1, 8, 16, 16, generator=torch.Generator().manual_seed(5)) * 0.7
+    a = pext.finish_args(Namespace(seed=1, cfg_tar=3, model_id="tiny/audioldm2", init_aud=None, num_diffusion_steps=T,
+                                   source_prompt=["rain"], target_neg_prompt=[""], corr_to_swap=0.8, drift_start=4,
+                                   drift_end=2, results_path="unused", const=1e-2, n_evs=2, patch=None, iters=2, dry=False))
+    torch.manual_seed(1)
+    ck = pext.extract_pcs(m, w0, a)
+    ts = [int(t) for t in m.model.scheduler.timesteps]
+    assert sorted(ck["eigdata"].keys(), reverse=True) == ts[1:3]                # its 1, 2 of T = 5
+    assert all(torch.isfinite(e["eigvec"]).all() and (e["eigval"] > 0).all() for e in ck["eigdata"].values())
+    ap = Namespace(drift_start=4, drift_end=2, amount=1.5, use_specific_ts_pc=None, fix_alpha=None, fade_length=0.0,
+                   evs=[1, 2], combine_evs=False, evals_pt=None, rand_v=False, shift_x0_for_np=True, sub_iters=None)
+    out = papply.apply_pcs(m, {k: ck[k] for k in ("eigdata", "args", "corrs", "in_corrs", "latents", "in_norms", "xts")},
+                           ap, torch.device("cpu"))
+    assert out.shape == (2, 8, 16, 16) and torch.isfinite(out).all()
+    assert rel(out[0:1], ck["final"]) > 1e-3                                      # the drift moved the sample

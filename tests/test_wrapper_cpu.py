@@ -263,3 +263,13 @@ def test_pc_extract_and_apply_on_the_product_stack_on_cpu(cpu_stack):
                            ap, torch.device("cpu"))
     assert out.shape == (2, 8, 16, 16) and torch.isfinite(out).all()
     assert rel(out[0:1], ck["final"]) > 1e-3                                      # the drift moved the sample
+
+
+def test_product_tape_executor_fails_loudly_without_gpu():
+    """Without the test-side interpreter patch, running a tape on a CPU box raises -- there is no CPU execution path in
+    the product."""
+    tp = Tape("cpu")
+    x, y = torch.ones(4, 8), tp.alloc(4, 8)
+    tp.axpby(x, y, numel=32, a=2.0, b=0.0)
+    with pytest.raises(Exception):
+        tp.run()

@@ -364,8 +364,8 @@ __global__ __launch_bounds__(256) void attention_split_kernel(AttnParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Split-KV kernel, second generation (opt-in: op slot i14 = 2; NOT the default until it has been measured on
-// hardware -- written from the ISA of the kernel above at the end of round 1, when the GPU budget was spent).
+// Split-KV kernel, second generation (opt-in: op slot i14 = 2).  Written from the ISA of the kernel above at the end
+// of round 1; its parity tests pass on the MI355X, its speed has not been measured yet, so it is not the default.
 // Same tiling and arithmetic; what changes is where the time went in the ISA of the first version:
 //   * staging: every global_load there is followed by s_waitcnt vmcnt(0) + one ds_write (predicated loads in
 //     run-time-bounded loops are not batched by the compiler) -> D/4 dependent memory round trips per round.

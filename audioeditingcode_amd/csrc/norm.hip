@@ -218,8 +218,8 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const float* __restrict__
     }
 }
 // Second generation (opt-in: op slot i7 = 1): written from the ISA of the kernel above at the end of round 1; its
-// parity tests pass on the MI355X, its speed has not been measured yet, so it is not the default.  Same arithmetic in the same order (bit-identical sums);
-// the ISA of the first version waits on every load right where it is issued (run-time-bounded loop with one load
+// parity tests pass on the MI355X, its speed has not been measured yet, so it is not the default.  Same arithmetic
+// in the same order (bit-identical sums); the ISA of the first version waits on every load right where it is issued (run-time-bounded loop with one load
 // per trip), i.e. HW*C/(G*1024) dependent memory round trips per pass.  Here U loads are issued back to back
 // (clamped addresses, masked use) before anything is consumed.
 template <int U>

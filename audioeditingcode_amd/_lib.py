@@ -11,8 +11,8 @@ LIB_PATH = os.path.join(_HERE, "libaed.so")
 
 
 class aed_op(ctypes.Structure):
-    _fields_ = [("code", ctypes.c_int32), ("flags", ctypes.c_int32), ("i", ctypes.c_int32 * 32),
-                ("f", ctypes.c_float * 8), ("p", ctypes.c_void_p * 8)]
+    _fields_ = [("code", ctypes.c_int32), ("flags", ctypes.c_int32), ("i", ctypes.c_int32 * 40),
+                ("f", ctypes.c_float * 8), ("p", ctypes.c_void_p * 10)]
 
 
 # opcodes (include/aed.h enum aed_opcode)
@@ -65,7 +65,7 @@ def lib():
                      "aed_event_elapsed_ms", "aed_event_destroy", "aed_get_zs_from_xts",
                      "aed_reverse_step_with_custom_noise", "aed_sample_xts_from_x0", "aed_device_info"):
             getattr(L, name).restype = ci
-        if L.aed_version() != 1:
+        if L.aed_version() != 2:
             raise AedError("libaed.so ABI version mismatch")
         _lib = L
     return _lib

@@ -92,7 +92,7 @@ int aed_tape_profile(const aed_op* ops, int n, void* stream, float* ms_host) {
     }
     AED_CHECK_HIP(hipEventSynchronize(ev[n]));
     for (int k = 0; k < n; ++k) AED_CHECK_HIP(hipEventElapsedTime(&ms_host[k], ev[k], ev[k + 1]));
-    for (int k = 0; k <= n; ++k) hipEventDestroy(ev[k]);
+    for (int k = 0; k <= n; ++k) (void)hipEventDestroy(ev[k]);
     return 0;
 }
 
@@ -105,7 +105,7 @@ int aed_graph_end(void* stream, void** graph_exec_out) {
     AED_CHECK_HIP(hipStreamEndCapture((hipStream_t)stream, &graph));
     hipGraphExec_t exec = nullptr;
     hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    hipGraphDestroy(graph);
+    (void)hipGraphDestroy(graph);
     if (e != hipSuccess) {
         aed_set_error("hipGraphInstantiate: %s", hipGetErrorString(e));
         return 1;

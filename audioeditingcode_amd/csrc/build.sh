@@ -7,6 +7,7 @@ FLAGS="--offload-arch=$ARCH -O3 -std=c++17 -fPIC -Wno-unused-result"
 mkdir -p obj
 pids=()
 hipcc $FLAGS -c conv_gemm.hip -o obj/conv_gemm.o & pids+=($!)
+hipcc $FLAGS -c lin_gemm.hip -o obj/lin_gemm.o & pids+=($!)
 hipcc $FLAGS -c attention.hip -o obj/attention.o & pids+=($!)
 hipcc $FLAGS -c norm.hip -o obj/norm.o & pids+=($!)
 hipcc $FLAGS -ffp-contract=off -c elementwise.hip -o obj/elementwise.o & pids+=($!)

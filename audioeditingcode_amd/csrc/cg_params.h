@@ -1,0 +1,63 @@
+// cg_params.h -- kernel-side view of an AED_OP_CONV_GEMM record, shared by the two GEMM families:
+//   conv_gemm.hip : LDS-staged block-tile kernels (throughput regime: inversion batches, VAE, vocoder)
+//   lin_gemm.hip  : wave-split-K kernels with wave-private LDS staging (latency regime: the U-Net batch-2 edit loop)
+#pragma once
+#include "aed_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct CGParams {
+    const float* A;
+    const float* W;
+    const float* bias;
+    float* C;
+    const float* res;
+    const float* rowvec;
+    float* ws;
+    long long* dbg;          // optional in-kernel timeline (block 0, lane 0): s_memtime stamps
+    const float* A2;         // second A source (channels [C1, Cin) of every tap): the skip half of an up-block concat
+    float* stats;            // optional GroupNorm partial sums of the OUTPUT: [M/stats_rows][N][2] (sum, sum of squares)
+    int M, N, K;
+    int lda, ldc, ldr, ld_rv;
+    int IH, IW, OH, OW, Cin;
+    int KH, KW, stride, pad_h, pad_w, dil_h, dil_w, up;
+    int a_bs;
+    int vIH, vIW;            // virtual (nearest-upsampled) input grid actually convolved: <= IH<<up, IW<<up
+    int o_mul, o_add, o_len, out_bs;
+    int in_act, out_act, accumulate, ksplit;
+    int rpb;                 // output rows per batch item = OH*OW
+    int nchunks;             // ceil(K/BKT)
+    float in_slope, out_p, out_div;
+    int ln_mode;             // 1: A rows are LayerNorm inputs; W has gamma folded in, rowvec = sum_k W'[n,k], bias = W.beta (+bias)
+    float ln_eps;
+    int C1, lda2, a_bs2;     // two-source A: channel c < C1 comes from A (lda, a_bs), c >= C1 from A2 (lda2, a_bs2) at c - C1
+    int geglu;               // 1: W rows are packed [32 value | 32 gate] per 32 output features; out = value * gelu(gate)
+};
+
+__device__ __forceinline__ float in_transform(float v, int act, float slope) {
+    if (act == AED_ACT_SILU) return v / (1.0f + __expf(-v));
+    if (act == AED_ACT_LEAKY) return v > 0.0f ? v : v * slope;
+    return v;
+}
+
+__device__ __forceinline__ float gelu_exact(float g) { return 0.5f * g * (1.0f + erff(g * 0.70710678118654752440f)); }
+
+// general (one element per call) epilogue: bias, per-batch row vector, residual, activation, accumulate, row scatter
+__device__ __forceinline__ void store_out(const CGParams& p, int m, int n, float v) {
+    int b = m / p.rpb;
+    int q = m - b * p.rpb;
+    int o = q * p.o_mul + p.o_add;
+    if ((unsigned)o >= (unsigned)p.o_len) return;
+    size_t row = (size_t)b * p.out_bs + o;
+    if (p.bias) v += p.bias[n];
+    if (p.rowvec && !p.ln_mode) v += p.rowvec[(size_t)b * p.ld_rv + n];
+    if (p.res) v += p.res[row * p.ldr + n];
+    v = aed_apply_act(v, p.out_act, p.out_p);
+    float* dst = p.C + row * p.ldc + n;
+    if (p.accumulate == 1) v += *dst;
+    else if (p.accumulate == 2) v = (*dst + v) / p.out_div;
+    *dst = v;
+}
+
+int cg_fill_params(const aed_op* op, CGParams& p, int bkt);
+int launch_lin_gemm(const CGParams& p, int cfg, hipStream_t s);

@@ -21,56 +21,7 @@
 // At the batch sizes of the edit loop (U-Net batch 2) most launches are a few microseconds of MFMA
 // work, so the kernel is written for LATENCY: 32-bit offsets, no per-chunk integer divisions, one
 // batch of residual loads in the epilogue (measured with the in-kernel s_memtime timeline, p.dbg).
-#include "aed_common.h"
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-struct CGParams {
-    const float* A;
-    const float* W;
-    const float* bias;
-    float* C;
-    const float* res;
-    const float* rowvec;
-    float* ws;
-    long long* dbg;          // optional in-kernel timeline (block 0, lane 0): s_memtime stamps
-    int M, N, K;
-    int lda, ldc, ldr, ld_rv;
-    int IH, IW, OH, OW, Cin;
-    int KH, KW, stride, pad_h, pad_w, dil_h, dil_w, up;
-    int a_bs;
-    int vIH, vIW;            // virtual (nearest-upsampled) input grid actually convolved: <= IH<<up, IW<<up
-    int o_mul, o_add, o_len, out_bs;
-    int in_act, out_act, accumulate, ksplit;
-    int rpb;                 // output rows per batch item = OH*OW
-    int nchunks;             // ceil(K/BKT)
-    float in_slope, out_p, out_div;
-    int ln_mode;             // 1: A rows are LayerNorm inputs; W has gamma folded in, rowvec = sum_k W'[n,k], bias = W.beta (+bias)
-    float ln_eps;
-};
-
-__device__ __forceinline__ float in_transform(float v, int act, float slope) {
-    if (act == AED_ACT_SILU) return v / (1.0f + __expf(-v));
-    if (act == AED_ACT_LEAKY) return v > 0.0f ? v : v * slope;
-    return v;
-}
-
-// shared by the split-K reduce kernel (one element per thread: the slow general form is fine there)
-__device__ __forceinline__ void store_out(const CGParams& p, int m, int n, float v) {
-    int b = m / p.rpb;
-    int q = m - b * p.rpb;
-    int o = q * p.o_mul + p.o_add;
-    if ((unsigned)o >= (unsigned)p.o_len) return;
-    size_t row = (size_t)b * p.out_bs + o;
-    if (p.bias) v += p.bias[n];
-    if (p.rowvec && !p.ln_mode) v += p.rowvec[(size_t)b * p.ld_rv + n];
-    if (p.res) v += p.res[row * p.ldr + n];
-    v = aed_apply_act(v, p.out_act, p.out_p);
-    float* dst = p.C + row * p.ldc + n;
-    if (p.accumulate == 1) v += *dst;
-    else if (p.accumulate == 2) v = (*dst + v) / p.out_div;
-    *dst = v;
-}
+#include "cg_params.h"
 
 // PLAIN: the A operand needs no transform (no loader activation, no LayerNorm statistics) -- the common case.
 // MINW: waves per SIMD the register allocation must leave room for (2 blocks per CU for the 128x128 tile).
@@ -126,7 +77,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 1) void conv_gemm
 
     // per-row gather state (32-bit element offsets: every tensor on the path is < 2^31 elements)
     int ay0[PA], ax0[PA];
-    unsigned abase[PA];
+    unsigned abase[PA], abase2[PA];
     bool avalid[PA];
 #pragma unroll
     for (int q = 0; q < PA; ++q) {
@@ -140,6 +91,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 1) void conv_gemm
         ay0[q] = oy * p.stride - p.pad_h;
         ax0[q] = ox * p.stride - p.pad_w;
         abase[q] = (unsigned)b * (unsigned)p.a_bs + lcol;
+        abase2[q] = (unsigned)b * (unsigned)p.a_bs2 + lcol;
     }
     unsigned wbase[PB];
     bool wvalid[PB];
@@ -170,13 +122,18 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 1) void conv_gemm
     auto prefetch = [&](int kc, float4 (&ra)[PA], float4 (&rb)[PB], unsigned& mask) {
         const int k0 = min(kc, p.nchunks - 1) * BKT;      // dead prefetches past the end stay in bounds
         if constexpr (!GENERIC) {
-            const int c0 = pf_c0;
+            int c0 = pf_c0;
             const int dy = pf_ty * p.dil_h, dx = pf_tx * p.dil_w;
             pf_c0 += BKT;
             if (pf_c0 >= p.Cin) {
                 pf_c0 = 0;
                 if (++pf_tx == p.KW) { pf_tx = 0; ++pf_ty; }
             }
+            // two-source A (an up-block concat that is never materialised): block-uniform select per chunk
+            const float* src = p.A;
+            unsigned ld = (unsigned)p.lda;
+            const bool second = p.C1 > 0 && c0 >= p.C1;
+            if (second) { src = p.A2; ld = (unsigned)p.lda2; c0 -= p.C1; }
             unsigned mk = 0;
 #pragma unroll
             for (int q = 0; q < PA; ++q) {
@@ -185,8 +142,9 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 1) void conv_gemm
                 // clamped, always-valid address; the zero padding is applied at the LDS write so that the
                 // raw load stays in flight (nothing consumes it here)
                 const int cy = ok ? (iy >> p.up) : 0, cx = ok ? (ix >> p.up) : 0;
-                const unsigned off = abase[q] + (unsigned)(cy * p.IW + cx) * (unsigned)p.lda + c0;
-                ra[q] = *reinterpret_cast<const float4*>(p.A + (ok ? off : (unsigned)lcol));
+                const unsigned base = second ? abase2[q] : abase[q];
+                const unsigned off = base + (unsigned)(cy * p.IW + cx) * ld + c0;
+                ra[q] = *reinterpret_cast<const float4*>(src + (ok ? off : (unsigned)lcol));
                 mk |= ok ? (1u << q) : 0u;
             }
             mask = mk;
@@ -366,6 +324,43 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 1) void conv_gemm
     // Straight-line: every flag is kernel-uniform, every address is clamped in-bounds, so the residual /
     // previous-value loads of a tile issue as one batch (C may alias the residual: a per-element
     // load->store chain costs ~25k cycles).
+    if constexpr (TN % 2 == 0) {
+        if (p.geglu) {
+            // FF1 of a transformer block with the GEGLU gate fused: the host packs W rows as [32 value | 32 gate] per 32
+            // output features, so sub-tiles (b, b+1) of one wave hold value and gate of the same features
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; b += 2) {
+                    const int nv = n0 + wc * WN + b * 32 + fi, ng = nv + 32;
+                    const int mbase = m0 + wr * WM + a * 32 + 4 * fh;
+                    if (ng >= p.N) continue;
+                    const float bv = p.bias ? p.bias[nv] : 0.f, bg = p.bias ? p.bias[ng] : 0.f;
+                    const float sv = p.ln_mode ? p.rowvec[nv] : 0.f, sg = p.ln_mode ? p.rowvec[ng] : 0.f;
+                    const int nf = ((n0 + wc * WN + b * 32) >> 1) + fi;      // output feature column
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int dm = (r & 3) + 8 * (r >> 2);
+                        const int m = mbase + dm;
+                        float val = acc[a][b][r], gate = acc[a][b + 1][r];
+                        if (p.ln_mode) {
+                            const int lr = wr * WM + a * 32 + 4 * fh + dm;
+                            const float mean = ln_stat[2 * lr], rstd = ln_stat[2 * lr + 1];
+                            val = rstd * (val - mean * sv);
+                            gate = rstd * (gate - mean * sg);
+                        }
+                        val += bv;
+                        gate += bg;
+                        if (m < p.M) {
+                            const int bb = m / p.rpb;
+                            const unsigned row = (unsigned)bb * (unsigned)p.out_bs + (unsigned)(m - bb * p.rpb);
+                            p.C[row * (unsigned)p.ldc + nf] = val * gelu_exact(gate);
+                        }
+                    }
+                }
+            return;
+        }
+    }
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -593,7 +588,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(CGParams p) {
     }
 }
 
-static int fill_params(const aed_op* op, CGParams& p, int bkt) {
+int cg_fill_params(const aed_op* op, CGParams& p, int bkt) {
     p.A = (const float*)op->p[0];
     p.W = (const float*)op->p[1];
     p.bias = (const float*)op->p[2];
@@ -610,6 +605,9 @@ static int fill_params(const aed_op* op, CGParams& p, int bkt) {
     p.in_act = i[25]; p.out_act = i[26]; p.accumulate = i[27]; p.ksplit = i[28];
     p.in_slope = op->f[0]; p.out_p = op->f[1]; p.out_div = op->f[2];
     p.ln_mode = i[31]; p.ln_eps = op->f[3];
+    p.C1 = i[32]; p.lda2 = i[33]; p.a_bs2 = i[34]; p.geglu = i[35];
+    p.A2 = (const float*)op->p[8];
+    p.stats = (float*)op->p[9];
     p.rpb = p.OH * p.OW;
     p.nchunks = (p.K + bkt - 1) / bkt;
     p.vIH = p.IH << p.up;
@@ -638,6 +636,14 @@ static int fill_params(const aed_op* op, CGParams& p, int bkt) {
     if (p.ln_mode)
         AED_REQUIRE(p.ksplit == 1 && p.KH * p.KW == 1 && p.rowvec && p.bias && p.in_act == 0,
                     "conv_gemm: fused LayerNorm needs a 1-tap, unsplit GEMM with folded weights");
+    if (p.C1 > 0)
+        AED_REQUIRE(p.A2 && p.C1 % 64 == 0 && p.C1 < p.Cin && p.lda2 % 4 == 0 && ((uintptr_t)p.A2 % 16) == 0 &&
+                        (long long)(p.M / p.rpb) * p.a_bs2 + (long long)p.IH * p.IW * p.lda2 < (1LL << 31),
+                    "conv_gemm: bad two-source split C1=%d of Cin=%d", p.C1, p.Cin);
+    if (p.geglu)
+        AED_REQUIRE(p.ksplit == 1 && p.N % 64 == 0 && !p.res && p.out_act == 0 && p.accumulate == 0 && p.o_mul == 1 &&
+                        p.o_add == 0 && (p.ln_mode || !p.rowvec),
+                    "conv_gemm: the GEGLU epilogue needs an unsplit GEMM with packed N %% 64 == 0 and a plain epilogue");
     return 0;
 }
 
@@ -666,6 +672,11 @@ int launch_conv_gemm(const aed_op* op, hipStream_t s) {
                          ((uintptr_t)op->p[1] % 16 != 0);
     int cfg = i[29];
     if (cfg == 3) cfg = 2;
+    if (cfg >= 10) {                 // latency-regime kernels (lin_gemm.hip)
+        int rc = cg_fill_params(op, p, 32);
+        if (rc) return rc;
+        return launch_lin_gemm(p, cfg, s);
+    }
     if (cfg == 0) {
         const int cus = aed_num_cus();
         const int M = i[0], N = i[1], ks = i[28] > 1 ? i[28] : 1;
@@ -681,9 +692,11 @@ int launch_conv_gemm(const aed_op* op, hipStream_t s) {
     // K chunk: 32 (two LDS stages of a 128x128 tile = 72 KB -> two blocks per CU); 64 for the 64x64 tile when the
     // channel count allows (half the barriers, still two blocks per CU)
     const bool bk64 = !generic && (Cin % 64 == 0) && i[30] != 1 && cfg == 4;
-    int rc = fill_params(op, p, cfg == 7 ? 8 : (bk64 ? 64 : 32));
+    int rc = cg_fill_params(op, p, cfg == 7 ? 8 : (bk64 ? 64 : 32));
     if (rc) return rc;
     const bool plain = p.in_act == 0 && p.ln_mode == 0;
+    if (p.geglu) AED_REQUIRE(cfg == 1, "conv_gemm: the GEGLU epilogue exists for the 128x128 tile (cfg %d)", cfg);
+    if (p.C1 > 0) AED_REQUIRE(!generic && cfg != 7, "conv_gemm: two-source A needs the vector path of a tiled kernel");
     switch (cfg) {
         case 1: launch_cfg<128, 128, 2, 2, 2, 32>(p, plain, s); break;
         case 2: launch_cfg<128, 64, 2, 2, 2, 32>(p, plain, s); break;
@@ -721,7 +734,7 @@ int launch_conv_gemm(const aed_op* op, hipStream_t s) {
 
 int launch_splitk_reduce(const aed_op* op, hipStream_t s) {
     CGParams p;
-    int rc = fill_params(op, p, 32);
+    int rc = cg_fill_params(op, p, 32);
     if (rc) return rc;
     size_t total = (size_t)p.M * p.N;
     int grid = (int)((total + 255) / 256);

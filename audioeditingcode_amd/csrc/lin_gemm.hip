@@ -1,0 +1,340 @@
+// lin_gemm.hip -- latency-regime GEMM / small convolution on the fp32 matrix cores of gfx950.
+//
+// The reverse (edit) loop of the reference runs the U-Net at batch 2 (inversion_utils.py:221-315: one uncond and one
+// cond sample per step), one hundred dependent times per clip.  At that batch most of the ~450 contractions of a
+// forward are a few hundred 32x32 output tiles with K of a few hundred: microseconds of MFMA work whose duration is
+// set by how fast the operands arrive, not by the matrix pipe.  Round 1's wave-split-K kernel fed the MFMAs with
+// lane=row loads (64 cache-line requests per instruction, 16 useful bytes per line per request) and spent ~10k of
+// its ~22k cycles in the texture address path.  This kernel keeps its decomposition and fixes the feed:
+//
+//   * a workgroup of NW wavefronts owns ONE (32*TM) x (32*TN) output tile; the wavefronts split K;
+//   * every wavefront stages ITS K-slice of the A and W tiles through a wave-private LDS slab with fully coalesced
+//     16-byte loads (8 lanes cover 128 contiguous bytes of one row, 8 rows per instruction), two 32-wide K chunks in
+//     flight in registers; no workgroup barrier inside the main loop (LDS operations of one wave execute in order);
+//   * MFMA fragments come from the padded slab (conflict-free ds_read_b128), v_mfma_f32_32x32x2_f32 chains;
+//   * the NW partial tiles meet once in LDS, are summed in a fixed order (deterministic) and every thread finishes
+//     its outputs with coalesced stores: bias, per-batch time-embedding row, residual, activation, the folded
+//     LayerNorm, and the fused GEGLU gate (value and gate columns are packed side by side, TN = 2).
+//   * A(m,k) supports the same implicit-GEMM gather as conv_gemm.hip (taps, stride, padding, dilation, nearest
+//     upsample) and a two-source channel split, so up-block concatenations are never materialised.
+//
+// Same arithmetic contract as conv_gemm.hip: exact fp32 FMA chains, fixed summation order per (tile config).
+#include "cg_params.h"
+
+// ordering of a wave's own LDS traffic: the hardware executes one wave's DS operations in issue order; this only
+// pins the compiler (a memory clobber on an empty asm, no instruction)
+#define LDS_ORDER() asm volatile("" ::: "memory")
+
+template <int NW, int TM, int TN, int DEPTH>
+__global__ __launch_bounds__(64 * NW) void lin_gemm_kernel(CGParams p) {
+    constexpr int CH = 32;                        // K per chunk
+    constexpr int LD = CH + 4;                    // padded LDS row (floats)
+    constexpr int AR = 32 * TM, WR = 32 * TN;     // tile rows of A / of W
+    constexpr int WAVE_LDS = (AR + WR) * LD;      // floats of one wave's slab (>= TM*TN*1024: the partial tiles fit)
+    constexpr int PA = AR / 8, PW = WR / 8;       // float4 loads per lane and chunk (8 rows per wave instruction)
+    static_assert(WAVE_LDS >= TM * TN * 1024, "partial tiles must fit the staging slab");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ float ln_part[NW][AR][2];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fi = lane & 31, fh = lane >> 5;
+    const int lrow = lane >> 3, lseg = (lane & 7) * 4;
+    float* slab = smem + wave * WAVE_LDS;
+    float* As = slab;
+    float* Ws = slab + AR * LD;
+
+    // XCD-aware tile order (see conv_gemm.hip): XCD x gets a contiguous range of tile ids, n fastest, so the tiles that
+    // share an A row panel share one L2.
+    int tile_x, tile_y;
+    {
+        const unsigned nx = gridDim.x, nwg = nx * gridDim.y;
+        const unsigned orig = blockIdx.y * nx + blockIdx.x;
+        const unsigned xcd = orig & 7u, q = nwg >> 3, r = nwg & 7u;
+        const unsigned id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+        tile_y = (int)(id / nx);
+        tile_x = (int)(id - (unsigned)tile_y * nx);
+    }
+    const int m0 = tile_y * AR;
+    const int n0 = tile_x * WR;                   // packed W row of the tile (GEGLU: 64 packed rows = 32 features)
+
+    // this wave's range of 32-wide K chunks
+    const int nch = p.K / CH;
+    const int cbase = nch / NW, crem = nch % NW;
+    const int c_begin = wave * cbase + min(wave, crem);
+    const int c_end = c_begin + cbase + (wave < crem ? 1 : 0);
+
+    // loader rows of this lane
+    int ay0[PA], ax0[PA], ab[PA];
+    bool avalid[PA];
+#pragma unroll
+    for (int j = 0; j < PA; ++j) {
+        const int m = m0 + lrow + 8 * j;
+        avalid[j] = m < p.M;
+        const int mm = avalid[j] ? m : 0;
+        const int b = mm / p.rpb;
+        const int r = mm - b * p.rpb;
+        const int oy = r / p.OW, ox = r - oy * p.OW;
+        ay0[j] = oy * p.stride - p.pad_h;
+        ax0[j] = ox * p.stride - p.pad_w;
+        ab[j] = b;
+    }
+    unsigned woff[PW];
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+        const int n = min(n0 + lrow + 8 * j, p.N - 1);      // rows past N compute garbage columns that are never stored
+        woff[j] = (unsigned)n * (unsigned)p.K + lseg;
+    }
+    const int vIH = p.vIH, vIW = p.vIW;
+    // running (tap, channel) position of the next chunk to prefetch
+    int pf_c0, pf_ty, pf_tx;
+    {
+        const int k0 = c_begin * CH;
+        const int tap = k0 / p.Cin;
+        pf_c0 = k0 - tap * p.Cin;
+        pf_ty = tap / p.KW;
+        pf_tx = tap - pf_ty * p.KW;
+    }
+
+    float4 ra[DEPTH][PA], rw[DEPTH][PW];
+    unsigned rmask[DEPTH];
+
+    auto prefetch = [&](int kc, float4 (&a)[PA], float4 (&w)[PW], unsigned& mask) {
+        const int k0 = min(kc, nch - 1) * CH;               // dead prefetches past the end stay in bounds
+        const int dy = pf_ty * p.dil_h, dx = pf_tx * p.dil_w;
+        int c0 = pf_c0;
+        pf_c0 += CH;
+        if (pf_c0 >= p.Cin) {
+            pf_c0 = 0;
+            if (++pf_tx == p.KW) { pf_tx = 0; ++pf_ty; }
+        }
+        // wave-uniform source select (C1 is a multiple of the chunk width)
+        const float* src = p.A;
+        int ld = p.lda, bs = p.a_bs;
+        if (p.C1 > 0 && c0 >= p.C1) { src = p.A2; ld = p.lda2; bs = p.a_bs2; c0 -= p.C1; }
+        unsigned mk = 0;
+#pragma unroll
+        for (int j = 0; j < PA; ++j) {
+            const int iy = ay0[j] + dy, ix = ax0[j] + dx;
+            const bool ok = avalid[j] & ((unsigned)iy < (unsigned)vIH) & ((unsigned)ix < (unsigned)vIW);
+            const int cy = ok ? (iy >> p.up) : 0, cx = ok ? (ix >> p.up) : 0;
+            const unsigned off = (unsigned)ab[j] * (unsigned)bs + (unsigned)(cy * p.IW + cx) * (unsigned)ld + c0 + lseg;
+            a[j] = *reinterpret_cast<const float4*>(src + (ok ? off : (unsigned)lseg));
+            mk |= ok ? (1u << j) : 0u;
+        }
+        mask = mk;
+#pragma unroll
+        for (int j = 0; j < PW; ++j) w[j] = *reinterpret_cast<const float4*>(p.W + woff[j] + k0);
+    };
+
+    auto stage_write = [&](const float4 (&a)[PA], const float4 (&w)[PW], unsigned mask) {
+#pragma unroll
+        for (int j = 0; j < PA; ++j) {
+            float4 v = a[j];
+            if (!((mask >> j) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.in_act) {
+                v.x = in_transform(v.x, p.in_act, p.in_slope);
+                v.y = in_transform(v.y, p.in_act, p.in_slope);
+                v.z = in_transform(v.z, p.in_act, p.in_slope);
+                v.w = in_transform(v.w, p.in_act, p.in_slope);
+            }
+            *reinterpret_cast<float4*>(As + (lrow + 8 * j) * LD + lseg) = v;
+        }
+#pragma unroll
+        for (int j = 0; j < PW; ++j) {
+            const float4 v = w[j];
+            *reinterpret_cast<float4*>(Ws + (lrow + 8 * j) * LD + lseg) = make_float4(v.x, v.y, v.z, v.w);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float ln_s1[TM], ln_s2[TM];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) { ln_s1[a] = 0.f; ln_s2[a] = 0.f; }
+
+    const float* a_frag = As + fi * LD + 4 * fh;
+    const float* b_frag = Ws + fi * LD + 4 * fh;
+
+    auto mfma_chunk = [&]() {
+#pragma unroll
+        for (int kb = 0; kb < CH / 8; ++kb) {
+            float4 af[TM], bf[TN];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) af[a] = *reinterpret_cast<const float4*>(a_frag + a * 32 * LD + 8 * kb);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) bf[b] = *reinterpret_cast<const float4*>(b_frag + b * 32 * LD + 8 * kb);
+            if (p.ln_mode) {
+#pragma unroll
+                for (int a = 0; a < TM; ++a) {
+                    ln_s1[a] += (af[a].x + af[a].y) + (af[a].z + af[a].w);
+                    ln_s2[a] += (af[a].x * af[a].x + af[a].y * af[a].y) + (af[a].z * af[a].z + af[a].w * af[a].w);
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].x, bf[b].x, acc[a][b], 0, 0, 0);
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].y, bf[b].y, acc[a][b], 0, 0, 0);
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].z, bf[b].z, acc[a][b], 0, 0, 0);
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].w, bf[b].w, acc[a][b], 0, 0, 0);
+        }
+    };
+
+    // every prefetch is unconditional (clamped addresses): the number of loads in flight is static
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) prefetch(c_begin + d, ra[d], rw[d], rmask[d]);
+    for (int kc0 = c_begin; kc0 < c_end; kc0 += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const int kc = kc0 + d;
+            if (kc >= c_end) break;
+            stage_write(ra[d], rw[d], rmask[d]);
+            prefetch(kc + DEPTH, ra[d], rw[d], rmask[d]);
+            // the slab is wave-private: LDS operations of one wave complete in issue order; only keep the compiler from
+            // moving the fragment reads above the staging writes (and the next writes above these reads)
+            LDS_ORDER();
+            __builtin_amdgcn_wave_barrier();
+            mfma_chunk();
+            LDS_ORDER();
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+
+    // ---- partial tiles -> this wave's own slab.  acc[a][b][r] = C[row (r&3)+8*(r>>2)+4*fh][col fi] of tile (a,b)
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) slab[((a * TN + b) * 16 + r) * 64 + lane] = acc[a][b][r];
+    if (p.ln_mode) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            const float s1 = ln_s1[a] + __shfl_xor(ln_s1[a], 32, 64);
+            const float s2 = ln_s2[a] + __shfl_xor(ln_s2[a], 32, 64);
+            if (fh == 0) { ln_part[wave][a * 32 + fi][0] = s1; ln_part[wave][a * 32 + fi][1] = s2; }
+        }
+    }
+    __syncthreads();
+
+    // ---- finish: thread t owns column t & 31 of rows (t >> 5) + 2*NW*i of every 32x32 sub-tile
+    const int col = tid & 31;
+    constexpr int RSTEP = 2 * NW;
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+        for (int row = tid >> 5; row < 32; row += RSTEP) {
+            const int h = (row >> 2) & 1;
+            const int r = (row & 3) + 4 * (row >> 3);
+            const int src_lane = col + 32 * h;
+            const int mo = m0 + a * 32 + row;
+            float mean = 0.f, rstd = 1.f;
+            if (p.ln_mode) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) { s1 += ln_part[w][a * 32 + row][0]; s2 += ln_part[w][a * 32 + row][1]; }
+                mean = s1 / (float)p.K;
+                const float var = fmaxf(s2 / (float)p.K - mean * mean, 0.f);
+                rstd = 1.0f / sqrtf(var + p.ln_eps);
+            }
+            float v[TN];
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) s += smem[w * WAVE_LDS + ((a * TN + b) * 16 + r) * 64 + src_lane];
+                v[b] = s;
+            }
+            if (mo >= p.M) continue;
+            if (p.geglu) {
+                // packed columns: sub-tile 2q holds 32 value columns, sub-tile 2q+1 the matching 32 gate columns
+#pragma unroll
+                for (int b = 0; b + 1 < TN; b += 2) {
+                    const int nv = n0 + b * 32 + col, ng = nv + 32;
+                    if (ng >= p.N) continue;
+                    float val = v[b], gate = v[b + 1];
+                    if (p.ln_mode) {
+                        val = rstd * (val - mean * p.rowvec[nv]);
+                        gate = rstd * (gate - mean * p.rowvec[ng]);
+                    }
+                    if (p.bias) { val += p.bias[nv]; gate += p.bias[ng]; }
+                    const int b0 = mo / p.rpb;
+                    const size_t orow = (size_t)b0 * p.out_bs + (mo - b0 * p.rpb);
+                    p.C[orow * p.ldc + (n0 >> 1) + b * 16 + col] = val * gelu_exact(gate);
+                }
+            } else {
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    const int no = n0 + b * 32 + col;
+                    if (no >= p.N) continue;
+                    float val = v[b];
+                    if (p.ln_mode) val = rstd * (val - mean * p.rowvec[no]);
+                    store_out(p, mo, no, val);
+                }
+            }
+        }
+    }
+}
+
+template <int NW, int TM, int TN, int DEPTH>
+static int launch_lin(const CGParams& p, hipStream_t s) {
+    constexpr int WAVE_LDS = (32 * TM + 32 * TN) * 36;
+    const size_t bytes = sizeof(float) * NW * WAVE_LDS;
+    static bool attr_set = false;
+    if (!attr_set) {
+        AED_CHECK_HIP(hipFuncSetAttribute((const void*)lin_gemm_kernel<NW, TM, TN, DEPTH>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        attr_set = true;
+    }
+    dim3 grid(aed_cdiv(p.N, 32 * TN), aed_cdiv(p.M, 32 * TM), 1);
+    hipLaunchKernelGGL((lin_gemm_kernel<NW, TM, TN, DEPTH>), grid, dim3(64 * NW), bytes, s, p);
+    return 0;
+}
+
+// cfg: 10 = 4 waves 32x32 | 11 = 8 waves 32x32 | 12 = 16 waves 32x32 | 13 = 4 waves 32x64 | 14 = 8 waves 32x64 |
+//      15 = 4 waves 64x64 | 16 = 4 waves 64x32 | 17 = 8 waves 64x64
+int launch_lin_gemm(const CGParams& p, int cfg, hipStream_t s) {
+    AED_REQUIRE(p.Cin % 32 == 0 && p.lda % 4 == 0 && ((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.W % 16) == 0,
+                "lin_gemm: needs Cin %% 32 == 0 and 16-byte aligned operands (Cin=%d lda=%d)", p.Cin, p.lda);
+    AED_REQUIRE(p.ksplit <= 1 && p.accumulate == 0 || !p.geglu, "lin_gemm: GEGLU epilogue cannot split or accumulate");
+    AED_REQUIRE(p.ksplit <= 1, "lin_gemm: K is split across the wavefronts of a workgroup, not across workgroups");
+    if (p.C1 > 0)
+        AED_REQUIRE(p.A2 && p.C1 % 32 == 0 && p.C1 < p.Cin && p.lda2 % 4 == 0 && ((uintptr_t)p.A2 % 16) == 0,
+                    "lin_gemm: bad two-source split C1=%d of Cin=%d", p.C1, p.Cin);
+    if (p.geglu)
+        AED_REQUIRE(p.N % 64 == 0 && (cfg == 13 || cfg == 14 || cfg == 15 || cfg == 17) && !p.res && p.out_act == 0 &&
+                        p.o_mul == 1 && p.o_add == 0 && (p.ln_mode || !p.rowvec),
+                    "lin_gemm: GEGLU needs a 64-wide tile (cfg %d), packed N %% 64 == 0 and a plain epilogue", cfg);
+    int rc = 0;
+    switch (cfg) {
+        case 10: rc = launch_lin<4, 1, 1, 2>(p, s); break;
+        case 11: rc = launch_lin<8, 1, 1, 2>(p, s); break;
+        case 12: rc = launch_lin<16, 1, 1, 1>(p, s); break;
+        case 13: rc = launch_lin<4, 1, 2, 2>(p, s); break;
+        case 14: rc = launch_lin<8, 1, 2, 2>(p, s); break;
+        case 15: rc = launch_lin<4, 2, 2, 1>(p, s); break;
+        case 16: rc = launch_lin<4, 2, 1, 2>(p, s); break;
+        case 17: rc = launch_lin<8, 2, 2, 1>(p, s); break;
+        default: AED_REQUIRE(false, "lin_gemm: bad tile cfg %d", cfg);
+    }
+    if (rc) return rc;
+    AED_CHECK_HIP(hipGetLastError());
+    return 0;
+}

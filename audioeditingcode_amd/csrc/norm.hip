@@ -9,6 +9,13 @@
 // LayerNorm: one 64-lane wavefront per token, two-pass variance, DPP/shuffle reductions.
 #include "aed_common.h"
 
+// Two-source rows: channel c < C1 of row `row` lives in x (stride ldx), c >= C1 in x2 (stride ldx2) at c - C1 -- the
+// (h | skip) concat of an up-block resnet (models.py:349-357 torch.cat) is never materialised.  c is a multiple of 4.
+__device__ __forceinline__ const float* gn_src(const float* x, const float* x2, int C1, int ldx, int ldx2, size_t row,
+                                               int c) {
+    return (x2 != nullptr && c >= C1) ? x2 + row * ldx2 + (c - C1) : x + row * ldx + c;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -17,7 +24,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, float* __restrict__ part,
-                                                        int HW, int C, int G, int ldx, int rpc, int nchunks) {
+                                                        int HW, int C, int G, int ldx, int rpc, int nchunks,
+                                                        const float* __restrict__ x2, int C1, int ldx2) {
     __shared__ float sh[256][2];
     __shared__ float gacc[64][2];
     const int tid = threadIdx.x;
@@ -35,7 +43,8 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
         float s = 0.f, ss = 0.f;
         if (rsub < rpi) {
             for (int r = row0 + rsub; r < row1; r += rpi) {
-                const float4 v = *reinterpret_cast<const float4*>(x + ((size_t)b * HW + r) * ldx + 4 * (cbase + col));
+                const float4 v = *reinterpret_cast<const float4*>(
+                    gn_src(x, x2, C1, ldx, ldx2, (size_t)b * HW + r, 4 * (cbase + col)));
                 s += (v.x + v.y) + (v.z + v.w);
                 ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
             }
@@ -67,7 +76,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float* __restrict__ y,
                                                         int HW, int C, int G, int ldx, int ldy, int rpc, int nchunks,
-                                                        float eps, int act) {
+                                                        float eps, int act, const float* __restrict__ x2, int C1,
+                                                        int ldx2) {
     // rpc here is the APPLY slab height; nchunks the number of STATS partials per batch item.
     __shared__ double red_s[256], red_ss[256];
     __shared__ float mean_s[64], rstd_s[64];
@@ -108,7 +118,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
         const int c4 = e - r * Q;
         const int g = c4 / cpg4;
         const size_t row = (size_t)b * HW + row0 + r;
-        float4 v = *reinterpret_cast<const float4*>(x + row * ldx + 4 * c4);
+        float4 v = *reinterpret_cast<const float4*>(gn_src(x, x2, C1, ldx, ldx2, row, 4 * c4));
         const float4 ga = *reinterpret_cast<const float4*>(gamma + 4 * c4);
         const float4 be = *reinterpret_cast<const float4*>(beta + 4 * c4);
         const float m = mean_s[g], rs = rstd_s[g];
@@ -172,17 +182,18 @@ __global__ __launch_bounds__(256) void gn_scale_shift_kernel(const float* __rest
 // instead of two is what matters; large maps (VAE) keep the two-pass streaming kernels above.
 __global__ __launch_bounds__(256) void gn_small_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float* __restrict__ y, int HW,
-                                                        int C, int G, int ldx, int ldy, float eps, int act) {
+                                                        int C, int G, int ldx, int ldy, float eps, int act,
+                                                        const float* __restrict__ x2, int C1, int ldx2) {
     __shared__ double rs[4], rss[4];
     const int tid = threadIdx.x, g = blockIdx.x, b = blockIdx.y;
     const int cpg = C / G, cpg4 = cpg >> 2;
-    const float* xb = x + (size_t)b * HW * ldx + g * cpg;
+    const size_t rb = (size_t)b * HW;
     float* yb = y + (size_t)b * HW * ldy + g * cpg;
     const int total = HW * cpg4;
     float s = 0.f, ss = 0.f;
     for (int e = tid; e < total; e += 256) {
         const int row = e / cpg4, j = e - row * cpg4;
-        const float4 v = *reinterpret_cast<const float4*>(xb + (size_t)row * ldx + 4 * j);
+        const float4 v = *reinterpret_cast<const float4*>(gn_src(x, x2, C1, ldx, ldx2, rb + row, g * cpg + 4 * j));
         s += (v.x + v.y) + (v.z + v.w);
         ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
     }
@@ -201,7 +212,7 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const float* __restrict__
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     for (int e = tid; e < total; e += 256) {
         const int row = e / cpg4, j = e - row * cpg4;
-        float4 v = *reinterpret_cast<const float4*>(xb + (size_t)row * ldx + 4 * j);
+        float4 v = *reinterpret_cast<const float4*>(gn_src(x, x2, C1, ldx, ldx2, rb + row, g * cpg + 4 * j));
         const float4 ga = *reinterpret_cast<const float4*>(gamma + g * cpg + 4 * j);
         const float4 be = *reinterpret_cast<const float4*>(beta + g * cpg + 4 * j);
         v.x = (v.x - mean) * rstd * ga.x + be.x;
@@ -225,11 +236,12 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const float* __restrict__
 template <int U>
 __global__ __launch_bounds__(256) void gn_small2_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float* __restrict__ y, int HW,
-                                                         int C, int G, int ldx, int ldy, float eps, int act) {
+                                                         int C, int G, int ldx, int ldy, float eps, int act,
+                                                         const float* __restrict__ x2, int C1, int ldx2) {
     __shared__ double rs[4], rss[4];
     const int tid = threadIdx.x, g = blockIdx.x, b = blockIdx.y;
     const int cpg = C / G, cpg4 = cpg >> 2;
-    const float* xb = x + (size_t)b * HW * ldx + g * cpg;
+    const size_t rb = (size_t)b * HW;
     float* yb = y + (size_t)b * HW * ldy + g * cpg;
     const int total = HW * cpg4;
     float s = 0.f, ss = 0.f;
@@ -240,7 +252,7 @@ __global__ __launch_bounds__(256) void gn_small2_kernel(const float* __restrict_
         for (int u = 0; u < U; ++u) {
             const int e = min(e0 + 256 * u, total - 1);
             const int row = e / cpg4, j = e - row * cpg4;
-            src[u] = xb + (size_t)row * ldx + 4 * j;
+            src[u] = gn_src(x, x2, C1, ldx, ldx2, rb + row, g * cpg + 4 * j);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const float4*>(src[u]);
@@ -277,7 +289,7 @@ __global__ __launch_bounds__(256) void gn_small2_kernel(const float* __restrict_
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            v[u] = *reinterpret_cast<const float4*>(xb + (size_t)rowv[u] * ldx + 4 * jv[u]);
+            v[u] = *reinterpret_cast<const float4*>(gn_src(x, x2, C1, ldx, ldx2, rb + rowv[u], g * cpg + 4 * jv[u]));
             ga[u] = *reinterpret_cast<const float4*>(gamma + g * cpg + 4 * jv[u]);
             be[u] = *reinterpret_cast<const float4*>(beta + g * cpg + 4 * jv[u]);
         }
@@ -300,19 +312,21 @@ __global__ __launch_bounds__(256) void gn_small2_kernel(const float* __restrict_
         }
     }
 }
-// slots: p0=x p1=gamma p2=beta p3=y ; i0=B i1=HW i2=C i3=G i4=ldx i5=ldy i6=act i7=variant(1 = opt-in v2) ; f0=eps
+// slots: p0=x p1=gamma p2=beta p3=y p4=x2(or null) ; i0=B i1=HW i2=C i3=G i4=ldx i5=ldy i6=act i7=variant(1 = v2)
+//        i8=C1 i9=ldx2 (two-source rows, see gn_src) ; f0=eps
 int launch_gn_small(const aed_op* op, hipStream_t s) {
     const int32_t* i = op->i;
     AED_REQUIRE(op->p[0] && op->p[1] && op->p[2] && op->p[3], "gn_small: null pointer");
     AED_REQUIRE(i[2] % (4 * i[3]) == 0 && i[4] % 4 == 0 && i[5] % 4 == 0, "gn_small: C=%d G=%d", i[2], i[3]);
+    AED_REQUIRE(!op->p[4] || (i[8] > 0 && i[8] < i[2] && i[8] % 4 == 0 && i[9] % 4 == 0), "gn_small: bad two-source split");
     if (i[7] == 1)
         hipLaunchKernelGGL(gn_small2_kernel<4>, dim3(i[3], i[0]), dim3(256), 0, s, (const float*)op->p[0],
                            (const float*)op->p[1], (const float*)op->p[2], (float*)op->p[3], i[1], i[2], i[3], i[4], i[5],
-                           op->f[0], i[6]);
+                           op->f[0], i[6], (const float*)op->p[4], i[8], i[9]);
     else
         hipLaunchKernelGGL(gn_small_kernel, dim3(i[3], i[0]), dim3(256), 0, s, (const float*)op->p[0],
                            (const float*)op->p[1], (const float*)op->p[2], (float*)op->p[3], i[1], i[2], i[3], i[4], i[5],
-                           op->f[0], i[6]);
+                           op->f[0], i[6], (const float*)op->p[4], i[8], i[9]);
     AED_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -329,27 +343,27 @@ int launch_gn_scale_shift(const aed_op* op, hipStream_t s) {
     return 0;
 }
 
-// slots: p0=x p1=partials ; i0=B i1=HW i2=C i3=G i4=ldx i5=rows_per_chunk i6=nchunks
+// slots: p0=x p1=partials p2=x2(or null) ; i0=B i1=HW i2=C i3=G i4=ldx i5=rows_per_chunk i6=nchunks i7=C1 i8=ldx2
 int launch_gn_stats(const aed_op* op, hipStream_t s) {
     const int32_t* i = op->i;
     AED_REQUIRE(op->p[0] && op->p[1], "gn_stats: null pointer");
     AED_REQUIRE(i[3] <= 64 && i[2] % (4 * i[3]) == 0, "gn_stats: C=%d must be a multiple of 4*G (G=%d<=64)", i[2], i[3]);
     AED_REQUIRE(i[4] % 4 == 0, "gn_stats: ldx %% 4");
     hipLaunchKernelGGL(gn_stats_kernel, dim3(i[6], i[0]), dim3(256), 0, s, (const float*)op->p[0], (float*)op->p[1],
-                       i[1], i[2], i[3], i[4], i[5], i[6]);
+                       i[1], i[2], i[3], i[4], i[5], i[6], (const float*)op->p[2], i[7], i[8]);
     AED_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
-// slots: p0=x p1=partials p2=gamma p3=beta p4=y ; i0..i4 as gn_stats, i5=apply rows/block, i6=#stats partials,
-//        i7=act, i8=ldy, i9=#apply blocks per batch item ; f0=eps
+// slots: p0=x p1=partials p2=gamma p3=beta p4=y p5=x2(or null) ; i0..i4 as gn_stats, i5=apply rows/block,
+//        i6=#stats partials, i7=act, i8=ldy, i9=#apply blocks per batch item, i10=C1 i11=ldx2 ; f0=eps
 int launch_gn_apply(const aed_op* op, hipStream_t s) {
     const int32_t* i = op->i;
     AED_REQUIRE(op->p[0] && op->p[1] && op->p[2] && op->p[3] && op->p[4], "gn_apply: null pointer");
     AED_REQUIRE(i[3] <= 64 && 256 % i[3] == 0 && i[2] % (4 * i[3]) == 0, "gn_apply: C=%d G=%d", i[2], i[3]);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(i[9], i[0]), dim3(256), 0, s, (const float*)op->p[0],
                        (const float*)op->p[1], (const float*)op->p[2], (const float*)op->p[3], (float*)op->p[4], i[1],
-                       i[2], i[3], i[4], i[8], i[5], i[6], op->f[0], i[7]);
+                       i[2], i[3], i[4], i[8], i[5], i[6], op->f[0], i[7], (const float*)op->p[5], i[10], i[11]);
     AED_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -24,6 +24,19 @@ FORCE_BK = int(os.environ.get("AED_FORCE_BK", "0"))
 # attention kernel variant (see Tape.attention); 0 = the measured default
 ATTN_VARIANT = int(os.environ.get("AED_ATTN_VARIANT", "0"))
 GN_VARIANT = int(os.environ.get("AED_GN_VARIANT", "0"))          # single-launch GroupNorm kernel generation
+# 1 (default): small contractions go to the latency-regime kernels of lin_gemm.hip; 0: round-1 routing (A/B runs)
+LIN_MODE = int(os.environ.get("AED_LIN_MODE", "1"))
+# measured (tile, ksplit) per (M, N, K, geglu), filled from tools/tile_sweep.py runs (see tile_table.py); the
+# environment override "M,N,K,g:tile[:ksplit];..." is what the sweep tool itself uses
+try:
+    from .tile_table import TILE_TABLE
+except ImportError:                                              # pragma: no cover
+    TILE_TABLE = {}
+TILE_TABLE = dict(TILE_TABLE)
+for _ent in filter(None, os.environ.get("AED_TILE_OVERRIDE", "").split(";")):
+    _k, _v = _ent.split(":", 1)
+    _v = [int(t) for t in _v.split(":")]
+    TILE_TABLE[tuple(int(t) for t in _k.split(","))] = (_v[0], _v[1] if len(_v) > 1 else 1)
 
 
 class Tape:
@@ -74,17 +87,47 @@ class Tape:
         return len(self.ops) - 1
 
     # ------------------------------------------------------------------ conv / linear
+    # tile codes of AED_OP_CONV_GEMM (slot i29): 1/2/4/5/6 = LDS-staged block tiles 128x128 / 128x64 / 64x64 / 128x32 /
+    # 32x128 (conv_gemm.hip), 7 = round-1 wave-split-K kernel, 10..17 = latency-regime kernels of lin_gemm.hip:
+    # (waves, tile) 10 = (4, 32x32), 11 = (8, 32x32), 12 = (16, 32x32), 13 = (4, 32x64), 14 = (8, 32x64),
+    # 15 = (4, 64x64), 16 = (4, 64x32), 17 = (8, 64x64)
+    LIN_TILES = {10: (32, 32), 11: (32, 32), 12: (32, 32), 13: (32, 64), 14: (32, 64), 15: (64, 64), 16: (64, 32),
+                 17: (64, 64)}
+
     @staticmethod
-    def pick_tile(M, N, K, cus=None, vector_ok=True):
-        """Tile / split-K choice, from the per-shape microbenchmarks of round 1 (tools/gemm_sweep.py):
-        small M*N with short K -> wave-split-K kernel (cfg 7, 32x32 tile per block, no reduce launch);
-        otherwise the LDS-staged kernel with the largest tile that still fills the chip, split-K
-        (deterministic slab reduce) when the grid would be < 1 block per CU."""
+    def pick_tile(M, N, K, cus=None, vector_ok=True, geglu=False, lin_ok=True):
+        """Tile / split-K choice.  Measured table first (tools/tile_sweep.py on the MI355X, shapes of the benchmark's
+        U-Net at batch 2 and 2G), then the rule the table was distilled into:
+        few output tiles -> lin_gemm (K split across the wavefronts of a workgroup, no reduce launch), more waves per
+        tile the fewer tiles there are and the longer K is; otherwise the LDS-staged kernel with the largest tile that
+        still fills the chip, split-K (deterministic slab reduce) when the grid would be < 1 block per CU."""
         cus = cus or CU_COUNT
+        hit = TILE_TABLE.get((M, N, K, int(bool(geglu))))
+        if hit is not None and (lin_ok or hit[0] < 10):
+            return hit
 
         def blocks(bm, bn):
             return math.ceil(M / bm) * math.ceil(N / bn)
-        if vector_ok and N > 32 and M > 32 and blocks(64, 64) <= 192 and K <= 2560 and K % 8 == 0:
+        if LIN_MODE and lin_ok and vector_ok and K % 32 == 0:
+            if geglu:
+                t = blocks(32, 64)
+                if t <= 2 * cus:
+                    return (14 if (t <= cus // 2 and K >= 512) else 13), 1
+                if blocks(64, 64) <= 4 * cus:
+                    return 15, 1
+            else:
+                t = blocks(32, 32)
+                if t <= 4 * cus:
+                    if t <= cus // 2 and K >= 2048:
+                        return 12, 1
+                    if t <= cus and K >= 512:
+                        return 11, 1
+                    return 10, 1
+                if blocks(64, 64) <= 4 * cus:
+                    return 15, 1
+        if geglu:
+            return 1, 1
+        if (not LIN_MODE) and vector_ok and N > 32 and M > 32 and blocks(64, 64) <= 192 and K <= 2560 and K % 8 == 0:
             return 7, max(1, math.ceil(K / 1024))
         if N <= 32:
             cfg, bm, bn = 5, 128, 32
@@ -108,8 +151,12 @@ class Tape:
     def conv(self, x, w, bias, out, *, B, IH, IW, Cin, OH, OW, N, KH=1, KW=1, stride=1, pad_h=0, pad_w=0,
              dil_h=1, dil_w=1, up=0, lda=None, a_bs=None, res=None, rowvec=None, ld_rv=0, in_act=0, in_slope=0.0,
              out_act=0, out_p=0.0, accumulate=0, out_div=1.0, o_mul=1, o_add=0, o_len=None, out_bs=None,
-             ldc=None, ldr=None, ksplit=0, tile=0, ln_rowsum=None, ln_eps=1e-5, name="conv"):
-        """Implicit-GEMM conv (AED_OP_CONV_GEMM).  x: [B,IH,IW,>=Cin] view, w: [N, KH*KW*Cin]."""
+             ldc=None, ldr=None, ksplit=0, tile=0, ln_rowsum=None, ln_eps=1e-5, x2=None, C1=0, lda2=None, a_bs2=None,
+             geglu=0, name="conv"):
+        """Implicit-GEMM conv (AED_OP_CONV_GEMM).  x: [B,IH,IW,>=Cin] view, w: [N, KH*KW*Cin].
+        x2/C1: two-source A -- channels [0,C1) of every tap come from x, [C1,Cin) from x2 (a concat that is never
+        materialised).  geglu: w rows are packed [32 value | 32 gate] per 32 features and out[:, f] =
+        value_f * gelu(gate_f) has N/2 columns."""
         M = B * OH * OW
         K = KH * KW * Cin
         lda = x.stride(-2) if lda is None else lda
@@ -119,10 +166,18 @@ class Tape:
             ldr = res.stride(-2)
         o_len = OH * OW if o_len is None else o_len
         out_bs = OH * OW if out_bs is None else out_bs
-        vec_ok = (Cin % 32 == 0) and (lda % 4 == 0)
-        auto_tile, auto_split = self.pick_tile(M, N, K, vector_ok=vec_ok)
+        if x2 is not None:
+            assert 0 < C1 < Cin and C1 % 64 == 0
+            lda2 = x2.stride(-2) if lda2 is None else lda2
+            a_bs2 = IH * IW * lda2 if a_bs2 is None else a_bs2
+        vec_ok = (Cin % 32 == 0) and (lda % 4 == 0) and (x2 is None or lda2 % 4 == 0)
+        # lin_gemm needs an unsplit epilogue without the accumulate modes (vocoder MRF) and 32-wide channel chunks
+        lin_ok = vec_ok and accumulate == 0 and (x2 is None or C1 % 32 == 0)
+        auto_tile, auto_split = self.pick_tile(M, N, K, vector_ok=vec_ok, geglu=bool(geglu), lin_ok=lin_ok)
         tile = tile or auto_tile
         ksplit = ksplit or auto_split
+        if tile >= 10:
+            ksplit = 1
         ln_mode = 0
         if ln_rowsum is not None:
             # fused LayerNorm: `w` carries gamma, `bias` = W.beta (+bias), `ln_rowsum`[n] = sum_k w[n,k]
@@ -130,11 +185,15 @@ class Tape:
             ln_mode, rowvec, ksplit = 1, ln_rowsum, 1
             if tile == 7 and K > 1024:
                 tile = 4
+        if x2 is not None and tile == 7:
+            tile = 4
         i = [M, N, K, lda, ldc, ldr or 0, ld_rv, IH, IW, OH, OW, Cin, KH, KW, stride, pad_h, pad_w, dil_h, dil_w, up,
-             a_bs, o_mul, o_add, o_len, out_bs, in_act, out_act, accumulate, ksplit, tile, FORCE_BK, ln_mode]
+             a_bs, o_mul, o_add, o_len, out_bs, in_act, out_act, accumulate, ksplit, tile, FORCE_BK, ln_mode,
+             C1 if x2 is not None else 0, lda2 or 0, a_bs2 or 0, int(bool(geglu))]
+        n_out = N // 2 if geglu else N
         idx = self._add(L.OP_CONV_GEMM, i, [in_slope, out_p, out_div, ln_eps],
-                        [x, w, bias, out, res, rowvec, None, None], name=name, flops=2 * M * N * K,
-                        nbytes=4 * (B * IH * IW * Cin + N * K + M * N))
+                        [x, w, bias, out, res, rowvec, None, None, x2, None], name=name, flops=2 * M * N * K,
+                        nbytes=4 * (B * IH * IW * Cin + N * K + M * n_out))
         if ksplit > 1:
             self._ws_need = max(self._ws_need, ksplit * M * N)
             self._ws_ops.append(idx)
@@ -148,15 +207,19 @@ class Tape:
     TILE_BM = {1: 128, 2: 128, 3: 64, 4: 64, 5: 128, 6: 32, 7: 32}
 
     # ------------------------------------------------------------------ norms
-    def groupnorm(self, x, gamma, beta, out, *, B, HW, C, G=32, eps=1e-5, act=0, variant=None, name="gn"):
+    def groupnorm(self, x, gamma, beta, out, *, B, HW, C, G=32, eps=1e-5, act=0, variant=None, x2=None, C1=0,
+                  name="gn"):
+        """GroupNorm(+act) over [B, HW, C].  x2/C1: two-source rows -- channels [0,C1) from x, [C1,C) from x2."""
         ldx = x.stride(-2)
         ldy = out.stride(-2)
+        ldx2 = x2.stride(-2) if x2 is not None else 0
+        C1 = C1 if x2 is not None else 0
         variant = GN_VARIANT if variant is None else variant
         if HW * (C // G) <= 65536 and B * G >= 32 and B * HW * C <= (1 << 22):
             # small map: one launch, one block per (group, batch item) -- latency, not bandwidth, is the cost
-            # (variant 1 = opt-in second-generation kernel with batched loads, see norm.hip)
-            self._add(L.OP_GN_SMALL, [B, HW, C, G, ldx, ldy, act, variant], [eps], [x, gamma, beta, out], name=name + ".gn1",
-                      nbytes=12 * B * HW * C)
+            # (variant 1 = second-generation kernel with batched loads, see norm.hip)
+            self._add(L.OP_GN_SMALL, [B, HW, C, G, ldx, ldy, act, variant, C1, ldx2], [eps], [x, gamma, beta, out, x2],
+                      name=name + ".gn1", nbytes=12 * B * HW * C)
             return out
         # stats: <=32 coarse slabs per batch item (few partials to re-reduce);
         # apply: fine slabs for parallelism (~2 blocks per CU)
@@ -167,9 +230,10 @@ class Tape:
         a_chunks = math.ceil(HW / a_rpc)
         part = self.alloc(B, s_chunks, G, 2)
         nb = 4 * B * HW * C
-        self._add(L.OP_GN_STATS, [B, HW, C, G, ldx, s_rpc, s_chunks], [], [x, part], name=name + ".stats", nbytes=nb)
-        self._add(L.OP_GN_APPLY, [B, HW, C, G, ldx, a_rpc, s_chunks, act, ldy, a_chunks], [eps],
-                  [x, part, gamma, beta, out], name=name + ".apply", nbytes=2 * nb)
+        self._add(L.OP_GN_STATS, [B, HW, C, G, ldx, s_rpc, s_chunks, C1, ldx2], [], [x, part, x2],
+                  name=name + ".stats", nbytes=nb)
+        self._add(L.OP_GN_APPLY, [B, HW, C, G, ldx, a_rpc, s_chunks, act, ldy, a_chunks, C1, ldx2], [eps],
+                  [x, part, gamma, beta, out, x2], name=name + ".apply", nbytes=2 * nb)
         return out
 
     def layernorm(self, x, gamma, beta, out, *, M, C, eps=1e-5, name="ln"):

@@ -15,12 +15,25 @@ Everything here is host-side graph construction; arithmetic happens in libaed.so
 Activations are channels-last; the NCHW<->NHWC change happens only at the wrapper boundary.
 """
 import math
+import os
 
 import torch
 
 from . import _lib as L
 from .tape import Tape
 from .weights import ctx_dims_per_block, _per_block
+
+
+FUSE_GEGLU = os.environ.get("AED_FUSE_GEGLU", "1") != "0"
+TWO_SOURCE = os.environ.get("AED_TWO_SOURCE", "1") != "0"
+
+
+def geglu_pack_index(dff):
+    """Row order of a GEGLU projection [2*dff, K] (value rows, then gate rows: diffusers GEGLU.chunk(2)) after packing
+    for the fused epilogue: block q = rows [value 32q..32q+31 | gate 32q..32q+31]."""
+    q = torch.arange(dff // 32)[:, None]
+    j = torch.arange(32)[None, :]
+    return torch.cat([32 * q + j, dff + 32 * q + j], 1).reshape(-1)
 
 
 class PackedUNetWeights:
@@ -88,6 +101,15 @@ class PackedUNetWeights:
                 blk = k[: -len(".ff.net.0.proj.weight")]
                 self._fold_ln(blk + ".ff1_ln", v, sd[blk + ".norm3.weight"], sd[blk + ".norm3.bias"],
                               sd[blk + ".ff.net.0.proj.bias"])
+                dff = v.shape[0] // 2
+                if dff % 32 == 0:
+                    # GEGLU fused into the FF1 epilogue: rows packed [32 value | 32 gate] per 32 features, so one
+                    # wavefront's adjacent 32-column sub-tiles hold value and gate of the same features
+                    perm = geglu_pack_index(dff)
+                    b1 = sd[blk + ".ff.net.0.proj.bias"]
+                    self._fold_ln(blk + ".ff1g_ln", v[perm], sd[blk + ".norm3.weight"], sd[blk + ".norm3.bias"], b1[perm])
+                    wd[blk + ".ff1g.weight"] = self._dev(v[perm])
+                    wd[blk + ".ff1g.bias"] = self._dev(b1[perm])
             if k.endswith(".to_k.weight") or k.endswith(".to_v.weight"):
                 continue
             wd[k] = self._dev(v)
@@ -95,9 +117,13 @@ class PackedUNetWeights:
 
 class UNetEngine:
     def __init__(self, cfg, weights, device, batch, H, W, ctx_len0=0, ctx_len1=0, use_ehs=True,
-                 timesteps_dev=None, state_dev=None, fuse_ln=True):
+                 timesteps_dev=None, state_dev=None, fuse_ln=True, fuse_geglu=None, two_source=None):
         self.cfg = cfg
         self.fuse_ln = fuse_ln
+        # GEGLU gate in the FF1 epilogue (no [M, 8C] round trip, one launch less); up-block concats read in place (no
+        # copy launches).  The environment switches exist for A/B profiling runs only.
+        self.fuse_geglu = FUSE_GEGLU if fuse_geglu is None else fuse_geglu
+        self.two_source = TWO_SOURCE if two_source is None else two_source
         # GroupNorm(+SiLU) inside the conv A-loader is implemented and parity-tested but OFF by default: measured
         # on MI355X it is a wash at U-Net batch 2 (11.53 vs 11.51 ms/forward) and 5 % slower at batch 32
         # (77.8 vs 73.8 ms): the loader's 9x-per-tap SiLU recompute costs more than the saved launch + round trip.
@@ -122,13 +148,15 @@ class UNetEngine:
         return self._tmp[key]
 
     # ------------------------------------------------------------------ modules
-    def _resnet(self, p, x, Cin, Cout, H, W, dest, groups, eps):
+    def _resnet(self, p, x, Cin, Cout, H, W, dest, groups, eps, x2=None, C1=0):
+        """ResnetBlock2D.  x2/C1: the block input is the channel concat (x[..., :C1] | x2) of an up block
+        (models.py:349-357), read in place by GroupNorm and the shortcut conv -- never materialised."""
         tp, wd, B = self.tape, self.wd, self.B
         h = self.tmp("res_h", B, H, W, Cout)
         off = self.temb_off[p + ".time_emb_proj"]
         a = self.tmp("gn_a", B, H, W, Cin)
         tp.groupnorm(x, wd[p + ".norm1.weight"], wd[p + ".norm1.bias"], a, B=B, HW=H * W, C=Cin, G=groups,
-                     eps=eps, act=L.ACT_SILU, name=p + ".norm1")
+                     eps=eps, act=L.ACT_SILU, x2=x2, C1=C1, name=p + ".norm1")
         tp.conv(a, wd[p + ".conv1.weight"], wd[p + ".conv1.bias"], h, B=B, IH=H, IW=W, Cin=Cin, OH=H, OW=W, N=Cout,
                 KH=3, KW=3, pad_h=1, pad_w=1, rowvec=self.temb_all[:, off:off + Cout], ld_rv=self.temb_total,
                 name=p + ".conv1")
@@ -139,7 +167,9 @@ class UNetEngine:
         if (p + ".conv_shortcut.weight") in wd:
             res = self.tmp("res_sc", B, H, W, Cout)
             tp.conv(x, wd[p + ".conv_shortcut.weight"], wd[p + ".conv_shortcut.bias"], res, B=B, IH=H, IW=W, Cin=Cin,
-                    OH=H, OW=W, N=Cout, name=p + ".conv_shortcut")
+                    OH=H, OW=W, N=Cout, x2=x2, C1=C1, name=p + ".conv_shortcut")
+        else:
+            assert x2 is None, "a concatenated input always changes the channel count"
         tp.conv(a2, wd[p + ".conv2.weight"], wd[p + ".conv2.bias"], dest, B=B, IH=H, IW=W, Cin=Cout, OH=H, OW=W,
                 N=Cout, KH=3, KW=3, pad_h=1, pad_w=1, res=res, name=p + ".conv2")
         return dest
@@ -211,11 +241,20 @@ class UNetEngine:
                   name=b + ".attn2.to_out")
         if not F:
             tp.layernorm(t2, wd[b + ".norm3.weight"], wd[b + ".norm3.bias"], ln, M=M, C=C, name=b + ".norm3")
-        g = self.tmp("t_g", M, 8 * C)
-        self._ln_linear(t2 if F else ln, b + ".ff1_ln", wd[b + ".ff.net.0.proj.weight"],
-                        wd[b + ".ff.net.0.proj.bias"], g, M, C, 8 * C, F, b + ".ff1")
         f = self.tmp("t_f", M, 4 * C)
-        tp.geglu(g, f, M=M, Dff=4 * C, name=b + ".geglu")
+        if self.fuse_geglu and (b + ".ff1g.weight") in wd:
+            # FF1 with the GEGLU gate in its epilogue: the [M, 8C] projection never reaches HBM
+            if F:
+                tp.linear(t2, wd[b + ".ff1g_ln.weight"], wd[b + ".ff1g_ln.t"], f, M=M, K=C, N=8 * C,
+                          ln_rowsum=wd[b + ".ff1g_ln.rowsum"], geglu=1, name=b + ".ff1+ln+geglu")
+            else:
+                tp.linear(ln, wd[b + ".ff1g.weight"], wd[b + ".ff1g.bias"], f, M=M, K=C, N=8 * C, geglu=1,
+                          name=b + ".ff1+geglu")
+        else:
+            g = self.tmp("t_g", M, 8 * C)
+            self._ln_linear(t2 if F else ln, b + ".ff1_ln", wd[b + ".ff.net.0.proj.weight"],
+                            wd[b + ".ff.net.0.proj.bias"], g, M, C, 8 * C, F, b + ".ff1")
+            tp.geglu(g, f, M=M, Dff=4 * C, name=b + ".geglu")
         t3 = self.tmp("t_3", M, C)
         tp.linear(f, wd[b + ".ff.net.2.weight"], wd[b + ".ff.net.2.bias"], t3, M=M, K=4 * C, N=C, res=t2,
                   name=b + ".ff2")
@@ -337,12 +376,16 @@ class UNetEngine:
             for j in range(lpb + 1):
                 sk, sc, sh_, sw_ = skips.pop()
                 assert (sh_, sw_) == (hh, ww), "skip / feature-map size mismatch"
-                cat = self.tmp("cat", B, hh, ww, ch + sc)
-                tp.copy2d(h, cat, rows=B * hh * ww, cols=ch, ld_src=h.stride(-2), ld_dst=ch + sc, name="cat.h")
-                tp.copy2d(sk, cat[..., ch:], rows=B * hh * ww, cols=sc, ld_src=sk.stride(-2), ld_dst=ch + sc,
-                          name="cat.skip")
                 d = tp.alloc(B, hh, ww, co)
-                h = self._resnet(f"up_blocks.{i}.resnets.{j}", cat, ch + sc, co, hh, ww, d, groups, eps)
+                if self.two_source and ch % 64 == 0 and (ch + sc) % 32 == 0 and sc % 4 == 0:
+                    # torch.cat([h, skip], dim=1) is never materialised: GroupNorm and the shortcut conv read both
+                    h = self._resnet(f"up_blocks.{i}.resnets.{j}", h, ch + sc, co, hh, ww, d, groups, eps, x2=sk, C1=ch)
+                else:
+                    cat = self.tmp("cat", B, hh, ww, ch + sc)
+                    tp.copy2d(h, cat, rows=B * hh * ww, cols=ch, ld_src=h.stride(-2), ld_dst=ch + sc, name="cat.h")
+                    tp.copy2d(sk, cat[..., ch:], rows=B * hh * ww, cols=sc, ld_src=sk.stride(-2), ld_dst=ch + sc,
+                              name="cat.skip")
+                    h = self._resnet(f"up_blocks.{i}.resnets.{j}", cat, ch + sc, co, hh, ww, d, groups, eps)
                 ch = co
                 if "CrossAttn" in bt:
                     h = self._site(f"up_blocks.{i}", j * len(ctx_pb[lvl]), h, co, hh, ww, heads_pb[lvl], ctx_pb[lvl],

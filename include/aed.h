@@ -30,14 +30,15 @@
 extern "C" {
 #endif
 
-#define AED_VERSION 1
+#define AED_VERSION 2
 
 /* ----------------------------------------------------------------------------------------
  * op tape
  * -------------------------------------------------------------------------------------- */
 enum aed_opcode {
     AED_OP_NOP = 0,
-    AED_OP_CONV_GEMM = 1,     /* implicit-GEMM conv / linear on fp32 MFMA (K5,K6,K11,K2,K3)   */
+    AED_OP_CONV_GEMM = 1,     /* implicit-GEMM conv / linear on fp32 MFMA (K5,K6,K11,K2,K3); optional two-source A
+                                 (skip concat never materialised), fused LayerNorm, fused GEGLU gate (K8)        */
     AED_OP_GN_STATS = 2,      /* GroupNorm partial sums (K4)                                   */
     AED_OP_GN_APPLY = 3,      /* GroupNorm normalise + affine (+SiLU) (K4)                     */
     AED_OP_LAYERNORM = 4,     /* LayerNorm over the last dim (K8)                              */
@@ -67,9 +68,9 @@ enum aed_opcode {
 typedef struct aed_op {
     int32_t code;
     int32_t flags;
-    int32_t i[32];
+    int32_t i[40];
     float   f[8];
-    void*   p[8];
+    void*   p[10];
 } aed_op;
 
 /* activation / transform codes used in aed_op slots */

@@ -68,10 +68,17 @@ def conv_gemm(op):
     ok = (iy >= 0) & (iy < vIH) & (ix >= 0) & (ix < vIW)
     cy, cx = torch.where(ok, iy >> up, 0), torch.where(ok, ix >> up, 0)
     pix = b[:, None] * a_bs + (cy * IW + cx) * lda                              # element offset of channel 0
-    n_a = int(pix.max()) + Cin
-    a_flat = _f32(p[0], n_a)
-    off = pix[:, :, None] + torch.arange(Cin)[None, None, :]                    # [M, taps, Cin]
-    A = torch.where(ok[:, :, None], a_flat[off.reshape(-1)].reshape(off.shape), torch.zeros(())).reshape(M, K)
+    C1, lda2, a_bs2, geglu_on = int(i[32]), int(i[33]), int(i[34]), int(i[35])
+
+    def gather(ptr, pix_, c_lo, c_hi):
+        flat = _f32(ptr, int(pix_.max()) + c_hi)
+        off = pix_[:, :, None] + torch.arange(c_lo, c_hi)[None, None, :]        # [M, taps, channels]
+        return torch.where(ok[:, :, None], flat[off.reshape(-1)].reshape(off.shape), torch.zeros(()))
+    if C1 > 0:          # two-source A: channels [0,C1) from p0, [C1,Cin) from p8 (a concat that is never materialised)
+        pix2 = b[:, None] * a_bs2 + (cy * IW + cx) * lda2
+        A = torch.cat([gather(p[0], pix, 0, C1), gather(p[8], pix2, 0, Cin - C1)], 2).reshape(M, K)
+    else:
+        A = gather(p[0], pix, 0, Cin).reshape(M, K)
     if ln_mode:
         mean = A.sum(1) / K
         var = torch.clamp((A * A).sum(1) / K - mean * mean, min=0.0)
@@ -92,6 +99,11 @@ def conv_gemm(op):
     o = r * o_mul + o_add
     okr = (o >= 0) & (o < o_len)
     row = b * out_bs + torch.clamp(o, 0, o_len - 1)
+    if geglu_on:        # packed columns: per 64 columns [32 value | 32 gate] -> 32 output features value * gelu(gate)
+        v3 = val.float().reshape(M, N // 64, 2, 32)
+        g = v3[:, :, 1]
+        val = (v3[:, :, 0] * (0.5 * g * (1.0 + torch.erf(g * 0.70710678118654752440)))).reshape(M, N // 2).double()
+        N = N // 2
     cols = torch.arange(N)[None, :]
     if p[4]:
         res = _f32(p[4], int(row.max()) * ldr + N)
@@ -109,8 +121,18 @@ def conv_gemm(op):
 
 
 # ------------------------------------------------------------------------------------------------- norms
+def _gn_input(op, px, px2, B, HW, C, ldx, C1, ldx2):
+    """[B, HW, C] input of a GroupNorm op; two-source rows (channels [0,C1) from px, the rest from px2) concatenated."""
+    if not op.p[px2]:
+        return _f32(op.p[px], (B * HW - 1) * ldx + C).as_strided((B, HW, C), (HW * ldx, ldx, 1))
+    a = _f32(op.p[px], (B * HW - 1) * ldx + C1).as_strided((B, HW, C1), (HW * ldx, ldx, 1))
+    c = _f32(op.p[px2], (B * HW - 1) * ldx2 + C - C1).as_strided((B, HW, C - C1), (HW * ldx2, ldx2, 1))
+    return torch.cat([a, c], 2)
+
+
 def _group_norm(x, gamma, beta, B, HW, C, G, ldx, eps):
-    xs = x[: (B * HW - 1) * ldx + C].as_strided((B, HW, C), (HW * ldx, ldx, 1)).double()
+    xs = x.double() if x.dim() == 3 else \
+        x[: (B * HW - 1) * ldx + C].as_strided((B, HW, C), (HW * ldx, ldx, 1)).double()
     g = xs.reshape(B, HW, G, C // G)
     mean = g.mean(dim=(1, 3), keepdim=True)
     var = g.var(dim=(1, 3), unbiased=False, keepdim=True)
@@ -130,7 +152,7 @@ def gn_stats(op):          # the partial sums are consumed only by gn_apply, whi
 def gn_apply(op):
     i, p = op.i, op.p
     B, HW, C, G, ldx, act, ldy = int(i[0]), int(i[1]), int(i[2]), int(i[3]), int(i[4]), int(i[7]), int(i[8])
-    x = _f32(p[0], (B * HW - 1) * ldx + C)
+    x = _gn_input(op, 0, 5, B, HW, C, ldx, int(i[10]), int(i[11]))
     y = _group_norm(x, _f32(p[2], C), _f32(p[3], C), B, HW, C, G, ldx, float(op.f[0]))
     _store_rows(_f32(p[4], (B * HW - 1) * ldy + C), _act(y, act, 0.0), ldy)
 
@@ -138,7 +160,7 @@ def gn_apply(op):
 def gn_small(op):
     i, p = op.i, op.p
     B, HW, C, G, ldx, ldy, act = [int(i[k]) for k in range(7)]
-    x = _f32(p[0], (B * HW - 1) * ldx + C)
+    x = _gn_input(op, 0, 4, B, HW, C, ldx, int(i[8]), int(i[9]))
     y = _group_norm(x, _f32(p[1], C), _f32(p[2], C), B, HW, C, G, ldx, float(op.f[0]))
     _store_rows(_f32(p[3], (B * HW - 1) * ldy + C), _act(y, act, 0.0), ldy)
 

@@ -101,7 +101,7 @@ def test_groupnorm(C, G, HW, B, act):
     _groupnorm_case(C, G, HW, B, act, variant=0)
 
 
-@EXPERIMENTAL          # opt-in second-generation single-launch GroupNorm (AED_GN_VARIANT=1)
+# second-generation single-launch GroupNorm (AED_GN_VARIANT=1); hardware-verified at the end of round 1
 @pytest.mark.parametrize("C,G,HW,B,act", [(128, 32, 4096, 2, 1), (384, 32, 256, 2, 0), (640, 32, 64, 3, 1),
                                           (32, 8, 100, 2, 1), (256, 32, 1000, 2, 0)])
 def test_groupnorm_variant1(C, G, HW, B, act):
@@ -144,7 +144,7 @@ def test_attention(B, H, Nq, Nk, D, masked):
     _attention_case(B, H, Nq, Nk, D, masked, variant=0)
 
 
-@EXPERIMENTAL          # opt-in second-generation split-KV attention kernel (AED_ATTN_VARIANT=2)
+# second-generation split-KV attention kernel (AED_ATTN_VARIANT=2); hardware-verified at the end of round 1
 @pytest.mark.parametrize("B,H,Nq,Nk,D,masked", [(2, 8, 1024, 1024, 32, False), (2, 8, 256, 256, 48, False),
                                                  (1, 2, 70, 130, 64, True), (1, 2, 40, 200, 16, False),
                                                  (1, 1, 33, 97, 80, True)])
@@ -254,3 +254,133 @@ def test_conv_nearest_resize_to_explicit_size(H, W, th, tw):
             IW=W, Cin=C, OH=th, OW=tw, N=N, KH=3, KW=3, pad_h=1, pad_w=1, up=1)
     run(tp)
     assert (nchw(out.cpu()) - ref).abs().max() < 3e-5
+
+
+# --------------------------------------------------------------------------------- lin_gemm (latency-regime kernels)
+LIN_TILES = [10, 11, 12, 13, 14, 15, 16, 17]
+
+
+@pytest.mark.parametrize("tile", LIN_TILES)
+@pytest.mark.parametrize("B,C,H,W,N,k,stride,pad,up", [
+    (2, 64, 16, 8, 96, 1, 1, 0, 0),      # linear-like 1x1, N not a tile multiple
+    (2, 32, 16, 8, 64, 3, 1, 1, 0),      # 3x3 with zero padding taps
+    (1, 64, 12, 6, 96, 3, 2, 1, 0),      # stride-2 downsample
+    (2, 32, 8, 4, 32, 3, 1, 1, 1),       # nearest-2x upsample fused
+    (3, 96, 5, 3, 160, 1, 1, 0, 0),      # ragged M (45 rows), K = 96 = 3 chunks over up to 16 waves
+    (2, 640, 4, 2, 640, 3, 1, 1, 0),     # deep K (5760), tiny M: the shape that used to need split-K + reduce
+])
+def test_lin_gemm_vs_torch(tile, B, C, H, W, N, k, stride, pad, up):
+    x = rnd(B, C, H, W, seed=1)
+    w = rnd(N, C, k, k, seed=2, scale=1 / math.sqrt(C * k * k))
+    b = rnd(N, seed=3, scale=0.1)
+    xin = F.interpolate(x, scale_factor=2.0, mode="nearest") if up else x
+    ref = F.conv2d(xin, w, b, stride=stride, padding=pad)
+    OH, OW = ref.shape[2], ref.shape[3]
+    tp = Tape(DEV)
+    out = tp.alloc(B, OH, OW, N)
+    tp.conv(nhwc(x).to(DEV), w.permute(0, 2, 3, 1).reshape(N, -1).contiguous().to(DEV), b.to(DEV), out, B=B, IH=H, IW=W,
+            Cin=C, OH=OH, OW=OW, N=N, KH=k, KW=k, stride=stride, pad_h=pad, pad_w=pad, up=up, tile=tile)
+    assert tp.ops[-1].i[29] == tile
+    run(tp)
+    err = (nchw(out.cpu()) - ref).abs().max().item()
+    assert err < 2e-5 * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("tile", LIN_TILES)
+def test_lin_gemm_epilogues(tile):
+    """bias + per-batch row vector + residual + loader/epilogue activations, row-strided operands."""
+    M, K, N = 200, 96, 72
+    x, w, b, r = rnd(M, K + 32, seed=1), rnd(N, K, seed=2, scale=0.1), rnd(N, seed=3), rnd(M, N + 8, seed=4)
+    rv = rnd(4, N, seed=5)
+    tp = Tape(DEV)
+    outw = tp.alloc(M, N + 16, zero=True)
+    xd, rd = x.to(DEV), r.to(DEV)
+    tp.conv(xd[:, :K], w.to(DEV), b.to(DEV), outw[:, :N], B=4, IH=50, IW=1, Cin=K, OH=50, OW=1, N=N, res=rd[:, :N],
+            rowvec=rv.to(DEV), ld_rv=N, in_act=L.ACT_SILU, out_act=L.ACT_SILU, tile=tile)
+    run(tp)
+    ref = F.silu(F.linear(F.silu(x[:, :K]), w, b) + r[:, :N] + rv.repeat_interleave(50, 0))
+    assert (outw.cpu()[:, :N] - ref).abs().max() < 3e-5
+    assert outw.cpu()[:, N:].abs().max() == 0          # nothing written past the N columns
+
+
+def _ln_fold(w, gamma, beta, bias):
+    wf = (w.double() * gamma.double()[None, :]).float()
+    t = w.double() @ beta.double() + (bias.double() if bias is not None else 0)
+    return wf, wf.double().sum(1).float(), t.float()
+
+
+@pytest.mark.parametrize("tile", LIN_TILES)
+def test_lin_gemm_fused_layernorm(tile):
+    M, C, N = 300, 384, 160
+    x = rnd(M, C, seed=1) * 2 + 0.3
+    ga, be = 1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3)
+    w, b = rnd(N, C, seed=4, scale=0.05), rnd(N, seed=5, scale=0.1)
+    wf, rs, t = _ln_fold(w, ga, be, b)
+    tp = Tape(DEV)
+    out = tp.alloc(M, N)
+    tp.linear(x.to(DEV), wf.to(DEV), t.to(DEV), out, M=M, K=C, N=N, ln_rowsum=rs.to(DEV), tile=tile)
+    run(tp)
+    ref = F.linear(F.layer_norm(x, (C,), ga, be), w, b)
+    assert (out.cpu() - ref).abs().max() < 5e-5
+
+
+@pytest.mark.parametrize("tile", [13, 14, 15, 17, 1])
+@pytest.mark.parametrize("ln", [0, 1])
+def test_fused_geglu(tile, ln):
+    """FF1 with the GEGLU gate in the epilogue (packed value/gate rows) vs Linear -> chunk -> x * gelu(gate)."""
+    from audioeditingcode_amd.unet import geglu_pack_index
+    M, C = (300, 128) if tile != 1 else (1100, 128)
+    dff = 4 * C
+    x = rnd(M, C, seed=1) * 1.5 + 0.2
+    w, b = rnd(2 * dff, C, seed=2, scale=0.08), rnd(2 * dff, seed=3, scale=0.1)
+    ga, be = 1 + 0.1 * rnd(C, seed=4), 0.1 * rnd(C, seed=5)
+    perm = geglu_pack_index(dff)
+    tp = Tape(DEV)
+    out = tp.alloc(M, dff)
+    if ln:
+        wf, rs, t = _ln_fold(w[perm], ga, be, b[perm])
+        tp.linear(x.to(DEV), wf.to(DEV), t.to(DEV), out, M=M, K=C, N=2 * dff, ln_rowsum=rs.to(DEV), geglu=1, tile=tile)
+        h = F.linear(F.layer_norm(x, (C,), ga, be), w, b)
+    else:
+        tp.linear(x.to(DEV), w[perm].contiguous().to(DEV), b[perm].contiguous().to(DEV), out, M=M, K=C, N=2 * dff,
+                  geglu=1, tile=tile)
+        h = F.linear(x, w, b)
+    run(tp)
+    a, gate = h.chunk(2, dim=-1)
+    assert (out.cpu() - a * F.gelu(gate)).abs().max() < 5e-5
+
+
+@pytest.mark.parametrize("tile", [10, 11, 15, 4, 1])
+def test_two_source_conv(tile):
+    """1x1 conv over a channel concat (h | skip) that is never materialised (up-block shortcut conv)."""
+    B, H, W, C1, C2, N = 2, 24, 8, 128, 64, 160
+    if tile == 1:
+        B, H = 4, 64
+    h, sk = rnd(B, H, W, C1 + 32, seed=1), rnd(B, H, W, C2, seed=2)
+    w, b = rnd(N, C1 + C2, seed=3, scale=0.07), rnd(N, seed=4)
+    tp = Tape(DEV)
+    out = tp.alloc(B, H, W, N)
+    hd = h.to(DEV)
+    tp.conv(hd[..., :C1], w.to(DEV), b.to(DEV), out, B=B, IH=H, IW=W, Cin=C1 + C2, OH=H, OW=W, N=N, x2=sk.to(DEV), C1=C1,
+            tile=tile)
+    run(tp)
+    ref = F.linear(torch.cat([h[..., :C1], sk], -1), w, b)
+    assert (out.cpu() - ref).abs().max() < 3e-5
+
+
+@pytest.mark.parametrize("C1,C2,HW,B,variant", [(384, 256, 256, 2, 0), (640, 640, 64, 2, 0), (128, 128, 4096, 2, 0),
+                                                (384, 256, 256, 2, 1), (256, 128, 4096, 6, 0)])
+def test_groupnorm_two_source(C1, C2, HW, B, variant):
+    """GroupNorm over (h | skip) read in place; 640 channels in 32 groups of 20 straddle the 384|256 boundary."""
+    C, G = C1 + C2, 32
+    h, sk = rnd(B, HW, C1 + 64, seed=1) * 2 + 0.5, rnd(B, HW, C2, seed=2) - 0.3
+    ga, be = 1 + 0.1 * rnd(C, seed=3), 0.1 * rnd(C, seed=4)
+    x = torch.cat([h[..., :C1], sk], -1)
+    ref = F.silu(F.group_norm(x.permute(0, 2, 1), G, ga, be, 1e-5)).permute(0, 2, 1)
+    tp = Tape(DEV)
+    out = tp.alloc(B, HW, C)
+    hd = h.to(DEV)
+    tp.groupnorm(hd[..., :C1], ga.to(DEV), be.to(DEV), out, B=B, HW=HW, C=C, G=G, eps=1e-5, act=1, x2=sk.to(DEV), C1=C1,
+                 variant=variant)
+    run(tp)
+    assert (out.cpu() - ref).abs().max() < 2e-5

@@ -32,8 +32,8 @@ def test_library_exports_every_header_symbol():
     for sym in declared:
         assert hasattr(lib, sym), f"{sym} declared in include/aed.h but not exported by libaed.so"
     assert sorted(L.EXPORTS) == declared
-    assert L.lib().aed_version() == 1
-    assert ctypes.sizeof(L.aed_op) == 4 + 4 + 32 * 4 + 8 * 4 + 8 * 8
+    assert L.lib().aed_version() == 2
+    assert ctypes.sizeof(L.aed_op) == 4 + 4 + 40 * 4 + 8 * 4 + 10 * 8
 
 
 def test_error_path_without_gpu():

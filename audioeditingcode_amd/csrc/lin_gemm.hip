@@ -25,8 +25,17 @@
 // pins the compiler (a memory clobber on an empty asm, no instruction)
 #define LDS_ORDER() asm volatile("" ::: "memory")
 
-template <int NW, int TM, int TN, int DEPTH>
+// MODE 0: plain Linear / 1x1 convolution with uniformly strided rows (A row m at m*lda): no tap arithmetic, no masks,
+//         no loader transform -- the lean path most launches of the edit loop take;
+// MODE 1: MODE 0 + fused LayerNorm row statistics;
+// MODE 2: general implicit-GEMM gather (taps, stride, padding, dilation, upsample, per-batch strides) and/or a loader
+//         activation (SiLU / LeakyReLU).
+// Everything that differs is compile-time: the run-time-flag version of this kernel spent more issue slots in
+// scalar branches than in MFMAs (and the compiler sank the masked loads into conditionals, serialising them).
+template <int NW, int TM, int TN, int DEPTH, int MODE>
 __global__ __launch_bounds__(64 * NW) void lin_gemm_kernel(CGParams p) {
+    constexpr bool GATHER = MODE == 2;
+    constexpr bool LN = MODE == 1;
     constexpr int CH = 32;                        // K per chunk
     constexpr int LD = CH + 4;                    // padded LDS row (floats)
     constexpr int AR = 32 * TM, WR = 32 * TN;     // tile rows of A / of W
@@ -56,6 +65,13 @@ __global__ __launch_bounds__(64 * NW) void lin_gemm_kernel(CGParams p) {
     }
     const int m0 = tile_y * AR;
     const int n0 = tile_x * WR;                   // packed W row of the tile (GEGLU: 64 packed rows = 32 features)
+    // optional in-kernel timeline (s_memtime, shader cycles): slots 0..15 = first workgroup, 16..31 = last workgroup
+    const bool last_wg = blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1;
+    const bool dbg_on = p.dbg != nullptr && tid == 0 && ((blockIdx.x == 0 && blockIdx.y == 0) || last_wg);
+    int dbg_n = last_wg ? 16 : 0;
+    const int dbg_end = dbg_n + 15;
+#define STAMP() do { if (dbg_on && dbg_n < dbg_end) p.dbg[dbg_n++] = __builtin_amdgcn_s_memtime(); } while (0)
+    STAMP();
 
     // this wave's range of 32-wide K chunks
     const int nch = p.K / CH;
@@ -65,18 +81,23 @@ __global__ __launch_bounds__(64 * NW) void lin_gemm_kernel(CGParams p) {
 
     // loader rows of this lane
     int ay0[PA], ax0[PA], ab[PA];
-    bool avalid[PA];
+    float amask[PA];                 // 1.0 for rows that exist (GATHER: per chunk, see prefetch)
+    unsigned aoff[PA], aoff2[PA];    // MODE 0/1: element offset of the row in A / in the second source
 #pragma unroll
     for (int j = 0; j < PA; ++j) {
         const int m = m0 + lrow + 8 * j;
-        avalid[j] = m < p.M;
-        const int mm = avalid[j] ? m : 0;
-        const int b = mm / p.rpb;
-        const int r = mm - b * p.rpb;
-        const int oy = r / p.OW, ox = r - oy * p.OW;
-        ay0[j] = oy * p.stride - p.pad_h;
-        ax0[j] = ox * p.stride - p.pad_w;
-        ab[j] = b;
+        const int mm = m < p.M ? m : p.M - 1;      // rows past M compute garbage that is never stored
+        if constexpr (GATHER) {
+            const int b = mm / p.rpb;
+            const int r = mm - b * p.rpb;
+            const int oy = r / p.OW, ox = r - oy * p.OW;
+            ay0[j] = oy * p.stride - p.pad_h;
+            ax0[j] = ox * p.stride - p.pad_w;
+            ab[j] = b;
+        } else {
+            aoff[j] = (unsigned)mm * (unsigned)p.lda + lseg;
+            aoff2[j] = (unsigned)mm * (unsigned)p.lda2 + lseg;
+        }
     }
     unsigned woff[PW];
 #pragma unroll
@@ -86,8 +107,8 @@ __global__ __launch_bounds__(64 * NW) void lin_gemm_kernel(CGParams p) {
     }
     const int vIH = p.vIH, vIW = p.vIW;
     // running (tap, channel) position of the next chunk to prefetch
-    int pf_c0, pf_ty, pf_tx;
-    {
+    int pf_c0 = c_begin * CH, pf_ty = 0, pf_tx = 0;
+    if constexpr (GATHER) {
         const int k0 = c_begin * CH;
         const int tap = k0 / p.Cin;
         pf_c0 = k0 - tap * p.Cin;
@@ -95,49 +116,99 @@ __global__ __launch_bounds__(64 * NW) void lin_gemm_kernel(CGParams p) {
         pf_tx = tap - pf_ty * p.KW;
     }
 
-    float4 ra[DEPTH][PA], rw[DEPTH][PW];
-    unsigned rmask[DEPTH];
-
-    auto prefetch = [&](int kc, float4 (&a)[PA], float4 (&w)[PW], unsigned& mask) {
-        const int k0 = min(kc, nch - 1) * CH;               // dead prefetches past the end stay in bounds
-        const int dy = pf_ty * p.dil_h, dx = pf_tx * p.dil_w;
-        int c0 = pf_c0;
-        pf_c0 += CH;
-        if (pf_c0 >= p.Cin) {
-            pf_c0 = 0;
-            if (++pf_tx == p.KW) { pf_tx = 0; ++pf_ty; }
-        }
-        // wave-uniform source select (C1 is a multiple of the chunk width)
-        const float* src = p.A;
-        int ld = p.lda, bs = p.a_bs;
-        if (p.C1 > 0 && c0 >= p.C1) { src = p.A2; ld = p.lda2; bs = p.a_bs2; c0 -= p.C1; }
-        unsigned mk = 0;
+    // epilogue operands of this thread's outputs are fetched NOW (column t & 31 of rows (t >> 5) + 2*NW*i of every 32x32
+    // sub-tile): after the last barrier the finish is LDS reads, arithmetic and stores -- no dependent global load
+    const int col = tid & 31;
+    constexpr int RSTEP = 2 * NW;
+    constexpr int RI = (32 + RSTEP - 1) / RSTEP;
+    // simple rows (every Linear of the U-Net): output row = m, no per-batch row vector, no accumulate modes
+    const bool simple = p.o_mul == 1 && p.o_add == 0 && p.out_bs == p.rpb && p.o_len == p.rpb && p.accumulate == 0 &&
+                        (p.rowvec == nullptr || p.ln_mode);
+    float e_bias[TN], e_sum[TN], e_res[TM][RI][TN];
 #pragma unroll
-        for (int j = 0; j < PA; ++j) {
-            const int iy = ay0[j] + dy, ix = ax0[j] + dx;
-            const bool ok = avalid[j] & ((unsigned)iy < (unsigned)vIH) & ((unsigned)ix < (unsigned)vIW);
-            const int cy = ok ? (iy >> p.up) : 0, cx = ok ? (ix >> p.up) : 0;
-            const unsigned off = (unsigned)ab[j] * (unsigned)bs + (unsigned)(cy * p.IW + cx) * (unsigned)ld + c0 + lseg;
-            a[j] = *reinterpret_cast<const float4*>(src + (ok ? off : (unsigned)lseg));
-            mk |= ok ? (1u << j) : 0u;
+    for (int b = 0; b < TN; ++b) {
+        const int no = min(n0 + b * 32 + col, p.N - 1);
+        e_bias[b] = p.bias ? p.bias[no] : 0.f;
+        e_sum[b] = LN ? p.rowvec[no] : 0.f;
+    }
+    if (simple && p.res != nullptr) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int i = 0; i < RI; ++i)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    const int mo = min(m0 + a * 32 + min((tid >> 5) + RSTEP * i, 31), p.M - 1);
+                    const int no = min(n0 + b * 32 + col, p.N - 1);
+                    e_res[a][i][b] = p.res[(size_t)mo * p.ldr + no];
+                }
+    } else {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int i = 0; i < RI; ++i)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) e_res[a][i][b] = 0.f;
+    }
+
+    float4 ra[DEPTH][PA], rw[DEPTH][PW];
+    float rmask[DEPTH][GATHER ? PA : 1];
+
+    auto prefetch = [&](int kc, float4 (&a)[PA], float4 (&w)[PW], float (&mask)[GATHER ? PA : 1]) {
+        const int k0 = min(kc, nch - 1) * CH;               // dead prefetches past the end stay in bounds
+        if constexpr (GATHER) {
+            const int dy = pf_ty * p.dil_h, dx = pf_tx * p.dil_w;
+            int c0 = pf_c0;
+            pf_c0 += CH;
+            if (pf_c0 >= p.Cin) {
+                pf_c0 = 0;
+                if (++pf_tx == p.KW) { pf_tx = 0; ++pf_ty; }
+            }
+            // wave-uniform source select (C1 is a multiple of the chunk width)
+            const float* src = p.A;
+            int ld = p.lda, bs = p.a_bs;
+            if (p.C1 > 0 && c0 >= p.C1) { src = p.A2; ld = p.lda2; bs = p.a_bs2; c0 -= p.C1; }
+#pragma unroll
+            for (int j = 0; j < PA; ++j) {
+                const int iy = ay0[j] + dy, ix = ax0[j] + dx;
+                const bool ok = ((unsigned)iy < (unsigned)vIH) & ((unsigned)ix < (unsigned)vIW);
+                // clamped, always-valid address; the zero padding is a multiply by 0.0 at the LDS write, so the load is
+                // unconditional and stays in flight (a select lets the compiler sink the load into a branch)
+                const int cy = min(max(iy, 0), vIH - 1) >> p.up, cx = min(max(ix, 0), vIW - 1) >> p.up;
+                const unsigned off = (unsigned)ab[j] * (unsigned)bs + (unsigned)(cy * p.IW + cx) * (unsigned)ld + c0 + lseg;
+                a[j] = *reinterpret_cast<const float4*>(src + off);
+                mask[j] = ok ? 1.0f : 0.0f;
+            }
+        } else {
+            int c0 = k0;
+            if (p.C1 > 0 && c0 >= p.C1) {                   // wave-uniform
+                c0 -= p.C1;
+#pragma unroll
+                for (int j = 0; j < PA; ++j) a[j] = *reinterpret_cast<const float4*>(p.A2 + aoff2[j] + c0);
+            } else {
+#pragma unroll
+                for (int j = 0; j < PA; ++j) a[j] = *reinterpret_cast<const float4*>(p.A + aoff[j] + c0);
+            }
         }
-        mask = mk;
 #pragma unroll
         for (int j = 0; j < PW; ++j) w[j] = *reinterpret_cast<const float4*>(p.W + woff[j] + k0);
     };
 
-    auto stage_write = [&](const float4 (&a)[PA], const float4 (&w)[PW], unsigned mask) {
+    auto stage_write = [&](const float4 (&a)[PA], const float4 (&w)[PW], const float (&mask)[GATHER ? PA : 1]) {
 #pragma unroll
         for (int j = 0; j < PA; ++j) {
             float4 v = a[j];
-            if (!((mask >> j) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p.in_act) {
-                v.x = in_transform(v.x, p.in_act, p.in_slope);
-                v.y = in_transform(v.y, p.in_act, p.in_slope);
-                v.z = in_transform(v.z, p.in_act, p.in_slope);
-                v.w = in_transform(v.w, p.in_act, p.in_slope);
+            if constexpr (GATHER) {
+                v.x *= mask[j]; v.y *= mask[j]; v.z *= mask[j]; v.w *= mask[j];
+                if (p.in_act == AED_ACT_SILU) {             // f(0) = 0 keeps the zero padding
+                    v.x = v.x / (1.0f + __expf(-v.x)); v.y = v.y / (1.0f + __expf(-v.y));
+                    v.z = v.z / (1.0f + __expf(-v.z)); v.w = v.w / (1.0f + __expf(-v.w));
+                } else if (p.in_act == AED_ACT_LEAKY) {
+                    v.x = v.x > 0.f ? v.x : v.x * p.in_slope; v.y = v.y > 0.f ? v.y : v.y * p.in_slope;
+                    v.z = v.z > 0.f ? v.z : v.z * p.in_slope; v.w = v.w > 0.f ? v.w : v.w * p.in_slope;
+                }
             }
-            *reinterpret_cast<float4*>(As + (lrow + 8 * j) * LD + lseg) = v;
+            *reinterpret_cast<float4*>(As + (lrow + 8 * j) * LD + lseg) = make_float4(v.x, v.y, v.z, v.w);
         }
 #pragma unroll
         for (int j = 0; j < PW; ++j) {
@@ -160,47 +231,59 @@ __global__ __launch_bounds__(64 * NW) void lin_gemm_kernel(CGParams p) {
     const float* a_frag = As + fi * LD + 4 * fh;
     const float* b_frag = Ws + fi * LD + 4 * fh;
 
+    // the MFMAs of one staged chunk; the fragments of k-block kb+1 are fetched before the MFMAs of kb issue
     auto mfma_chunk = [&]() {
+        float4 af[2][TM], bf[2][TN];
+#pragma unroll
+        for (int a = 0; a < TM; ++a) af[0][a] = *reinterpret_cast<const float4*>(a_frag + a * 32 * LD);
+#pragma unroll
+        for (int b = 0; b < TN; ++b) bf[0][b] = *reinterpret_cast<const float4*>(b_frag + b * 32 * LD);
 #pragma unroll
         for (int kb = 0; kb < CH / 8; ++kb) {
-            float4 af[TM], bf[TN];
+            const int c = kb & 1, nx = c ^ 1;
+            if (kb + 1 < CH / 8) {
 #pragma unroll
-            for (int a = 0; a < TM; ++a) af[a] = *reinterpret_cast<const float4*>(a_frag + a * 32 * LD + 8 * kb);
+                for (int a = 0; a < TM; ++a)
+                    af[nx][a] = *reinterpret_cast<const float4*>(a_frag + a * 32 * LD + 8 * (kb + 1));
 #pragma unroll
-            for (int b = 0; b < TN; ++b) bf[b] = *reinterpret_cast<const float4*>(b_frag + b * 32 * LD + 8 * kb);
-            if (p.ln_mode) {
+                for (int b = 0; b < TN; ++b)
+                    bf[nx][b] = *reinterpret_cast<const float4*>(b_frag + b * 32 * LD + 8 * (kb + 1));
+            }
+            if constexpr (LN) {
 #pragma unroll
                 for (int a = 0; a < TM; ++a) {
-                    ln_s1[a] += (af[a].x + af[a].y) + (af[a].z + af[a].w);
-                    ln_s2[a] += (af[a].x * af[a].x + af[a].y * af[a].y) + (af[a].z * af[a].z + af[a].w * af[a].w);
+                    const float4 v = af[c][a];
+                    ln_s1[a] += (v.x + v.y) + (v.z + v.w);
+                    ln_s2[a] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
                 }
             }
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
                 for (int b = 0; b < TN; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].x, bf[b].x, acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][a].x, bf[c][b].x, acc[a][b], 0, 0, 0);
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
                 for (int b = 0; b < TN; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].y, bf[b].y, acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][a].y, bf[c][b].y, acc[a][b], 0, 0, 0);
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
                 for (int b = 0; b < TN; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].z, bf[b].z, acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][a].z, bf[c][b].z, acc[a][b], 0, 0, 0);
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
                 for (int b = 0; b < TN; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].w, bf[b].w, acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][a].w, bf[c][b].w, acc[a][b], 0, 0, 0);
         }
     };
 
     // every prefetch is unconditional (clamped addresses): the number of loads in flight is static
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) prefetch(c_begin + d, ra[d], rw[d], rmask[d]);
+    STAMP();
     for (int kc0 = c_begin; kc0 < c_end; kc0 += DEPTH) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
@@ -215,6 +298,7 @@ __global__ __launch_bounds__(64 * NW) void lin_gemm_kernel(CGParams p) {
             mfma_chunk();
             LDS_ORDER();
             __builtin_amdgcn_wave_barrier();
+            STAMP();
         }
     }
 
@@ -225,7 +309,7 @@ __global__ __launch_bounds__(64 * NW) void lin_gemm_kernel(CGParams p) {
         for (int b = 0; b < TN; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) slab[((a * TN + b) * 16 + r) * 64 + lane] = acc[a][b][r];
-    if (p.ln_mode) {
+    if constexpr (LN) {
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
             const float s1 = ln_s1[a] + __shfl_xor(ln_s1[a], 32, 64);
@@ -233,20 +317,23 @@ __global__ __launch_bounds__(64 * NW) void lin_gemm_kernel(CGParams p) {
             if (fh == 0) { ln_part[wave][a * 32 + fi][0] = s1; ln_part[wave][a * 32 + fi][1] = s2; }
         }
     }
+    STAMP();
     __syncthreads();
+    STAMP();
 
     // ---- finish: thread t owns column t & 31 of rows (t >> 5) + 2*NW*i of every 32x32 sub-tile
-    const int col = tid & 31;
-    constexpr int RSTEP = 2 * NW;
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
-        for (int row = tid >> 5; row < 32; row += RSTEP) {
+#pragma unroll
+        for (int i = 0; i < RI; ++i) {
+            const int row = (tid >> 5) + RSTEP * i;
+            if (row >= 32) break;
             const int h = (row >> 2) & 1;
             const int r = (row & 3) + 4 * (row >> 3);
             const int src_lane = col + 32 * h;
             const int mo = m0 + a * 32 + row;
             float mean = 0.f, rstd = 1.f;
-            if (p.ln_mode) {
+            if constexpr (LN) {
                 float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                 for (int w = 0; w < NW; ++w) { s1 += ln_part[w][a * 32 + row][0]; s2 += ln_part[w][a * 32 + row][1]; }
@@ -257,27 +344,39 @@ __global__ __launch_bounds__(64 * NW) void lin_gemm_kernel(CGParams p) {
             float v[TN];
 #pragma unroll
             for (int b = 0; b < TN; ++b) {
-                float s = 0.f;
+                float sacc = 0.f;
 #pragma unroll
-                for (int w = 0; w < NW; ++w) s += smem[w * WAVE_LDS + ((a * TN + b) * 16 + r) * 64 + src_lane];
-                v[b] = s;
+                for (int w = 0; w < NW; ++w) sacc += smem[w * WAVE_LDS + ((a * TN + b) * 16 + r) * 64 + src_lane];
+                v[b] = sacc;
             }
             if (mo >= p.M) continue;
-            if (p.geglu) {
+            if (TN % 2 == 0 && p.geglu) {
                 // packed columns: sub-tile 2q holds 32 value columns, sub-tile 2q+1 the matching 32 gate columns
 #pragma unroll
                 for (int b = 0; b + 1 < TN; b += 2) {
                     const int nv = n0 + b * 32 + col, ng = nv + 32;
                     if (ng >= p.N) continue;
                     float val = v[b], gate = v[b + 1];
-                    if (p.ln_mode) {
-                        val = rstd * (val - mean * p.rowvec[nv]);
-                        gate = rstd * (gate - mean * p.rowvec[ng]);
+                    if constexpr (LN) {
+                        val = rstd * (val - mean * e_sum[b]);
+                        gate = rstd * (gate - mean * e_sum[b + 1]);
                     }
-                    if (p.bias) { val += p.bias[nv]; gate += p.bias[ng]; }
+                    val += e_bias[b];
+                    gate += e_bias[b + 1];
                     const int b0 = mo / p.rpb;
                     const size_t orow = (size_t)b0 * p.out_bs + (mo - b0 * p.rpb);
                     p.C[orow * p.ldc + (n0 >> 1) + b * 16 + col] = val * gelu_exact(gate);
+                }
+            } else if (simple) {
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    const int no = n0 + b * 32 + col;
+                    if (no >= p.N) continue;
+                    float val = v[b];
+                    if constexpr (LN) val = rstd * (val - mean * e_sum[b]);
+                    val += e_bias[b] + e_res[a][i][b];
+                    if (p.out_act != AED_ACT_NONE) val = aed_apply_act(val, p.out_act, p.out_p);
+                    p.C[(size_t)mo * p.ldc + no] = val;
                 }
             } else {
 #pragma unroll
@@ -285,35 +384,52 @@ __global__ __launch_bounds__(64 * NW) void lin_gemm_kernel(CGParams p) {
                     const int no = n0 + b * 32 + col;
                     if (no >= p.N) continue;
                     float val = v[b];
-                    if (p.ln_mode) val = rstd * (val - mean * p.rowvec[no]);
+                    if constexpr (LN) val = rstd * (val - mean * e_sum[b]);
                     store_out(p, mo, no, val);
                 }
             }
         }
     }
+    STAMP();
+    if (dbg_on) p.dbg[dbg_end] = dbg_n - (last_wg ? 16 : 0);
+#undef STAMP
 }
 
-template <int NW, int TM, int TN, int DEPTH>
-static int launch_lin(const CGParams& p, hipStream_t s) {
+template <int NW, int TM, int TN, int DEPTH, int MODE>
+static int launch_lin_mode(const CGParams& p, hipStream_t s) {
     constexpr int WAVE_LDS = (32 * TM + 32 * TN) * 36;
     const size_t bytes = sizeof(float) * NW * WAVE_LDS;
     static bool attr_set = false;
     if (!attr_set) {
-        AED_CHECK_HIP(hipFuncSetAttribute((const void*)lin_gemm_kernel<NW, TM, TN, DEPTH>,
+        AED_CHECK_HIP(hipFuncSetAttribute((const void*)lin_gemm_kernel<NW, TM, TN, DEPTH, MODE>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
         attr_set = true;
     }
     dim3 grid(aed_cdiv(p.N, 32 * TN), aed_cdiv(p.M, 32 * TM), 1);
-    hipLaunchKernelGGL((lin_gemm_kernel<NW, TM, TN, DEPTH>), grid, dim3(64 * NW), bytes, s, p);
+    hipLaunchKernelGGL((lin_gemm_kernel<NW, TM, TN, DEPTH, MODE>), grid, dim3(64 * NW), bytes, s, p);
     return 0;
 }
 
+template <int NW, int TM, int TN, int DEPTH>
+static int launch_lin(const CGParams& p, hipStream_t s) {
+    // uniformly strided rows: a Linear, or a 1x1 stride-1 convolution whose batch items are contiguous
+    const bool uniform = p.KH * p.KW == 1 && p.stride == 1 && p.pad_h == 0 && p.pad_w == 0 && p.up == 0 &&
+                         (p.M == p.rpb || p.a_bs == p.rpb * p.lda) && p.IH * p.IW == p.rpb &&
+                         (p.C1 == 0 || p.M == p.rpb || p.a_bs2 == p.rpb * p.lda2) && p.in_act == 0;
+    if (p.ln_mode) {
+        AED_REQUIRE(uniform, "lin_gemm: the fused LayerNorm needs uniformly strided rows");
+        return launch_lin_mode<NW, TM, TN, DEPTH, 1>(p, s);
+    }
+    if (uniform) return launch_lin_mode<NW, TM, TN, DEPTH, 0>(p, s);
+    return launch_lin_mode<NW, TM, TN, DEPTH, 2>(p, s);
+}
+
 // cfg: 10 = 4 waves 32x32 | 11 = 8 waves 32x32 | 12 = 16 waves 32x32 | 13 = 4 waves 32x64 | 14 = 8 waves 32x64 |
-//      15 = 4 waves 64x64 | 16 = 4 waves 64x32 | 17 = 8 waves 64x64
+//      15 = 4 waves 64x64 | 16 = 4 waves 64x32 | 17 = 8 waves 64x64 | 18 = 10 waves 32x32 | 19 = 12 waves 32x32
+//      (10 / 12 waves split K = 640 / 384 -- the channel counts of U-Net levels 3 / 2 -- into equal chunk counts)
 int launch_lin_gemm(const CGParams& p, int cfg, hipStream_t s) {
     AED_REQUIRE(p.Cin % 32 == 0 && p.lda % 4 == 0 && ((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.W % 16) == 0,
                 "lin_gemm: needs Cin %% 32 == 0 and 16-byte aligned operands (Cin=%d lda=%d)", p.Cin, p.lda);
-    AED_REQUIRE(p.ksplit <= 1 && p.accumulate == 0 || !p.geglu, "lin_gemm: GEGLU epilogue cannot split or accumulate");
     AED_REQUIRE(p.ksplit <= 1, "lin_gemm: K is split across the wavefronts of a workgroup, not across workgroups");
     if (p.C1 > 0)
         AED_REQUIRE(p.A2 && p.C1 % 32 == 0 && p.C1 < p.Cin && p.lda2 % 4 == 0 && ((uintptr_t)p.A2 % 16) == 0,
@@ -332,6 +448,8 @@ int launch_lin_gemm(const CGParams& p, int cfg, hipStream_t s) {
         case 15: rc = launch_lin<4, 2, 2, 1>(p, s); break;
         case 16: rc = launch_lin<4, 2, 1, 2>(p, s); break;
         case 17: rc = launch_lin<8, 2, 2, 1>(p, s); break;
+        case 18: rc = launch_lin<10, 1, 1, 2>(p, s); break;
+        case 19: rc = launch_lin<12, 1, 1, 2>(p, s); break;
         default: AED_REQUIRE(false, "lin_gemm: bad tile cfg %d", cfg);
     }
     if (rc) return rc;

@@ -180,61 +180,11 @@ __global__ __launch_bounds__(256) void gn_scale_shift_kernel(const float* __rest
 // computes the statistics of its slice and normalises it in the same launch (the slice -- at most a few
 // hundred KB -- is re-read from L1/L2).  At U-Net batch 2 a GroupNorm is latency-bound, so one launch
 // instead of two is what matters; large maps (VAE) keep the two-pass streaming kernels above.
-__global__ __launch_bounds__(256) void gn_small_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, float* __restrict__ y, int HW,
-                                                        int C, int G, int ldx, int ldy, float eps, int act,
-                                                        const float* __restrict__ x2, int C1, int ldx2) {
-    __shared__ double rs[4], rss[4];
-    const int tid = threadIdx.x, g = blockIdx.x, b = blockIdx.y;
-    const int cpg = C / G, cpg4 = cpg >> 2;
-    const size_t rb = (size_t)b * HW;
-    float* yb = y + (size_t)b * HW * ldy + g * cpg;
-    const int total = HW * cpg4;
-    float s = 0.f, ss = 0.f;
-    for (int e = tid; e < total; e += 256) {
-        const int row = e / cpg4, j = e - row * cpg4;
-        const float4 v = *reinterpret_cast<const float4*>(gn_src(x, x2, C1, ldx, ldx2, rb + row, g * cpg + 4 * j));
-        s += (v.x + v.y) + (v.z + v.w);
-        ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-    }
-    double ds = (double)s, dss = (double)ss;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { ds += __shfl_xor(ds, o, 64); dss += __shfl_xor(dss, o, 64); }
-    if ((tid & 63) == 0) { rs[tid >> 6] = ds; rss[tid >> 6] = dss; }
-    __syncthreads();
-    ds = (rs[0] + rs[1]) + (rs[2] + rs[3]);
-    dss = (rss[0] + rss[1]) + (rss[2] + rss[3]);
-    const double n = (double)HW * (double)cpg;
-    const double dmean = ds / n;
-    double var = dss / n - dmean * dmean;
-    if (var < 0.0) var = 0.0;
-    const float mean = (float)dmean;
-    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-    for (int e = tid; e < total; e += 256) {
-        const int row = e / cpg4, j = e - row * cpg4;
-        float4 v = *reinterpret_cast<const float4*>(gn_src(x, x2, C1, ldx, ldx2, rb + row, g * cpg + 4 * j));
-        const float4 ga = *reinterpret_cast<const float4*>(gamma + g * cpg + 4 * j);
-        const float4 be = *reinterpret_cast<const float4*>(beta + g * cpg + 4 * j);
-        v.x = (v.x - mean) * rstd * ga.x + be.x;
-        v.y = (v.y - mean) * rstd * ga.y + be.y;
-        v.z = (v.z - mean) * rstd * ga.z + be.z;
-        v.w = (v.w - mean) * rstd * ga.w + be.w;
-        if (act == AED_ACT_SILU) {
-            v.x = v.x / (1.0f + expf(-v.x));
-            v.y = v.y / (1.0f + expf(-v.y));
-            v.z = v.z / (1.0f + expf(-v.z));
-            v.w = v.w / (1.0f + expf(-v.w));
-        }
-        *reinterpret_cast<float4*>(yb + (size_t)row * ldy + 4 * j) = v;
-    }
-}
-// Second generation (opt-in: op slot i7 = 1): written from the ISA of the kernel above at the end of round 1; its
-// parity tests pass on the MI355X, its speed has not been measured yet, so it is not the default.  Same arithmetic
-// in the same order (bit-identical sums); the ISA of the first version waits on every load right where it is issued (run-time-bounded loop with one load
-// per trip), i.e. HW*C/(G*1024) dependent memory round trips per pass.  Here U loads are issued back to back
-// (clamped addresses, masked use) before anything is consumed.
+// U loads are issued back to back (clamped addresses, masked use) before anything is consumed: round 1's first version
+// waited on every load where it was issued (run-time-bounded loop, one load per trip); measured in round 2 this one is
+// ~10 % faster per launch at U-Net batch 2.
 template <int U>
-__global__ __launch_bounds__(256) void gn_small2_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256) void gn_small_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float* __restrict__ y, int HW,
                                                          int C, int G, int ldx, int ldy, float eps, int act,
                                                          const float* __restrict__ x2, int C1, int ldx2) {
@@ -312,21 +262,16 @@ __global__ __launch_bounds__(256) void gn_small2_kernel(const float* __restrict_
         }
     }
 }
-// slots: p0=x p1=gamma p2=beta p3=y p4=x2(or null) ; i0=B i1=HW i2=C i3=G i4=ldx i5=ldy i6=act i7=variant(1 = v2)
+// slots: p0=x p1=gamma p2=beta p3=y p4=x2(or null) ; i0=B i1=HW i2=C i3=G i4=ldx i5=ldy i6=act i7=(unused)
 //        i8=C1 i9=ldx2 (two-source rows, see gn_src) ; f0=eps
 int launch_gn_small(const aed_op* op, hipStream_t s) {
     const int32_t* i = op->i;
     AED_REQUIRE(op->p[0] && op->p[1] && op->p[2] && op->p[3], "gn_small: null pointer");
     AED_REQUIRE(i[2] % (4 * i[3]) == 0 && i[4] % 4 == 0 && i[5] % 4 == 0, "gn_small: C=%d G=%d", i[2], i[3]);
     AED_REQUIRE(!op->p[4] || (i[8] > 0 && i[8] < i[2] && i[8] % 4 == 0 && i[9] % 4 == 0), "gn_small: bad two-source split");
-    if (i[7] == 1)
-        hipLaunchKernelGGL(gn_small2_kernel<4>, dim3(i[3], i[0]), dim3(256), 0, s, (const float*)op->p[0],
-                           (const float*)op->p[1], (const float*)op->p[2], (float*)op->p[3], i[1], i[2], i[3], i[4], i[5],
-                           op->f[0], i[6], (const float*)op->p[4], i[8], i[9]);
-    else
-        hipLaunchKernelGGL(gn_small_kernel, dim3(i[3], i[0]), dim3(256), 0, s, (const float*)op->p[0],
-                           (const float*)op->p[1], (const float*)op->p[2], (float*)op->p[3], i[1], i[2], i[3], i[4], i[5],
-                           op->f[0], i[6], (const float*)op->p[4], i[8], i[9]);
+    hipLaunchKernelGGL(gn_small_kernel<4>, dim3(i[3], i[0]), dim3(256), 0, s, (const float*)op->p[0],
+                       (const float*)op->p[1], (const float*)op->p[2], (float*)op->p[3], i[1], i[2], i[3], i[4], i[5],
+                       op->f[0], i[6], (const float*)op->p[4], i[8], i[9]);
     AED_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -21,9 +21,8 @@ CU_COUNT = 256          # MI355X; tiling heuristics target this, overridable for
 
 # A/B switch for the K-chunk width of conv_gemm: 0 auto, 1 force 32, 2 allow 64 on the 128x128 tile too
 FORCE_BK = int(os.environ.get("AED_FORCE_BK", "0"))
-# attention kernel variant (see Tape.attention); 0 = the measured default
-ATTN_VARIANT = int(os.environ.get("AED_ATTN_VARIANT", "0"))
-GN_VARIANT = int(os.environ.get("AED_GN_VARIANT", "0"))          # single-launch GroupNorm kernel generation
+ATTN_VARIANT = int(os.environ.get("AED_ATTN_VARIANT", "0"))      # 0 auto (split-KV when Nk > 64), 1 forces single-pass
+GN_VARIANT = 0                                                   # (round-1 A/B switch; one kernel generation remains)
 # 1 (default): small contractions go to the latency-regime kernels of lin_gemm.hip; 0: round-1 routing (A/B runs)
 LIN_MODE = int(os.environ.get("AED_LIN_MODE", "1"))
 # measured (tile, ksplit) per (M, N, K, geglu), filled from tools/tile_sweep.py runs (see tile_table.py); the
@@ -90,9 +89,9 @@ class Tape:
     # tile codes of AED_OP_CONV_GEMM (slot i29): 1/2/4/5/6 = LDS-staged block tiles 128x128 / 128x64 / 64x64 / 128x32 /
     # 32x128 (conv_gemm.hip), 7 = round-1 wave-split-K kernel, 10..17 = latency-regime kernels of lin_gemm.hip:
     # (waves, tile) 10 = (4, 32x32), 11 = (8, 32x32), 12 = (16, 32x32), 13 = (4, 32x64), 14 = (8, 32x64),
-    # 15 = (4, 64x64), 16 = (4, 64x32), 17 = (8, 64x64)
+    # 15 = (4, 64x64), 16 = (4, 64x32), 17 = (8, 64x64), 18 = (10, 32x32), 19 = (12, 32x32)
     LIN_TILES = {10: (32, 32), 11: (32, 32), 12: (32, 32), 13: (32, 64), 14: (32, 64), 15: (64, 64), 16: (64, 32),
-                 17: (64, 64)}
+                 17: (64, 64), 18: (32, 32), 19: (32, 32)}
 
     @staticmethod
     def pick_tile(M, N, K, cus=None, vector_ok=True, geglu=False, lin_ok=True):
@@ -244,8 +243,7 @@ class Tape:
     # ------------------------------------------------------------------ attention & friends
     def attention(self, q, k, v, out, *, B, H, Nq, Nk, D, ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, scale,
                   bias=None, ld_bias=0, variant=None, name="attn"):
-        """variant: 0 auto (split-KV kernel when Nk > 64), 1 single-pass kernel, 2 opt-in second-generation split-KV
-        kernel (batched/prefetched staging, DPP row reductions; default comes from AED_ATTN_VARIANT)."""
+        """variant: 0 auto (split-KV kernel when Nk > 64), 1 single-pass kernel."""
         variant = ATTN_VARIANT if variant is None else variant
         self._add(L.OP_ATTENTION, [B, H, Nq, Nk, D, ldq, ldk, ldv, ldo, ld_bias, bsq, bsk, bsv, bso, variant], [scale],
                   [q, k, v, bias, out], name=name, flops=4 * B * H * Nq * Nk * D,

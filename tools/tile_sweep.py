@@ -59,7 +59,7 @@ def candidates(M, N, K, taps, geglu, generic):
     if geglu:
         c = [(13, 1), (14, 1), (15, 1), (17, 1), (1, 1)]
     else:
-        c = [(10, 1), (11, 1), (12, 1), (13, 1), (15, 1), (16, 1), (17, 1), (4, 1), (1, 1), (2, 1)]
+        c = [(10, 1), (11, 1), (12, 1), (18, 1), (19, 1), (13, 1), (15, 1), (16, 1), (17, 1), (4, 1), (1, 1), (2, 1)]
         t4 = -(-M // 64) * -(-N // 64)
         if t4 < 256 and K >= 256:          # legacy split-K + reduce
             nch = -(-K // 32)

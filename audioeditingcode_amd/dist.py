@@ -49,10 +49,13 @@ def _arena_shapes(shapes: Dict[str, tuple]):
     return offs, total
 
 
-def broadcast_state_dict(sd, shapes: Dict[str, tuple], device, src: int = 0, max_bucket: int = 1 << 28):
+def broadcast_state_dict(sd, shapes: Dict[str, tuple], device, src: int = 0, max_bucket: int = 1 << 28,
+                         on_device: bool = False):
     """Broadcast one component's weights as contiguous fp32 arenas of <= max_bucket elements (1 GiB).
     `sd` is the real state dict on `src` and may be None elsewhere; `shapes` (name -> shape, identical and
-    identically ordered on every rank) comes from weights.*_param_shapes.  Returns the state dict."""
+    identically ordered on every rank) comes from weights.*_param_shapes.  Returns the state dict.
+    on_device=True: the returned tensors are views of the received arenas on `device` (no host bounce: the engines'
+    weight packers consume device tensors directly); False keeps the round-1 behaviour (CPU copies)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return sd
     rank = dist.get_rank()
@@ -74,10 +77,10 @@ def broadcast_state_dict(sd, shapes: Dict[str, tuple], device, src: int = 0, max
                 p += cnt
         dist.broadcast(arena, src=src)
         p = 0
-        cpu = arena.cpu()
+        flat = arena if on_device else arena.cpu()
         for k in names[i:j]:
             cnt, shp = offs[k][1], offs[k][2]
-            out[k] = cpu[p:p + cnt].view(shp).clone()
+            out[k] = flat[p:p + cnt].view(shp) if on_device else flat[p:p + cnt].view(shp).clone()
             p += cnt
         i = j
     return out

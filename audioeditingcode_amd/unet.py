@@ -26,6 +26,7 @@ from .weights import ctx_dims_per_block, _per_block
 
 FUSE_GEGLU = os.environ.get("AED_FUSE_GEGLU", "1") != "0"
 TWO_SOURCE = os.environ.get("AED_TWO_SOURCE", "1") != "0"
+MERGE_FF2_PROJ = os.environ.get("AED_MERGE_FF2_PROJ", "1") != "0"
 
 
 def geglu_pack_index(dff):
@@ -110,6 +111,20 @@ class PackedUNetWeights:
                     self._fold_ln(blk + ".ff1g_ln", v[perm], sd[blk + ".norm3.weight"], sd[blk + ".norm3.bias"], b1[perm])
                     wd[blk + ".ff1g.weight"] = self._dev(v[perm])
                     wd[blk + ".ff1g.bias"] = self._dev(b1[perm])
+            if k.endswith(".ff.net.2.weight"):
+                # FF2 followed by the site's proj_out is one linear map of [f | t2] (exact algebra, folded in fp64):
+                #   proj_out(ff2(f) + t2) = f.(Wp.W2)^T + t2.Wp^T + (Wp.b2 + bp)
+                # -> one GEMM with K = 4C + C over a two-source A instead of two dependent launches (same FLOPs)
+                blk = k[: -len(".ff.net.2.weight")]
+                site = blk[: blk.index(".transformer_blocks")]
+                wp = sd[site + ".proj_out.weight"]
+                if wp.dim() == 4:
+                    wp = wp.reshape(wp.shape[0], -1)
+                w2, b2, bp = v.double(), sd[blk + ".ff.net.2.bias"].double(), sd[site + ".proj_out.bias"].double()
+                wp = wp.double()
+                if w2.shape[1] % 64 == 0:
+                    wd[blk + ".ff2_proj.weight"] = self._dev(torch.cat([wp @ w2, wp], 1).float())
+                    wd[blk + ".ff2_proj.bias"] = self._dev((wp @ b2 + bp).float())
             if k.endswith(".to_k.weight") or k.endswith(".to_v.weight"):
                 continue
             wd[k] = self._dev(v)
@@ -124,6 +139,8 @@ class UNetEngine:
         # copy launches).  The environment switches exist for A/B profiling runs only.
         self.fuse_geglu = FUSE_GEGLU if fuse_geglu is None else fuse_geglu
         self.two_source = TWO_SOURCE if two_source is None else two_source
+        # FF2 and the site's proj_out as one GEMM over [f | t2] with host-folded weights (one dependent launch less)
+        self.merge_ff2_proj = MERGE_FF2_PROJ and self.two_source
         # GroupNorm(+SiLU) inside the conv A-loader is implemented and parity-tested but OFF by default: measured
         # on MI355X it is a wash at U-Net batch 2 (11.53 vs 11.51 ms/forward) and 5 % slower at batch 32
         # (77.8 vs 73.8 ms): the loader's 9x-per-tap SiLU recompute costs more than the saved launch + round trip.
@@ -255,6 +272,10 @@ class UNetEngine:
             self._ln_linear(t2 if F else ln, b + ".ff1_ln", wd[b + ".ff.net.0.proj.weight"],
                             wd[b + ".ff.net.0.proj.bias"], g, M, C, 8 * C, F, b + ".ff1")
             tp.geglu(g, f, M=M, Dff=4 * C, name=b + ".geglu")
+        if self.merge_ff2_proj and (b + ".ff2_proj.weight") in wd:
+            tp.linear(f, wd[b + ".ff2_proj.weight"], wd[b + ".ff2_proj.bias"], dest, M=M, K=5 * C, N=C, x2=t2,
+                      C1=4 * C, res=x, name=b + ".ff2+proj_out")
+            return dest
         t3 = self.tmp("t_3", M, C)
         tp.linear(f, wd[b + ".ff.net.2.weight"], wd[b + ".ff.net.2.bias"], t3, M=M, K=4 * C, N=C, res=t2,
                   name=b + ".ff2")

@@ -12,8 +12,12 @@ collective; weights broadcast once from rank 0 over RCCL, edited latents gathere
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,7 +33,28 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(fam, state_dicts, cores):
+def csrc_hash():
+    """sha1 over the native sources: ties a committed PMC traffic summary to the binary being benched."""
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(ROOT, "audioeditingcode_amd", "csrc", "*.h*"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:12]
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a torchrun environment: launch the N ranks ourselves (one process per GPU)
+    and relay rank 0's JSON line.  The driver's own torchrun launch sets WORLD_SIZE and never gets here."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    log(f"--gpus {n} without WORLD_SIZE: spawning {n} ranks through torch.distributed.run (port {port})")
+    return subprocess.call(cmd, env=env)
+
+
+def cpu_baseline(fam, state_dicts, cores, anchor_steps=50):
     """The oracle (CPU restatement pinned to the reference, oracle/) timed on the host cores on a bounded
     sample: 1 warm + 3 timed AudioLDM2 U-Net forwards (B=1), one VAE encode/decode, one vocoder call, one
     STFT; a clip is 600 U-Net forwards + enc + dec + 2 vocoder + STFT."""
@@ -63,10 +88,51 @@ def cpu_baseline(fam, state_dicts, cores):
         ohifi.hifigan_forward(fam["vocoder"], state_dicts["vocoder"], rec[:, 0])
         t_voc = time.time() - t0
     clip_s = 600 * t_unet + t_enc + t_dec + 2 * t_voc + t_stft
-    return dict(value=1.0 / clip_s, unit="edited-clips/sec", cores=cores, kind="port",
-                sample=f"oracle (torch CPU fp32): 3 AudioLDM2 U-Net fwd B=1 ({t_unet:.3f} s each), VAE enc "
-                       f"{t_enc:.2f} s, dec {t_dec:.2f} s, vocoder {t_voc:.2f} s, STFT {t_stft:.3f} s; "
-                       f"clip = 600*unet + enc + dec + 2*voc + stft = {clip_s:.1f} s (extrapolated)")
+    out = dict(value=1.0 / clip_s, unit="edited-clips/sec", cores=cores, kind="port",
+               sample=f"oracle (torch CPU fp32): 3 AudioLDM2 U-Net fwd B=1 ({t_unet:.3f} s each), VAE enc "
+                      f"{t_enc:.2f} s, dec {t_dec:.2f} s, vocoder {t_voc:.2f} s, STFT {t_stft:.3f} s; "
+                      f"clip = 600*unet + enc + dec + 2*voc + stft = {clip_s:.1f} s (extrapolated)")
+    if anchor_steps > 0:
+        out["config1_anchor"] = cpu_config1_anchor(anchor_steps, cores)
+    return out
+
+
+def cpu_config1_anchor(T, cores):
+    """BASELINE configs[0], un-extrapolated: ONE whole clip through the oracle on the host cores -- AudioLDM-S
+    (cvssp/audioldm-s-full architecture, seeded-random weights), --mode ddim, T DDIM steps (ddim_inversion.py:44-84:
+    T inversion + T sampling steps, two U-Net forwards each), VAE encode/decode, vocoder twice, STFT."""
+    from audioeditingcode_amd import configs, weights
+    from oracle import audio as oaudio, hifigan as ohifi, loops as oloops, unet as ounet, vae as ovae
+    from oracle.scheduler import OracleDDIMScheduler
+    from oracle.synth import chirp_waveform
+    fam = configs.get_family("cvssp/audioldm-s-full")
+    sds = {k: weights.random_state_dict(fn(fam[k]), seed=i) for i, (k, fn) in enumerate(
+        (("unet", weights.unet_param_shapes), ("vae", weights.vae_param_shapes), ("vocoder", weights.vocoder_param_shapes)))}
+    g = torch.Generator().manual_seed(3)
+    clap = torch.nn.functional.normalize(torch.randn(3, 1, 512, generator=g), dim=-1)        # src / tgt / uncond
+    sched = OracleDDIMScheduler()
+    sched.set_timesteps(T)
+    n_fwd = [0]
+
+    def unet_fn(x, t, cond):
+        n_fwd[0] += x.shape[0]
+        return ounet.unet_forward(fam["unet"], sds["unet"], x, t, class_labels=cond.expand(x.shape[0], -1))[0]
+    ow = oloops.OracleWrapper(sched, unet_fn)
+    t0 = time.time()
+    with torch.no_grad():
+        wav = torch.from_numpy(oaudio.prepare_waveform(chirp_waveform().numpy(), 163840))[None]
+        mel, _, _ = oaudio.mel_spectrogram(wav)
+        mel4 = mel[:, :, :1024].transpose(1, 2)[:, None]
+        w0 = ovae.vae_encode(fam["vae"], sds["vae"], mel4)
+        wT = oloops.ddim_invert(ow, w0, clap[0], clap[2], 3.0, T, 0)
+        w_e = oloops.ddim_sample(ow, wT, clap[1], clap[2], 12.0, 0)
+        rec = ovae.vae_decode(fam["vae"], sds["vae"], w_e)
+        ohifi.hifigan_forward(fam["vocoder"], sds["vocoder"], rec[:, 0])
+        ohifi.hifigan_forward(fam["vocoder"], sds["vocoder"], mel4[:, 0])
+    dt = time.time() - t0
+    return dict(workload=f"AudioLDM-S (185 M U-Net, seeded-random weights), --mode ddim, T={T}, one 10 s clip, "
+                         f"{n_fwd[0]} U-Net sample-forwards + codec, oracle on {cores} host threads, measured end to end",
+                seconds=dt, clips_per_sec=1.0 / dt, finite=bool(torch.isfinite(w_e).all()))
 
 
 def main():
@@ -86,14 +152,18 @@ def main():
     ap.add_argument("--clips-per-gpu", type=int, default=1,
                     help="independent clips edited together per step and GPU (BASELINE configs[2]: 8; default: the "
                          "headline configs[1] shape, 1)")
+    ap.add_argument("--cpu-anchor-steps", type=int, default=50,
+                    help="DDIM steps of the un-extrapolated config-1 CPU anchor clip (0 = skip; BASELINE configs[0] is 50)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     from audioeditingcode_amd import configs, dist as adist, models, weights
     from audioeditingcode_amd.main_run import edit_clip
     from audioeditingcode_amd.utils import prepare_waveform, synthetic_clip
 
     rank, world, local = adist.init_distributed()
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert world == args.gpus, f"--gpus {args.gpus} but {world} rank(s) are running (n_gpus must equal the ranks that ran)"
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
 
@@ -106,7 +176,8 @@ def main():
         sds = {k: weights.random_state_dict(shapes[k], seed=i) for i, k in enumerate(("unet", "vae", "vocoder"))}
     t0 = time.time()
     if world > 1:
-        sds = {k: adist.broadcast_state_dict(None if sds is None else sds[k], shapes[k], dev) for k in shapes}
+        sds = {k: adist.broadcast_state_dict(None if sds is None else sds[k], shapes[k], dev, on_device=True)
+               for k in shapes}
         torch.cuda.synchronize()
     t_bcast = time.time() - t0
     m = models.load_model(args.model_id, dev, args.T, state_dicts=sds)
@@ -175,6 +246,10 @@ def main():
         torch.cuda.synchronize()
         adist.barrier()
         dt = adist.max_over_ranks(time.perf_counter() - t0, dev)
+        if gathered is not None:            # a fast clip of NaNs is not a result
+            for r, gl in enumerate(gathered):
+                assert torch.isfinite(gl).all(), f"non-finite edited latents from rank {r} ({schedule} schedule)"
+                assert gl.abs().max() > 0, f"all-zero edited latents from rank {r}"
         return dt, gathered
 
     # Headline schedule: timestep-batched forward inversion (G timesteps per U-Net call) + sequential edit.
@@ -194,12 +269,14 @@ def main():
         extra[f"ms_per_step_{key}"] = 1e3 * dto / args.steps
         log(f"{other}: {dto / args.steps:.3f} s/clip")
 
-    # ---- roofline of the dominant kernel (conv_gemm_kernel, fp32 MFMA), HIP events on the engine stream
+    # ---- roofline of the dominant kernel family (conv_gemm / lin_gemm, fp32 MFMA).  Durations are measured live, on the
+    # stream the kernels run on, with HIP events: (1) the captured U-Net forward graph of each batch shape of the clip is
+    # replayed n times between one event pair -> forward_ms (what the loops actually pay per U-Net call, no per-launch
+    # event overhead); (2) one eager pass with an event pair per op gives every op's share; the family's time inside the
+    # graph is forward_ms * (family share).  rocprofv3 --kernel-trace of the same command (profiles/) must agree.
     roof = None
     if rank == 0:
         ed = m.editor(256, 16)
-        # conv_gemm launches of one clip = (T/G) forwards at batch 2G (inversion) + tstart forwards at batch 2
-        # (edit); per-launch durations from HIP events around every op on the engine stream.
         st = torch.cuda.Stream(device=dev)
         tot_fl = tot_ms = 0.0
         n_launch = 0
@@ -220,44 +297,66 @@ def main():
             with torch.cuda.stream(st):
                 eng.tape.profile()
                 ms = [eng.tape.profile() for _ in range(3)]
-            ms = [sum(x) / len(ms) for x in zip(*ms)]
+                ms = [sum(x) / len(ms) for x in zip(*ms)]
+                eng.tape.capture()
+                for _ in range(2):
+                    eng.tape.replay()
+                n_rep = 20 if B <= 8 else 5
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record(st)
+                for _ in range(n_rep):
+                    eng.tape.replay()
+                ev1.record(st)
+                ev1.synchronize()
+                fwd_ms = ev0.elapsed_time(ev1) / n_rep
             conv = [(mt["flops"], t) for mt, t in zip(eng.tape.meta, ms) if mt["code"] == 1]
-            fl, tt = sum(f for f, _ in conv), sum(t for _, t in conv)
+            fl, share = sum(f for f, _ in conv), sum(t for _, t in conv) / sum(ms)
+            tt = fwd_ms * share
             tot_fl += calls[B] * fl
             tot_ms += calls[B] * tt
             n_launch += calls[B] * len(conv)
             per_clip_flops += calls[B] * eng.tape.flops
-            detail[f"unet_batch_{B}"] = dict(forwards_per_clip=calls[B], conv_gemm_launches=len(conv),
-                                             conv_gemm_tflops=fl / (tt * 1e-3) / 1e12, forward_ms=sum(ms),
+            detail[f"unet_batch_{B}"] = dict(forwards_per_clip=calls[B], launches_per_forward=len(eng.tape.ops),
+                                             conv_gemm_launches=len(conv), forward_ms=fwd_ms,
+                                             forward_tflops=eng.tape.flops / (fwd_ms * 1e-3) / 1e12,
+                                             conv_gemm_share_of_forward=share,
+                                             conv_gemm_tflops=fl / (tt * 1e-3) / 1e12,
+                                             eager_event_per_op_sum_ms=sum(ms),
                                              algorithmic_gflop=eng.tape.flops / 1e9)
         achieved = tot_fl / (tot_ms * 1e-3) / 1e12
-        # HBM-side traffic per conv_gemm launch comes from the committed rocprofv3 --pmc passes (counter passes
-        # serialise every dispatch and cannot run inside a timed bench); null when the summary is absent
+        # HBM-side traffic per conv_gemm launch: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs; counter
+        # passes serialise every dispatch and cannot run inside a timed bench) committed under profiles/, used only when
+        # they were taken on THIS source tree (hash of csrc/); null otherwise
         traffic = traffic_note = None
-        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01b_pmc_forward_B40.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_forward.json")
         if os.path.exists(pmc_path):
             try:
                 with open(pmc_path) as f:
                     pmc = json.load(f)
-                traffic = pmc["measured_bytes_per_launch"]
-                traffic_note = (f"bytes per launch, {pmc['counters']}; {pmc['kernel']}; algorithmic "
-                                f"{pmc['algorithmic_bytes_per_launch']:.3g} B per launch; {pmc['source']} "
-                                f"({pmc['binary']})")
+                if pmc.get("csrc_hash") == csrc_hash():
+                    traffic = pmc["measured_bytes_per_launch"]
+                    traffic_note = (f"bytes per conv_gemm-family launch, {pmc['counters']}; algorithmic "
+                                    f"{pmc['algorithmic_bytes_per_launch']:.3g} B per launch; {pmc['source']}")
+                else:
+                    traffic_note = (f"null: profiles/r02_pmc_forward.json was measured on csrc {pmc.get('csrc_hash')}, "
+                                    f"this binary is {csrc_hash()}")
             except (OSError, KeyError, ValueError) as e:
                 log(f"PMC summary unreadable: {e!r}")
         roof = dict(bound="mfma", achieved=achieved, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
                     frac=achieved / PEAK_FP32_MFMA_TFLOPS, traffic=traffic, traffic_note=traffic_note,
-                    kernel="conv_gemm_kernel (+wsk variant)",
+                    kernel="conv_gemm_kernel + lin_gemm_kernel (every conv / Linear of the U-Net forwards of one clip)",
+                    method="HIP events around graph replays of each U-Net batch shape x per-op share from one eager "
+                           "event-per-op pass (see comment in bench.py)",
                     launches_per_clip=n_launch, avg_launch_us=1e3 * tot_ms / n_launch, by_batch=detail,
-                    clip_unet_tflop=per_clip_flops / 1e12,
-                    unet_loop_tflops=per_clip_flops / (dt / args.steps) / 1e12,
-                    unet_loop_frac=per_clip_flops / (dt / args.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS)
+                    csrc_hash=csrc_hash(), clip_unet_tflop=per_clip_flops / 1e12,
+                    path_tflops=per_clip_flops / (dt / args.steps) / 1e12,
+                    path_frac=per_clip_flops / (dt / args.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS)
     base = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # many-core hosts (the MI355X box has 256) make torch's CPU kernels slower, not faster, on these
         # small tensors: use at most 32 threads and report that number as `cores`
         try:
-            base = cpu_baseline(fam, m.state_dicts, min(os.cpu_count() or 1, 32))
+            base = cpu_baseline(fam, m.state_dicts, min(os.cpu_count() or 1, 32), args.cpu_anchor_steps)
         except Exception as e:          # the headline line must survive a failure of the reported-only baseline leg
             log(f"cpu_baseline failed: {e!r}")
 

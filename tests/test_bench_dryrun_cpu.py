@@ -19,9 +19,30 @@ from audioeditingcode_amd import main_run, models               # noqa: E402
 class _Tape:
     flops = 3.4e11
     meta = [dict(code=1, flops=1e9, name="x.conv1"), dict(code=22, flops=0, name="gn")]
+    ops = [None, None]
 
     def profile(self):
         return [0.01, 0.005]
+
+    def capture(self):
+        return None
+
+    def replay(self):
+        return None
+
+
+class _Event:
+    def __init__(self, *a, **k):
+        pass
+
+    def record(self, *a):
+        pass
+
+    def synchronize(self):
+        pass
+
+    def elapsed_time(self, other):
+        return 12.0
 
 
 class _Eng:
@@ -35,7 +56,7 @@ class _Ed:
         self.state = torch.zeros(4, dtype=torch.int32)
 
     def edit_latents(self, w0, *a, **k):
-        return torch.zeros(w0.shape[0], 8, 256, 16)
+        return torch.ones(w0.shape[0], 8, 256, 16)
 
 
 class _STFT:
@@ -81,9 +102,9 @@ def _stream_ctx(s):
 def _run(argv, batches):
     with mock.patch.object(sys, "argv", ["bench.py", *argv]), mock.patch("torch.cuda.set_device"), \
             mock.patch("torch.cuda.synchronize"), mock.patch("torch.cuda.Stream", _Stream), \
-            mock.patch("torch.cuda.stream", _stream_ctx), \
+            mock.patch("torch.cuda.stream", _stream_ctx), mock.patch("torch.cuda.Event", _Event), \
             mock.patch.object(models, "load_model", lambda *a, **k: _Model(batches)), \
-            mock.patch.object(main_run, "edit_clip", lambda m, x0, *a, **k: (None, None, torch.zeros(1, 8, 256, 16))), \
+            mock.patch.object(main_run, "edit_clip", lambda m, x0, *a, **k: (None, None, torch.ones(1, 8, 256, 16))), \
             mock.patch("audioeditingcode_amd.weights.random_state_dict", lambda *a, **k: {}), \
             mock.patch("torch.Tensor.to", lambda self, *a, **k: self), mock.patch("torch.device", lambda *a, **k: "cpu"):
         buf = io.StringIO()

@@ -29,6 +29,9 @@ def _worker(rank, world, port, q):
     # tiny bucket size forces several arenas
     got = adist.broadcast_state_dict(sd, shapes, "cpu", src=0, max_bucket=200_000)
     ck = adist.state_checksum(got)
+    # the no-host-bounce form (views of the received arenas) must carry the same weights
+    got_dev = adist.broadcast_state_dict(sd, shapes, "cpu", src=0, max_bucket=200_000, on_device=True)
+    assert adist.state_checksum(got_dev) == ck and all(got_dev[k].shape == got[k].shape for k in got)
     mine = adist.shard_clips(7, r, w)
     local = torch.full((len(adist.shard_clips(8, r, w)), 8, 4, 4), float(r))
     gathered = adist.gather_to_rank0(local)

@@ -21,4 +21,5 @@ for B in [int(a) for a in sys.argv[1:]] or [40, 2]:
     eng.set_timestep(500)
     eng.forward()
     torch.cuda.synchronize()
-    print("forward done", B, flush=True)
+    conv = [m for m in eng.tape.meta if m["code"] == 1]
+    print("forward done", B, "conv_gemm launches", len(conv), "algorithmic bytes", sum(m["bytes"] for m in conv), flush=True)

@@ -1,0 +1,111 @@
+"""Segment a rocprofv3 --kernel-trace CSV of bench.py into the diffusion steps of the clip and summarise each class.
+
+    rocprofv3 --kernel-trace --stats -d gpurun_out/kt -o kt --output-format csv -- \
+        python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-batched
+    python tools/trace_segments.py gpurun_out/kt/**/kt_kernel_trace.csv > profiles/r02_kernel_trace_headline.md
+
+A segment ends with the fused step kernel(s) of the loop (reverse_step_kernel = one edit step at U-Net batch 2;
+a run of invert_step_kernel = one inversion call at U-Net batch 2G) and starts after the previous one; only segments
+with a full U-Net forward (>= 300 launches) are kept.  Per class: launches, sum of kernel durations, wall span
+(first start -> last end), per-family breakdown, and the conv/lin GEMM family's algorithmic TFLOP/s (2*M*N*K summed over
+the tape of that batch shape, built on the CPU -- no GPU needed to run this tool)."""
+import collections
+import csv
+import re
+import sys
+
+PEAK = 157.3
+
+
+def short(n):
+    n = re.sub(r"^void ", "", n)
+    n = re.sub(r"\(.*", "", n)
+    return n
+
+
+def family(n):
+    if n.startswith("conv_gemm") or n.startswith("lin_gemm") or n.startswith("splitk_reduce"):
+        return "gemm (conv_gemm + lin_gemm)"
+    if n.startswith("attention"):
+        return "attention"
+    if n.startswith("gn_"):
+        return "groupnorm"
+    return "other"
+
+
+def tape_flops(B):
+    import torch
+    from audioeditingcode_amd import configs, weights
+    from audioeditingcode_amd.unet import UNetEngine
+    fam = configs.FAMILIES["audioldm2"]
+    sd = {k: torch.zeros(s) for k, s in weights.unet_param_shapes(fam["unet"]).items()}
+    eng = UNetEngine(fam["unet"], sd, "cpu", B, 256, 16, ctx_len0=8, ctx_len1=16)
+    conv = sum(m["flops"] for m in eng.tape.meta if m["code"] == 1)
+    return conv, eng.tape.flops, len(eng.tape.ops)
+
+
+rows = []
+with open(sys.argv[1]) as f:
+    for r in csv.DictReader(f):
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])))
+rows.sort()
+segs, cur = [], []
+i = 0
+while i < len(rows):
+    s, e, n = rows[i]
+    cur.append(rows[i])
+    if n.startswith("reverse_step_kernel") or n.startswith("invert_step_kernel") or n.startswith("ddim_step"):
+        kind = n.split("_kernel")[0]
+        j = i + 1
+        nstep = 1
+        while j < len(rows) and (rows[j][2].startswith(kind) or rows[j][2].startswith("advance")):
+            cur.append(rows[j])
+            nstep += rows[j][2].startswith(kind)
+            j += 1
+        segs.append((kind, nstep, cur))
+        cur = []
+        i = j
+        continue
+    i += 1
+
+classes = collections.OrderedDict()
+for kind, nstep, ks in segs:
+    if len(ks) < 300:
+        continue
+    classes.setdefault((kind, nstep), []).append(ks)
+
+print(f"# per-step segmentation of `{sys.argv[1]}`\n")
+print(f"{len(rows)} dispatches, {sum(e - s for s, e, _ in rows) / 1e6:.1f} ms of kernel time; "
+      f"{len(segs)} step segments, classes with a full U-Net forward:\n")
+for (kind, nstep), lst in classes.items():
+    B = 2 * nstep
+    conv_fl, all_fl, n_ops = tape_flops(B)
+    n = len(lst)
+    launches = sum(len(k) for k in lst) / n
+    busy = sum(sum(e - s for s, e, _ in k) for k in lst) / n / 1e6
+    span = sum(k[-1][1] - k[0][0] for k in lst) / n / 1e6
+    print(f"## {kind} x{nstep} per segment -> U-Net batch {B}: {n} segments\n")
+    print(f"* launches per segment {launches:.0f} (U-Net tape: {n_ops} ops); sum of kernel durations **{busy:.3f} ms**; "
+          f"wall span first-start -> last-end **{span:.3f} ms**")
+    print(f"* whole segment: {all_fl / 1e9:.1f} GF algorithmic -> {all_fl / span / 1e9:.1f} TFLOP/s = "
+          f"{all_fl / span / 1e9 / PEAK:.3f} of the {PEAK} TF fp32-MFMA peak\n")
+    fam_t = collections.defaultdict(lambda: [0, 0.0])
+    ker_t = collections.defaultdict(lambda: [0, 0.0])
+    for k in lst:
+        for s, e, nm in k:
+            fam_t[family(nm)][0] += 1
+            fam_t[family(nm)][1] += (e - s) / 1e6
+            ker_t[nm][0] += 1
+            ker_t[nm][1] += (e - s) / 1e6
+    print("| family | launches / segment | ms / segment | share | avg us |")
+    print("|---|---|---|---|---|")
+    for fm, (c, t) in sorted(fam_t.items(), key=lambda kv: -kv[1][1]):
+        extra = ""
+        if fm.startswith("gemm"):
+            extra = f" ({conv_fl / (t / n) / 1e9:.1f} TFLOP/s algorithmic = {conv_fl / (t / n) / 1e9 / PEAK:.3f} of peak)"
+        print(f"| {fm}{extra} | {c / n:.0f} | {t / n:.3f} | {100 * t / n / busy:.1f} % | {1e3 * t / c:.2f} |")
+    print("\n| kernel | launches / segment | ms / segment | avg us |")
+    print("|---|---|---|---|")
+    for nm, (c, t) in sorted(ker_t.items(), key=lambda kv: -kv[1][1])[:16]:
+        print(f"| `{nm[:90]}` | {c / n:.1f} | {t / n:.3f} | {1e3 * t / c:.2f} |")
+    print()

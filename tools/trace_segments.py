@@ -10,11 +10,13 @@ with a full U-Net forward (>= 300 launches) are kept.  Per class: launches, sum 
 (first start -> last end), per-family breakdown, and the conv/lin GEMM family's algorithmic TFLOP/s (2*M*N*K summed over
 the tape of that batch shape, built on the CPU -- no GPU needed to run this tool)."""
 import collections
+import os
 import csv
 import re
 import sys
 
 PEAK = 157.3
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def short(n):

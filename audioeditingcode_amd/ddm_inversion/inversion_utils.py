@@ -170,7 +170,11 @@ def inversion_reverse_process(model, xT: torch.Tensor, tstart: torch.Tensor, fix
     if type(etas) in [int, float]:
         etas = [etas] * sched.num_inference_steps
     assert len(etas) == sched.num_inference_steps
-    if hooks or uneven:
+    # the device-resident loop starts at xT[len(zs)] with one eta; anything else (a start index that differs from the
+    # number of noise maps, per-step eta lists) takes the step-by-step path, which follows the reference literally
+    general = int(tstart.max()) != (zs.shape[0] if zs is not None else int(tstart.max())) or \
+        any(float(e) != float(etas[0]) for e in etas)
+    if hooks or uneven or general:
         return _reverse_with_hooks(model, xT, tstart, fix_alpha, etas, prompts, neg_prompts, cfg_scales, zs,
                                    cutoff_points, hspace_add, hspace_replace, skipconns_replace, zero_out_resconns,
                                    extract_h_space, extract_skipconns)

@@ -83,8 +83,33 @@ class EditEngine:
         self.state = torch.zeros(4, dtype=torch.int32, device=self.device)
         self.ts_dev = torch.zeros(scheduler.config.num_train_timesteps, dtype=torch.int64, device=self.device)
         self._plans = {}        # loop plans: persistent buffers + tapes + captured graph, keyed by loop shape
+        self.max_plans = 8      # least-recently-used plans beyond this are dropped (cfg / tstart sweeps would otherwise
+        #                         grow HBM without bound: every plan owns trajectory buffers and an instantiated hipGraph)
 
     # ------------------------------------------------------------------ helpers
+    def _drop_plan(self, key):
+        old = self._plans.pop(key)
+        g = old.get("graph")
+        if g is not None:
+            if self.stream is not None:
+                self.stream.synchronize()
+            L.check(L.lib().aed_graph_destroy(g), "aed_graph_destroy")
+
+    def _get_plan(self, key):
+        """LRU lookup of a loop plan; on a miss makes room for the plan the caller is about to build."""
+        plan = self._plans.pop(key, None)
+        if plan is not None:
+            self._plans[key] = plan                 # re-insert: most recently used last
+            return plan
+        while self._plans and len(self._plans) >= self.max_plans:
+            self._drop_plan(next(iter(self._plans)))
+        return None
+
+    def clear_plans(self):
+        """Drop every cached loop plan (trajectory buffers + instantiated hipGraphs)."""
+        for key in list(self._plans):
+            self._drop_plan(key)
+
     def unet(self, B, L0=0, L1=0):
         key = (B, L0, L1)
         if key not in self._unets:
@@ -220,7 +245,7 @@ class EditEngine:
         L0, L1 = self._ctx_lens(groups)
         scalar = float(cfg_src[0]) if (cfg_tensor is None and P) else 1.0
         key = ("invert", n, P, T, G, L0, L1, bool(numerical_fix), v_pred, cfg_tensor is not None, scalar)
-        plan = self._plans.get(key)
+        plan = self._get_plan(key)
         if plan is None:
             plan = self._plans[key] = dict(
                 xts=torch.empty((T + 1, n, self.H, self.W, self.C), device=self.device, dtype=torch.float32),
@@ -284,9 +309,10 @@ class EditEngine:
     # ------------------------------------------------------------------ A11: reverse / edit
     @torch.inference_mode()
     def edit(self, xts, zs, tstart, cond_tgt, cond_neg, cfg_tar, eta=1.0, cfg_tensor=None, use_graph=True,
-             table_kind="ddpm"):
+             table_kind="ddpm", n_steps=None):
         """inversion_reverse_process (inversion_utils.py:147-323) from x_{tstart}, noise maps zs[:tstart].
-        xts/zs channels-last as returned by invert().  Returns the edited latent [n,H,W,C]."""
+        xts/zs channels-last as returned by invert().  Returns the edited latent [n,H,W,C].
+        n_steps < tstart stops early and returns x_{tstart - n_steps} (trajectory-replay checks)."""
         s = self.sched
         T = s.num_inference_steps
         n = xts.shape[1]
@@ -300,7 +326,7 @@ class EditEngine:
         L0, L1 = self._ctx_lens(groups)
         has_noise = int(eta > 0 and zs is not None)
         key = ("edit", n, P, T, Z, L0, L1, v_pred, cfg_tensor is not None, scalar, has_noise, table_kind)
-        plan = self._plans.get(key)
+        plan = self._get_plan(key)
         if plan is None:
             plan = self._plans[key] = dict(
                 cur=torch.empty((n, self.H, self.W, self.C), device=self.device, dtype=torch.float32),
@@ -336,9 +362,8 @@ class EditEngine:
             pre.run()
             eng.tape.run()
             post.run()
-        self._run_graph(body, Z, use_graph, plan)
+        self._run_graph(body, Z if n_steps is None else max(0, min(int(n_steps), Z)), use_graph, plan)
         return cur.clone()
-        return cur
 
     # ------------------------------------------------------------------ A16: DDIM baseline
     @torch.inference_mode()

@@ -100,3 +100,18 @@ def test_vocoder_full_size_matches_oracle():
     ref = ohifi.hifigan_forward(cfg, sd, mel)
     assert wav.shape == ref.shape == (1, 256 * 160 + 32)
     assert rel(wav.cpu(), ref) < 2e-4, rel(wav.cpu(), ref)
+
+
+def test_vocoder_ten_second_clip_matches_oracle():
+    """The benchmark clip length: 1024 mel frames -> 163 872 samples (main_run.py:184-185 calls the vocoder twice)."""
+    cfg = configs.VOCODER_AUDIOLDM
+    sd = weights.random_state_dict(weights.vocoder_param_shapes(cfg), seed=0)
+    g = torch.Generator().manual_seed(2)
+    mel = torch.randn(1, 1024, 64, generator=g) * 2 - 4
+    eng = VocoderEngine(cfg, sd, DEV, 1, 1024)
+    wav = eng(mel)
+    torch.cuda.synchronize()
+    ref = ohifi.hifigan_forward(cfg, sd, mel)
+    assert wav.shape == ref.shape == (1, 1024 * 160 + 32)
+    assert torch.isfinite(wav).all()
+    assert rel(wav.cpu(), ref) < 2e-4, rel(wav.cpu(), ref)

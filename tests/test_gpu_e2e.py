@@ -148,3 +148,31 @@ def test_graft_entry_smoke():
     """The driver's smoke(): one tiny clip through the wrapper API, checked against the oracle."""
     import __graft_entry__
     __graft_entry__.smoke()
+
+
+def test_two_prompt_segments_equal_and_unequal_tstart_on_the_gpu():
+    """Multi-prompt segment editing (inversion_utils.py:32-49,180-198,308-315) through the wrapper API on the GPU:
+    two SOURCE prompts (per-element cfg tensor in the inversion), two target prompts with cutoff masks -- equal tstart on
+    the device-resident loop (cfg_tensor on both loops), unequal tstart on the host-driven loop with the fix_alpha
+    trajectory blend -- against the oracle loops."""
+    T = 8
+    m = models.load_model("tiny/audioldm2", DEV, T, seed=0)
+    ow = _oracle_wrapper(m, T)
+    enc = lambda p, **k: tuple(None if t is None else t.cpu() for t in m.encode_text(p, **k))     # noqa: E731
+    w0 = torch.randn(1, 8, 32, 16, generator=torch.Generator().manual_seed(4)) * 0.7
+    torch.manual_seed(8)
+    _, zs, wts, _ = inversion_forward_process(m, w0.to(DEV), etas=1.0, prompts=["rain", "wind"], cfg_scales=[3.0, 2.0],
+                                              num_inference_steps=T, numerical_fix=True, cutoff_points=[0.4])
+    xts0 = ow.sample_xts_from_x0(w0, T, generator=torch.Generator().manual_seed(8))
+    _, zs_o, xts_o = oloops.invert(ow, w0, enc(["rain", "wind"]), enc([""]), [3.0, 2.0], T, xts=xts0, n_prompts=2,
+                                   cutoff_points=[0.4], prompt_empty=[False, False])
+    assert rel(zs.cpu()[1:], zs_o[1:]) < 5e-3, rel(zs.cpu()[1:], zs_o[1:])
+    tgt = enc(["jazz", "rock"])
+    for tstart in ([5, 5], [5, 3]):
+        w, _ = inversion_reverse_process(m, xT=wts, tstart=torch.tensor(tstart), fix_alpha=0.2, etas=1.0,
+                                         prompts=["jazz", "rock"], neg_prompts=[""], cfg_scales=[9.0, 6.0],
+                                         zs=zs[:max(tstart)], cutoff_points=[0.5])
+        w_o = oloops.edit(ow, xts_o, torch.tensor(tstart), tgt, enc([""]), [9.0, 6.0], zs_o[:max(tstart)],
+                          eta=1.0, n_prompts=2, cutoff_points=[0.5], fix_alpha=0.2)
+        torch.cuda.synchronize()
+        assert rel(w.cpu(), w_o) < 5e-3, (tstart, rel(w.cpu(), w_o))

@@ -71,3 +71,15 @@ def test_unet_with_sizes_not_multiple_of_8_uses_upsample_size_path():
     got, ref, hs, ref_h, _ = _run_case(fam, B=2, H=36, W=12, L0=8, L1=5, t=301, seed=5)
     assert ref_h.shape[-2:] == (5, 2)
     assert (got - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item())
+
+
+def test_full_audioldm_s_unet_matches_oracle():
+    """BASELINE config 1's model at its real size: AudioLDM-S U-Net (185 M parameters, CLAP FiLM conditioning through the
+    concatenated class embedding, attn2 degenerating to self-attention), latent 8x256x16, cond+uncond batched."""
+    fam = configs.get_family("cvssp/audioldm-s-full")
+    got, ref, hs, ref_h, eng = _run_case(fam, B=2, H=256, W=16, L0=0, L1=0, t=981, use_ehs=False)
+    rel = ((got - ref).norm() / ref.norm()).item()
+    assert rel < 1e-4, rel
+    assert ((hs - ref_h).norm() / ref_h.norm()).item() < 1e-4
+    n_params = sum(v.numel() for v in weights.random_state_dict(weights.unet_param_shapes(fam["unet"]), seed=0).values())
+    assert abs(n_params / 1e6 - 185.0) < 1.0, n_params                      # in-tree twin: 185.0 M (SURVEY 8c)

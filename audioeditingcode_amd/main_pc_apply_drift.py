@@ -126,6 +126,9 @@ def build_parser():
     p.add_argument("--combine_evs", action="store_true")
     p.add_argument("--evals_pt", type=str, default=None)
     p.add_argument("--rand_v", action="store_true")
+    p.add_argument("--allow_synthetic", action="store_true",
+                   help="run with seeded-random weights / stand-in text embeddings when no checkpoint is on disk "
+                        "(benchmarking only: the output is noise)")
     return p
 
 
@@ -145,7 +148,9 @@ def main(argv: Optional[List[str]] = None):
     ex = load_dict["args"]
     if args.evals_pt is not None:
         args.evals_pt = torch.load(args.evals_pt, weights_only=False)
-    ldm_stable = load_model(ex.model_id, device, ex.num_diffusion_steps, ex.double_precision)
+    ldm_stable = load_model(ex.model_id, device, ex.num_diffusion_steps, ex.double_precision,
+                            allow_synthetic=getattr(args, "allow_synthetic", False) or None)
+    print(f"weights: {ldm_stable.weights_source}; text conditioning: {ldm_stable.conditioning_source}")
     t0 = time.time()
     xt = apply_pcs(ldm_stable, load_dict, args, device)
     with torch.inference_mode():

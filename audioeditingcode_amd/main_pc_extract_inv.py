@@ -134,6 +134,9 @@ def build_parser():
     p.add_argument("-p", "--patch", nargs=2, default=None, type=int)
     p.add_argument("-t", "--iters", type=int, default=50)
     p.add_argument("-d", "--dry", action="store_true")
+    p.add_argument("--allow_synthetic", action="store_true",
+                   help="run with seeded-random weights / stand-in text embeddings when no checkpoint is on disk "
+                        "(benchmarking only: the output is noise)")
     return p
 
 
@@ -154,7 +157,9 @@ def main(argv: Optional[List[str]] = None):
     set_reproducability(args.seed, extreme=False)
     device = f"cuda:{args.device_num}"
     torch.cuda.set_device(args.device_num)
-    ldm_stable = load_model(args.model_id, device, args.num_diffusion_steps, args.double_precision)
+    ldm_stable = load_model(args.model_id, device, args.num_diffusion_steps, args.double_precision,
+                            allow_synthetic=getattr(args, "allow_synthetic", False) or None)
+    print(f"weights: {ldm_stable.weights_source}; text conditioning: {ldm_stable.conditioning_source}")
     src = args.init_aud if args.init_aud else (synthetic_clip(), 16000)
     x0 = load_audio(src, ldm_stable.get_fn_STFT(), device=device)
     with torch.inference_mode():

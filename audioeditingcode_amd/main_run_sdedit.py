@@ -21,6 +21,9 @@ def build_parser():
     p.add_argument("--target_neg_prompt", type=str, nargs="+", default=[""])
     p.add_argument("--results_path", default="sdedit")
     p.add_argument("--tstart", type=int, default=100)
+    p.add_argument("--allow_synthetic", action="store_true",
+                   help="run with seeded-random weights / stand-in text embeddings when no checkpoint is on disk "
+                        "(benchmarking only: the output is noise)")
     return p
 
 
@@ -35,7 +38,9 @@ def main(argv: Optional[List[str]] = None):
     name = f"s{args.seed}_skip{skip}_cfg{args.cfg_tar}"
     device = f"cuda:{args.device_num}"
     torch.cuda.set_device(args.device_num)
-    ldm_stable = load_model(args.model_id, device, args.num_diffusion_steps)
+    ldm_stable = load_model(args.model_id, device, args.num_diffusion_steps,
+                            allow_synthetic=getattr(args, "allow_synthetic", False) or None)
+    print(f"weights: {ldm_stable.weights_source}; text conditioning: {ldm_stable.conditioning_source}")
     src = args.init_aud if args.init_aud else (synthetic_clip(), 16000)
     x0 = load_audio(src, ldm_stable.get_fn_STFT(), device=device)
     t0 = time.time()

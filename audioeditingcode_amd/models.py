@@ -8,6 +8,8 @@ model underneath and no CPU fallback.
 Tensors cross this boundary exactly as in the reference: NCHW fp32 torch tensors on `device`.
 """
 import ctypes
+import os
+import sys
 import zlib
 from types import SimpleNamespace
 from typing import Dict, List, Optional, Tuple, Union
@@ -50,9 +52,17 @@ class PipelineWrapper(torch.nn.Module):
     family_name = None
 
     def __init__(self, model_id: str, device: torch.device, double_precision: bool = False,
-                 token: Optional[str] = None, seed: int = 0, state_dicts: Optional[Dict] = None, *args,
-                 **kwargs) -> None:
+                 token: Optional[str] = None, seed: int = 0, state_dicts: Optional[Dict] = None,
+                 allow_synthetic: Optional[bool] = None, *args, **kwargs) -> None:
         super().__init__()
+        # Seeded-random weights and stand-in text embeddings exist for benchmarks and parity tests (no checkpoint can be
+        # downloaded here).  They must never be used silently: a run that edits audio with them exits 0 and writes
+        # noise.  They need an explicit opt-in: allow_synthetic=True, AED_ALLOW_SYNTHETIC=1, or a "tiny/" test model.
+        if allow_synthetic is None:
+            allow_synthetic = os.environ.get("AED_ALLOW_SYNTHETIC") == "1" or model_id.startswith("tiny/")
+        self.synthetic_ok = bool(allow_synthetic)
+        self.text_encoders = None
+        self.conditioning_source = "unset"
         if double_precision:
             raise NotImplementedError("double_precision=True: the native path is fp32 (the reference's default)")
         self.model_id = model_id
@@ -75,7 +85,22 @@ class PipelineWrapper(torch.nn.Module):
             if "scheduler" in comp:
                 self.family["scheduler"] = comp["scheduler"]
             self.weights_source = ckpt
+            try:
+                from .text_encoders import TextEncoders
+                self.text_encoders = TextEncoders.from_pretrained(ckpt, self.kind, device=self.device)
+                self.conditioning_source = f"transformers text encoders from {ckpt}"
+            except (FileNotFoundError, OSError, ImportError) as e:
+                if not self.synthetic_ok:
+                    raise L.AedError(f"{ckpt}: U-Net/VAE/vocoder weights were found but the text-conditioning "
+                                     f"components could not be loaded ({e}); prompts would have no effect. Pass "
+                                     f"allow_synthetic=True (or AED_ALLOW_SYNTHETIC=1) to run with stand-in "
+                                     f"embeddings anyway.") from e
         else:
+            if not self.synthetic_ok:
+                raise L.AedError(f"no checkpoint for '{model_id}' on disk (weights.find_checkpoint) and none can be "
+                                 f"downloaded here. Seeded-random weights are for benchmarks and parity tests only: "
+                                 f"pass allow_synthetic=True to load_model, set AED_ALLOW_SYNTHETIC=1, or use "
+                                 f"--allow_synthetic on the CLIs.")
             unet_sd = weights.random_state_dict(weights.unet_param_shapes(self.family["unet"]), seed=seed)
             vae_sd = weights.random_state_dict(weights.vae_param_shapes(self.family["vae"]), seed=seed + 1)
             voc_sd = weights.random_state_dict(weights.vocoder_param_shapes(self.family["vocoder"]), seed=seed + 2)
@@ -267,7 +292,7 @@ class PipelineWrapper(torch.nn.Module):
                         (type(zero_out_resconns) is list and i in zero_out_resconns):
                     for buf in grp:
                         buf.zero_()
-            extracted[i] = [b.permute(0, 3, 1, 2).contiguous() for b in grp] if hooks or True else None
+            extracted[i] = [b.permute(0, 3, 1, 2).contiguous() for b in grp]
         eng.forward(second_half_only=True)
         out = eng.eps.permute(0, 3, 1, 2).contiguous()
         if not return_dict:
@@ -325,6 +350,18 @@ class _SyntheticText:
         return torch.stack([torch.randn(dim, generator=_prompt_generator(p, salt)) for p in prompts])
 
 
+def _require_synthetic_text(w):
+    """Stand-in text embeddings need the explicit opt-in (see PipelineWrapper.__init__)."""
+    if not w.synthetic_ok:
+        raise L.AedError("encode_text: no text encoders are loaded (wrapper.text_encoders is None), so prompts would be "
+                         "replaced by prompt-seeded random tensors. Load a checkpoint with its tokenizer/text_encoder "
+                         "directories, set wrapper.text_encoders = TextEncoders(...), or opt in with allow_synthetic.")
+    if w.conditioning_source != "synthetic":
+        w.conditioning_source = "synthetic"
+        print(f"[audioeditingcode_amd] WARNING: {w.model_id}: text conditioning is SYNTHETIC (prompt-seeded random "
+              f"tensors of the real shapes); weights: {w.weights_source}", file=sys.stderr, flush=True)
+
+
 class AudioLDMWrapper(PipelineWrapper):
     family_name = "audioldm"
 
@@ -332,7 +369,8 @@ class AudioLDMWrapper(PipelineWrapper):
         """(None, L2-normalised CLAP text embedding [P,512], None) -- models.py:511-537."""
         enc = getattr(self, "text_encoders", None)
         if enc is not None:
-            return enc.encode_audioldm(prompts, self.device)
+            return enc.encode_audioldm(prompts, self.device, **kwargs)
+        _require_synthetic_text(self)
         v = torch.nn.functional.normalize(_SyntheticText.vec(prompts, self.family["ctx"]["clap_dim"], "clap"), dim=-1)
         return None, v.to(self.device), None
 
@@ -344,7 +382,8 @@ class AudioLDM2Wrapper(PipelineWrapper):
         """(GPT-2 generated states [P,8,768], T5 states [P,L,1024], T5 mask [P,L]) -- models.py:599-677."""
         enc = getattr(self, "text_encoders", None)
         if enc is not None:
-            return enc.encode_audioldm2(prompts, self.device)
+            return enc.encode_audioldm2(prompts, self.device, **kwargs)
+        _require_synthetic_text(self)
         c = self.family["ctx"]
         gen = torch.stack([torch.randn(c["gpt2_len"], c["gpt2_dim"], generator=_prompt_generator(p, "gpt2"))
                            for p in prompts])
@@ -366,18 +405,21 @@ class TangoWrapper(PipelineWrapper):
         """(T5 states [P,L,1024], None, mask [P,L]) -- models.py:462-467."""
         enc = getattr(self, "text_encoders", None)
         if enc is not None:
-            return enc.encode_tango(prompts, self.device)
+            return enc.encode_tango(prompts, self.device, **kwargs)
+        _require_synthetic_text(self)
         t5, mask = _SyntheticText.t5(prompts, self.family["ctx"]["t5_dim"])
         return t5.to(self.device), None, mask.to(self.device)
 
 
 def load_model(model_id: str, device: torch.device, num_diffusion_steps: int, double_precision: bool = False,
-               token: Optional[str] = None, seed: int = 0, state_dicts: Optional[Dict] = None) -> PipelineWrapper:
-    """Substring dispatch + scheduler setup of models.py:1357-1374."""
+               token: Optional[str] = None, seed: int = 0, state_dicts: Optional[Dict] = None,
+               allow_synthetic: Optional[bool] = None) -> PipelineWrapper:
+    """Substring dispatch + scheduler setup of models.py:1357-1374.  `allow_synthetic`: opt-in to seeded-random weights
+    and stand-in text embeddings when no checkpoint is on disk (benchmarks / tests; see PipelineWrapper.__init__)."""
     fam = configs.family_of(model_id)
     cls = {"tango": TangoWrapper, "audioldm2": AudioLDM2Wrapper, "audioldm": AudioLDMWrapper}[fam]
     ldm_stable = cls(model_id=model_id, device=device, double_precision=double_precision, token=token, seed=seed,
-                     state_dicts=state_dicts)
+                     state_dicts=state_dicts, allow_synthetic=allow_synthetic)
     ldm_stable.load_scheduler()
     ldm_stable.model.scheduler.set_timesteps(num_diffusion_steps, device=None)
     torch.cuda.empty_cache()

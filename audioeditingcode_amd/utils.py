@@ -29,7 +29,9 @@ def pad_wav(waveform, segment_length):
     if segment_length is None or n == segment_length:
         return waveform
     if n > segment_length:
-        return waveform[..., :segment_length]
+        # the reference slices the FIRST axis of the [1, N] array here (tools.py:39-40): a no-op, the waveform is not
+        # cropped and the surplus frames are cut by _pad_spec; kept as is (pinned by tests/golden/waveform_prep.npz)
+        return waveform[:segment_length]
     tmp = np.zeros((1, segment_length))          # float64 like the reference
     tmp[:, :n] = waveform
     return tmp

@@ -259,7 +259,7 @@ def _load_component(root, sub, fname_candidates):
         if os.path.exists(p):
             if p.endswith(".safetensors"):
                 return load_file(p)
-            return torch.load(p, map_location="cpu")
+            return torch.load(p, map_location="cpu", weights_only=True)
     raise FileNotFoundError(f"no weights for {sub} under {root}")
 
 

@@ -30,9 +30,11 @@ def prepare_waveform(w, segment_length):
     """read_wav_file after resampling: normalise, pad/crop to segment_length, normalise again."""
     w = normalize_wav(np.asarray(w))
     n = w.shape[-1]
-    if n > segment_length:
-        w = w[:segment_length]
-    elif n < segment_length:
+    # n > segment_length: the reference slices `waveform[:segment_length]` on the [1, N] array (tools.py:39-40 after
+    # :58), i.e. the FIRST axis -- the waveform is NOT cropped; the surplus frames are cut later by _pad_spec.
+    # (Pinned by tests/golden/waveform_prep.npz "long"; unreachable from load_audio for clips > 0.42 s, where
+    # int(duration*102.4)*160 >= duration*16000.)
+    if n < segment_length:
         tmp = np.zeros(segment_length)          # float64, as the reference's pad_wav
         tmp[:n] = w
         w = tmp

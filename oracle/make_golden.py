@@ -414,6 +414,26 @@ def gen_audio():
                         basis_rows=fn.stft_fn.forward_basis[[0, 1, 7, 512, 513, 514, 900, 1025], 0, :].numpy(),
                         basis_row_ids=np.array([0, 1, 7, 512, 513, 514, 900, 1025]))
     print("audio", tuple(mel.shape), float(mel.mean()))
+    # ---- A1: the reference's own waveform preparation (audioldm/audio/tools.py:18-85) run here.  torchaudio is absent;
+    # its two calls (load, functional.resample) are replaced by an in-memory 16 kHz waveform -- everything after them
+    # (normalize_wav, pad_wav incl. its float64 zero-pad, the second normalisation, get_mel_from_wav, _pad_spec) is the
+    # reference's code.
+    ta = sys.modules["torchaudio"]
+    tools = _load_by_path("audioldm.audio.tools", os.path.join(REF, "audioldm/audio/tools.py"))
+    rec = {}
+    for name, n_in, frames in (("short", 160 * 40 + 37, 64), ("long", 160 * 80 + 11, 64), ("exact", 160 * 64, 64)):
+        raw = (chirp_waveform(n=n_in, seed=77).numpy() * 1.7 + 0.2).astype(np.float32)      # offset + gain: exercises both norms
+        ta.load = lambda fn, _w=raw: (torch.from_numpy(_w)[None], 16000)
+        ta.functional = types.SimpleNamespace(resample=lambda w, orig_freq, new_freq: w)
+        wave = tools.read_wav_file("in-memory", frames * 160)
+        fbank, logmag, wav_t = tools.wav_to_fbank("in-memory", target_length=frames, fn_STFT=fn)
+        rec.update({f"{name}.raw": raw, f"{name}.wave": np.asarray(wave), f"{name}.fbank": fbank.numpy(),
+                    f"{name}.wav_t": wav_t.numpy(), f"{name}.frames": frames})
+    rec["pad_spec.in"] = torch.arange(7 * 65, dtype=torch.float32).reshape(7, 65).numpy()
+    rec["pad_spec.out10"] = tools._pad_spec(torch.from_numpy(rec["pad_spec.in"]), 10).numpy()
+    rec["pad_spec.out5"] = tools._pad_spec(torch.from_numpy(rec["pad_spec.in"]), 5).numpy()
+    np.savez_compressed(os.path.join(OUT, "waveform_prep.npz"), **rec)
+    print("waveform prep", {k: v.shape for k, v in rec.items() if hasattr(v, "shape")})
 
 
 # --------------------------------------------------------------------------- hifigan

@@ -154,9 +154,32 @@ def test_waveform_preparation_rules():
     assert abs(np.abs(out).max() - 0.5) < 1e-6            # second normalisation (tools.py:61-62)
     assert np.all(out[1000:] == 0)
     out2 = oaudio.prepare_waveform(w, 640)
-    assert out2.shape == (640,)
+    assert out2.shape == (1000,)                          # NOT cropped: the reference's first-axis slice (tools.py:39-40)
     fb = oaudio.pad_spec(torch.ones(7, 65), 10)
     assert fb.shape == (10, 64) and fb[7:].abs().sum() == 0   # even-bin trim + zero pad (tools.py:18-31)
+
+
+def test_waveform_preparation_matches_the_reference_tools():
+    """A1 pinned: audioldm/audio/tools.py (normalize_wav, pad_wav with its float64 zero-pad and its first-axis slice
+    quirk, the second normalisation, get_mel_from_wav, _pad_spec) run by oracle/make_golden.py on in-memory waveforms
+    -> the oracle's and the product's host-side restatements reproduce waveform and fbank."""
+    from audioeditingcode_amd import utils as putils
+    g = np.load(os.path.join(G, "waveform_prep.npz"))
+    for name in ("short", "long", "exact"):
+        raw, frames = g[f"{name}.raw"], int(g[f"{name}.frames"])
+        ref_wave = g[f"{name}.wave"][0].astype(np.float32)
+        for prep in (oaudio.prepare_waveform, putils.prepare_waveform):
+            got = prep(raw, frames * 160)
+            assert got.shape == ref_wave.shape, (name, got.shape, ref_wave.shape)
+            np.testing.assert_allclose(got, ref_wave, atol=1e-7, rtol=0)
+        fb, w = oaudio.wav_to_fbank(raw, frames)
+        assert tuple(fb.shape) == g[f"{name}.fbank"].shape
+        np.testing.assert_allclose(fb.numpy(), g[f"{name}.fbank"], atol=2e-4, rtol=0)
+        np.testing.assert_allclose(w.numpy(), g[f"{name}.wav_t"], atol=1e-7, rtol=0)
+    x = torch.from_numpy(g["pad_spec.in"])
+    for fn in (oaudio.pad_spec, putils.pad_spec):
+        assert torch.equal(fn(x, 10), torch.from_numpy(g["pad_spec.out10"]))
+        assert torch.equal(fn(x, 5), torch.from_numpy(g["pad_spec.out5"]))
 
 
 def test_hifigan_matches_transformers_class():

@@ -1,0 +1,126 @@
+"""A15: the transformers-backed text-conditioning adapter (audioeditingcode_amd/text_encoders.py) with random-init
+CLAP / T5 / GPT-2 modules of reduced width: shapes, mask semantics (padding=True for T5 -> the empty prompt has length 1,
+CLAP padded to max_length), the `negative=True` keyword, the restated projection model and the continuous GPT-2
+autoregression, and the wrapper's refusal to fall back to stand-in embeddings silently."""
+import pytest
+import torch
+
+from audioeditingcode_amd.text_encoders import ProjectionModel, TextEncoders
+
+
+class WordTokenizer:
+    """Whitespace tokenizer with the call signature the reference uses (models.py:512-529, :606-625)."""
+
+    def __init__(self, model_max_length, pad_to_max_length, vocab=97):
+        self.model_max_length, self.pad_to_max_length, self.vocab = model_max_length, pad_to_max_length, vocab
+
+    def _ids(self, p):
+        return [2 + (sum(map(ord, w)) % (self.vocab - 3)) for w in p.split()] + [1]            # ... + EOS
+
+    def __call__(self, prompts, padding=True, max_length=None, truncation=False, return_tensors="pt"):
+        seqs = [self._ids(p) for p in prompts]
+        if truncation and max_length:
+            seqs = [s[:max_length] for s in seqs]
+        L = max_length if padding == "max_length" else max(len(s) for s in seqs)
+        ids = torch.zeros(len(seqs), L, dtype=torch.long)
+        mask = torch.zeros(len(seqs), L, dtype=torch.long)
+        for i, s in enumerate(seqs):
+            ids[i, :len(s)] = torch.tensor(s)
+            mask[i, :len(s)] = 1
+        return type("Enc", (), dict(input_ids=ids, attention_mask=mask))()
+
+    def batch_decode(self, ids):
+        return [" ".join(map(str, r.tolist())) for r in ids]
+
+
+def _t5(d=32):
+    from transformers import T5Config, T5EncoderModel
+    torch.manual_seed(0)
+    return T5EncoderModel(T5Config(vocab_size=97, d_model=d, d_kv=8, d_ff=64, num_layers=2, num_heads=4))
+
+
+def _gpt2(d=24):
+    from transformers import GPT2Config, GPT2Model
+    torch.manual_seed(1)
+    return GPT2Model(GPT2Config(vocab_size=50, n_positions=64, n_embd=d, n_layer=2, n_head=4))
+
+
+class FakeClap(torch.nn.Module):
+    """`config.model_type == "clap"` + get_text_features: the two things models.py:629-637 uses of ClapModel."""
+
+    def __init__(self, dim=16):
+        super().__init__()
+        self.config = type("C", (), dict(model_type="clap"))()
+        self.emb = torch.nn.Embedding(97, dim)
+
+    def get_text_features(self, input_ids, attention_mask=None):
+        m = attention_mask[..., None].float()
+        return (self.emb(input_ids) * m).sum(1) / m.sum(1).clamp_min(1)
+
+
+def test_audioldm2_triple_shapes_masks_and_generation():
+    torch.manual_seed(2)
+    proj = ProjectionModel(16, 32, 24)
+    enc = TextEncoders("audioldm2", WordTokenizer(12, True), FakeClap(16), WordTokenizer(20, False), _t5(32), _gpt2(24),
+                       proj, max_new_tokens=8)
+    prompts = ["a dog barking loudly in the rain", "jazz"]
+    gen, t5, mask = enc.encode_audioldm2(prompts, "cpu")
+    assert gen.shape == (2, 8, 24) and t5.shape == (2, 8, 32) and mask.shape == (2, 8)       # padding=True -> longest
+    assert mask[0].sum() == 8 and mask[1].sum() == 2                                         # "jazz" + EOS
+    # the unconditional / negative prompt: T5 length 1 (EOS only), keyword accepted
+    g0, t0, m0 = enc.encode_audioldm2([""], "cpu", negative=True)
+    assert g0.shape == (1, 8, 24) and t0.shape == (1, 1, 32) and m0.tolist() == [[1]]
+    # restated generate_language_model == explicit loop over GPT2Model with growing inputs
+    h, hm = proj(torch.randn(1, 1, 16), torch.randn(1, 3, 32), torch.ones(1, 1, dtype=torch.long),
+                 torch.tensor([[1, 1, 0]]))
+    assert h.shape == (1, (1 + 2) + (3 + 2), 24) and hm.tolist() == [[1, 1, 1, 1, 1, 1, 0, 1]]
+    out = enc.generate_language_model(h, hm, max_new_tokens=3)
+    x, m = h, hm
+    for _ in range(3):
+        y = enc.language_model(inputs_embeds=x, attention_mask=m).last_hidden_state[:, -1:]
+        x, m = torch.cat([x, y], 1), torch.cat([m, m.new_ones(1, 1)], 1)
+    assert torch.allclose(out, x[:, -3:], atol=1e-6)
+    # the T5 states of a padded row equal the un-padded run on its valid positions (key mask); the GENERATED states do
+    # depend on the batch padding (GPT-2 absolute positions shift behind the padded block) -- as in the reference
+    _, ta, _ = enc.encode_audioldm2(["jazz"], "cpu")
+    assert torch.allclose(ta[0], t5[1, :2], atol=1e-5)
+
+
+def test_audioldm_and_tango_triples():
+    from transformers import ClapTextConfig, ClapTextModelWithProjection
+    torch.manual_seed(3)
+    clap = ClapTextModelWithProjection(ClapTextConfig(vocab_size=97, hidden_size=32, intermediate_size=64,
+                                                      num_hidden_layers=1, num_attention_heads=4, projection_dim=16,
+                                                      max_position_embeddings=40))
+    enc = TextEncoders("audioldm", WordTokenizer(12, True), clap)
+    hs, cl, mk = enc.encode_audioldm(["rain", "a cat"], "cpu")
+    assert hs is None and mk is None and cl.shape == (2, 16)
+    assert torch.allclose(cl.norm(dim=-1), torch.ones(2), atol=1e-5)                          # F.normalize, models.py:533
+    enc = TextEncoders("tango", WordTokenizer(20, False), _t5(32))
+    hs, cl, mk = enc.encode_tango(["rain on a roof", ""], "cpu")
+    assert cl is None and hs.shape == (2, 5, 32) and mk.dtype == torch.bool and mk.sum(1).tolist() == [5, 1]
+
+
+def test_wrapper_refuses_silent_synthetic_conditioning(monkeypatch):
+    from audioeditingcode_amd import _lib as L, models
+    monkeypatch.delenv("AED_ALLOW_SYNTHETIC", raising=False)
+
+    class W(models.AudioLDM2Wrapper):
+        def __init__(self, ok):                               # host logic only: no engines, no device
+            torch.nn.Module.__init__(self)
+            self.synthetic_ok, self.text_encoders, self.conditioning_source = ok, None, "unset"
+            self.model_id, self.weights_source, self.device = "cvssp/audioldm2", "x", torch.device("cpu")
+            from audioeditingcode_amd import configs
+            self.family = configs.get_family("cvssp/audioldm2")
+    with pytest.raises(L.AedError, match="no text encoders"):
+        W(False).encode_text(["rain"])
+    w = W(True)
+    gen, t5, mask = w.encode_text(["rain on a roof"], negative=True)
+    assert gen.shape == (1, 8, 768) and t5.shape == (1, 5, 1024) and w.conditioning_source == "synthetic"
+    w.text_encoders = TextEncoders("audioldm2", WordTokenizer(12, True), FakeClap(16), WordTokenizer(20, False), _t5(32),
+                                   _gpt2(24), ProjectionModel(16, 32, 24))
+    gen, t5, mask = w.encode_text(["rain on a roof"], negative=True)
+    assert gen.shape == (1, 8, 24) and t5.shape == (1, 5, 32)
+    # and load_model refuses seeded-random weights without the opt-in (before any device work)
+    with pytest.raises(L.AedError):
+        models.load_model("cvssp/audioldm2", "cpu", 10)

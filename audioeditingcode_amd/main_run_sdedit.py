@@ -42,7 +42,8 @@ def main(argv: Optional[List[str]] = None):
                             allow_synthetic=getattr(args, "allow_synthetic", False) or None)
     print(f"weights: {ldm_stable.weights_source}; text conditioning: {ldm_stable.conditioning_source}")
     src = args.init_aud if args.init_aud else (synthetic_clip(), 16000)
-    x0 = load_audio(src, ldm_stable.get_fn_STFT(), device=device)
+    # (stale call site in the reference, main_run_sdedit.py:69 -- SURVEY quirk 10; the evident intent is implemented)
+    x0, _, _ = load_audio(src, ldm_stable.get_fn_STFT(), device=device, stft=True, model_sr=ldm_stable.get_sr())
     t0 = time.time()
     with torch.inference_mode():
         w0 = ldm_stable.vae_encode(x0)

@@ -16,3 +16,40 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def install_cpu_stack(monkeypatch):
+    """Run the product's HOST logic on CPU: tapes are executed by oracle/tape_interp.py, the three direct C-ABI calls by
+    its FakeLib, the graph loop by a plain Python loop (test instrumentation only; the product has no CPU path)."""
+    import torch
+    from audioeditingcode_amd import _lib as L
+    from audioeditingcode_amd.editing import EditEngine
+    from audioeditingcode_amd.tape import Tape
+    from oracle import tape_interp
+    fake = tape_interp.FakeLib()
+    monkeypatch.setattr(Tape, "run", tape_interp.run_tape)
+    monkeypatch.setattr(L, "lib", lambda: fake)
+    monkeypatch.setattr(L, "current_stream_ptr", lambda: None)
+
+    def run_graph(self, body, steps, use_graph=True, plan=None):
+        for _ in range(steps):
+            body()
+
+    def sample_xts(self, x0, noise=None, generator=None):
+        s = self.sched
+        T = s.num_inference_steps
+        x0 = x0.float()
+        if noise is None:
+            noise = torch.stack([torch.randn(x0.shape, generator=generator, dtype=torch.float32) for _ in range(T)])
+        ts, abar = s.timesteps.cpu(), s.alphas_cumprod
+        t_rows = torch.stack([ts[T - (r + 1)] for r in range(T)])
+        shape = (T, *[1] * x0.dim())
+        return torch.cat([x0[None], x0[None] * (abar[t_rows] ** 0.5).reshape(shape)
+                          + noise * ((1 - abar) ** 0.5)[t_rows].reshape(shape)])
+    monkeypatch.setattr(EditEngine, "_run_graph", run_graph)
+    monkeypatch.setattr(EditEngine, "sample_xts", sample_xts)
+
+
+@pytest.fixture
+def cpu_stack(monkeypatch):
+    install_cpu_stack(monkeypatch)

@@ -236,3 +236,23 @@ def test_full_size_headline_length_batched_vs_sequential():
     assert rel(xts_b[1:], xts_s[1:]) < 1e-5, rel(xts_b[1:], xts_s[1:])
     assert rel(zs_b[1:], zs_s[1:]) < 5e-3, rel(zs_b[1:], zs_s[1:])
     assert rel(w_b, w_s) < 5e-3, rel(w_b, w_s)
+
+
+def test_eight_clips_per_engine_equal_eight_single_runs():
+    """BASELINE config 3's per-rank shape: 8 clips edited as ONE U-Net batch per step (EditEngine.edit_latents, batch
+    [uncond x 8 | prompt x 8]) against 8 single-clip runs with the same per-clip noise -- same kernels at another batch
+    size, so the tolerance is the loop tolerance (z amplifies eps differences by 1/sigma_t)."""
+    T, tstart, n = 10, 6, 8
+    fam, eng, ow, conds, to_c, x0 = _setup("audioldm2", T)
+    g = torch.Generator().manual_seed(21)
+    x0s = torch.randn(n, 8, H, W, generator=g) * 0.8
+    noise = torch.randn(T, n, 8, H, W, generator=g)
+    w8 = eng.edit_latents(x0s, to_c(conds["src"]), to_c(conds["unc"]), to_c(conds["tgt"]), to_c(conds["unc"]), [3.0],
+                          [12.0], tstart, schedule="batched", group=5, noise=noise)
+    torch.cuda.synchronize()
+    assert w8.shape == (n, 8, H, W) and torch.isfinite(w8).all()
+    for i in (0, 3, 7):
+        w1 = eng.edit_latents(x0s[i:i + 1], to_c(conds["src"]), to_c(conds["unc"]), to_c(conds["tgt"]),
+                              to_c(conds["unc"]), [3.0], [12.0], tstart, schedule="sequential", noise=noise[:, i:i + 1])
+        torch.cuda.synchronize()
+        assert rel(w8[i:i + 1].cpu(), w1.cpu()) < 3e-3, (i, rel(w8[i:i + 1].cpu(), w1.cpu()))

@@ -1,4 +1,6 @@
 """GPU parity of the unsupervised-PC utilities (SURVEY 8f row 1 / BASELINE config 4 case) vs the CPU oracle."""
+import os
+
 import pytest
 import torch
 
@@ -93,3 +95,69 @@ def test_sdedit_matches_oracle_sampler():
                                         eta=1.0)
     err = ((got.cpu() - xt).norm() / xt.norm()).item()
     assert err < 1e-3, err
+
+
+def test_pc_clis_extract_pt_apply_on_the_gpu(tmp_path, monkeypatch):
+    """(f2) main_pc_extract_inv -> .pt -> main_pc_apply_drift on the GPU (BASELINE config 4's call pattern at test
+    size): (1) the two CLI mains end to end -- checkpoint keys / recorded args / window, wav outputs; (2) the same
+    extract_pcs / apply_pcs on the HIP wrapper against the CPU tape-interpreter stack (an independent statement of every
+    opcode, oracle/tape_interp.py) with identical seeds: eigenvalues, eigenvector cosines, inverted trajectory and
+    drifted latents."""
+    import glob
+    from argparse import Namespace
+    from conftest import install_cpu_stack
+    from audioeditingcode_amd import main_pc_apply_drift as papply, main_pc_extract_inv as pext
+    from audioeditingcode_amd.utils import synthetic_clip, write_wav
+    T = 6
+    wav = str(tmp_path / "clip.wav")
+    write_wav(wav, synthetic_clip(seconds=1.25, seed=4), 16000)
+    # ---- (1) the CLIs
+    pext.main(["--model_id", "tiny/audioldm2", "--init_aud", wav, "--num_diffusion_steps", str(T), "--source_prompt",
+               "rain", "--drift_start", "5", "--drift_end", "3", "--n_evs", "2", "--iters", "3", "-c", "1e-2",
+               "--results_path", str(tmp_path / "ext"), "-s", "1"])
+    pts = glob.glob(str(tmp_path / "ext" / "**" / "*.pt"), recursive=True)
+    assert len(pts) == 1
+    ck = torch.load(pts[0], map_location="cpu", weights_only=False)
+    assert set(ck) == {"eigdata", "args", "corrs", "in_corrs", "latents", "in_norms", "xts"}       # main_pc_extract_inv.py:234-256
+    assert ck["args"].model_id == "tiny/audioldm2" and ck["args"].n_evs == 2 and len(ck["eigdata"]) == 2
+    for e in ck["eigdata"].values():
+        assert e["eigvec"].shape == (2, 8, 32, 16) and torch.isfinite(e["eigvec"]).all() and (e["eigval"] > 0).all()
+    papply.main(["--extraction_path", pts[0], "--drift_start", "5", "--drift_end", "3", "--amount", "1.5", "--evs", "1",
+                 "2", "-s", "1"])
+    assert len(glob.glob(pts[0][:-3] + "_driftgens/*.wav")) == 2 and os.path.exists(pts[0][:-3] + ".wav")
+    # ---- (2) HIP vs the CPU interpreter stack, same seeds
+    a = pext.finish_args(Namespace(seed=1, cfg_tar=3, model_id="tiny/audioldm2", init_aud=None, num_diffusion_steps=T,
+                                   source_prompt=["rain"], target_neg_prompt=[""], corr_to_swap=0.8, drift_start=5,
+                                   drift_end=3, results_path="unused", const=1e-2, n_evs=2, patch=None, iters=4,
+                                   dry=False))
+    ap = Namespace(drift_start=5, drift_end=3, amount=1.5, use_specific_ts_pc=None, fix_alpha=None, fade_length=0.0,
+                   evs=[1, 2], combine_evs=False, evals_pt=None, rand_v=False, shift_x0_for_np=True, sub_iters=None)
+    w0 = torch.randn(1, 8, 32, 16, generator=torch.Generator().manual_seed(5)) * 0.7
+    keys = ("eigdata", "args", "corrs", "in_corrs", "latents", "in_norms", "xts")
+    m = models.load_model("tiny/audioldm2", DEV, T, seed=0)
+    torch.manual_seed(1)
+    ck_g = pext.extract_pcs(m, w0.to(DEV), a)
+    out_g = papply.apply_pcs(m, {k: ck_g[k] for k in keys}, ap, torch.device(DEV)).cpu()
+    torch.cuda.synchronize()
+
+    class _Cpu(models.AudioLDM2Wrapper):
+        def _require_device(self):
+            pass
+    install_cpu_stack(monkeypatch)
+    mc = _Cpu(model_id="tiny/audioldm2", device="cpu", seed=0)
+    mc.load_scheduler()
+    mc.model.scheduler.set_timesteps(T, device=None)
+    torch.manual_seed(1)
+    ck_c = pext.extract_pcs(mc, w0, a)
+    out_c = papply.apply_pcs(mc, {k: ck_c[k] for k in keys}, ap, torch.device("cpu"))
+    rel = lambda x, y: ((x - y).norm() / y.norm().clamp_min(1e-12)).item()                        # noqa: E731
+    assert rel(ck_g["xts"].cpu()[1:], ck_c["xts"][1:]) < 1e-4                                     # inverted trajectory
+    assert sorted(ck_g["eigdata"]) == sorted(ck_c["eigdata"])
+    for t in ck_c["eigdata"]:
+        eg, ec = ck_g["eigdata"][t], ck_c["eigdata"][t]
+        torch.testing.assert_close(eg["eigval"].cpu().reshape(-1), ec["eigval"].reshape(-1), rtol=0.1, atol=1e-6)
+        cos = (eg["eigvec"].cpu().reshape(2, -1) * ec["eigvec"].reshape(2, -1)).sum(1).abs()
+        assert cos.min() > 0.98, (t, cos)
+    assert rel(ck_g["final"].cpu(), ck_c["final"]) < 5e-3
+    assert out_g.shape == out_c.shape == (2, 8, 32, 16) and rel(out_g, out_c) < 3e-2, rel(out_g, out_c)
+    assert rel(out_g[0:1], ck_g["final"].cpu()) > 1e-3                                           # the drift moved the sample

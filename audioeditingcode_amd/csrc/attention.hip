@@ -425,6 +425,256 @@ __global__ __launch_bounds__(256) void attention_split_kernel(AttnParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Transposed-score flash attention on v_mfma_f32_32x32x2_f32 (round 2) for long key sequences (self-attention at
+// 1024 / 256 tokens: 15 % of the batch-40 inversion forward).  Each wavefront owns 32 queries and works alone:
+//   S^T[key, q] = K Q^T   -- A = a 32-key tile of K (from the wave's own LDS slab), B = Q^T held in registers.
+//     In the 32x32 accumulator layout a lane holds 16 keys of ONE query (column = lane & 31), so the softmax row
+//     statistics are in-lane reductions plus one v_permlane32_swap between the two lane halves -- no DPP ladders;
+//   O^T[d, q] += V^T P^T   -- B = P^T: accumulator register r of S^T carries keys {k, k+4} of query q in lanes
+//     (q, 0) / (q, 1), which is exactly the k-pair one 32x32x2 MFMA consumes: the probabilities feed the second MFMA
+//     straight from the accumulator registers, P never touches LDS; A = V^T read from the slab (stored transposed).
+// K/V tiles are staged by the wave itself (coalesced K rows, transposed V), the next tile is prefetched into registers
+// under the MFMAs, LDS operations of one wave execute in order -> no workgroup barrier in the key loop.
+// KSPLIT = 1: the 4 waves of a workgroup take 4 consecutive query tiles (throughput regime, U-Net batch 2G);
+// KSPLIT = 4: they take the SAME query tile and every 4th key tile each, merged once through LDS (latency regime).
+typedef float f32x16a __attribute__((ext_vector_type(16)));
+
+template <int D, int KSPLIT>
+__global__ __launch_bounds__(256) void attention_t_kernel(AttnParams p) {
+    constexpr int DT = (D + 31) / 32;              // 32-row tiles of O^T
+    constexpr int KLD = D + 4;                     // K slab row (floats)
+    constexpr int VLD = 32 + 4;                    // V^T slab row
+    constexpr int NJ = D / 8;                      // float4 per lane of a Q / K fragment
+    constexpr int SLAB = 32 * KLD + DT * 32 * VLD;
+    constexpr int MSZ = DT * 16 + 2;               // merge record per lane
+    static_assert(D % 8 == 0, "head dim");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fi = lane & 31, fh = lane >> 5;
+    float* Ks = smem + wave * SLAB;
+    float* Vt = Ks + 32 * KLD;
+
+    // XCD-aware order: the query tiles of one (batch, head) run on one XCD (they share that head's K/V in its L2)
+    int qt, head, b;
+    {
+        const unsigned nx = gridDim.x, ny = gridDim.y, nwg = nx * ny * gridDim.z;
+        const unsigned orig = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
+        const unsigned xcd = orig & 7u, q = nwg >> 3, r = nwg & 7u;
+        const unsigned id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+        qt = (int)(id % nx);
+        head = (int)((id / nx) % ny);
+        b = (int)(id / (nx * ny));
+    }
+    const int q0 = (KSPLIT == 1 ? qt * 128 + wave * 32 : qt * 32);
+    const int hoff = head * D;
+    const float* Q = p.q + (size_t)b * p.bsq + hoff;
+    const float* K = p.k + (size_t)b * p.bsk + hoff;
+    const float* V = p.v + (size_t)b * p.bsv + hoff;
+    const float* bias = p.bias ? p.bias + (size_t)b * p.ld_bias : nullptr;
+
+    // Q^T fragments (B operand): lane (n, h) holds Q[q0+n][8j + 4h .. +3], pre-scaled
+    float4 qf[NJ];
+    {
+        const int qr = min(q0 + fi, p.Nq - 1);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            float4 v = *reinterpret_cast<const float4*>(Q + (size_t)qr * p.ldq + 8 * j + 4 * fh);
+            qf[j] = make_float4(v.x * p.scale, v.y * p.scale, v.z * p.scale, v.w * p.scale);
+        }
+    }
+    f32x16a oacc[DT];
+#pragma unroll
+    for (int c = 0; c < DT; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[c][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;          // l_run: this lane's 16-key share; halves are added at the end
+
+    // staging maps.  K: float4 idx = lane + 64*i -> (key = idx / (D/4), c4 = idx % (D/4)), coalesced rows.
+    //                V: key = lane & 31, channels 4*(2*i + fh) .. +3, written transposed.
+    constexpr int KC4 = D / 4;
+    constexpr int NKL = (32 * KC4) / 64;           // = D/8 float4 per lane for K, same count for V
+    float4 kreg[NKL], vreg[NKL];
+    const int ntiles = (p.Nk + 31) / 32;
+    auto prefetch = [&](int t) {
+        const int k0 = min(t, ntiles - 1) * 32;    // dead prefetches stay in bounds
+#pragma unroll
+        for (int i = 0; i < NKL; ++i) {
+            const int idx = lane + 64 * i;
+            const int key = min(k0 + idx / KC4, p.Nk - 1);
+            kreg[i] = *reinterpret_cast<const float4*>(K + (size_t)key * p.ldk + 4 * (idx % KC4));
+        }
+        const int vk = min(k0 + fi, p.Nk - 1);
+#pragma unroll
+        for (int i = 0; i < NKL; ++i)
+            vreg[i] = *reinterpret_cast<const float4*>(V + (size_t)vk * p.ldv + 4 * (2 * i + fh));
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < NKL; ++i) {
+            const int idx = lane + 64 * i;
+            const float4 v = kreg[i];
+            *reinterpret_cast<float4*>(Ks + (idx / KC4) * KLD + 4 * (idx % KC4)) = make_float4(v.x, v.y, v.z, v.w);
+        }
+#pragma unroll
+        for (int i = 0; i < NKL; ++i) {
+            const int dd = 4 * (2 * i + fh);
+            const float4 v = vreg[i];
+            Vt[(dd + 0) * VLD + fi] = v.x;
+            Vt[(dd + 1) * VLD + fi] = v.y;
+            Vt[(dd + 2) * VLD + fi] = v.z;
+            Vt[(dd + 3) * VLD + fi] = v.w;
+        }
+    };
+    if constexpr (DT * 32 > D) {                   // rows d >= D of V^T are never staged: keep them zero
+        for (int e = lane; e < (DT * 32 - D) * VLD; e += 64) Vt[D * VLD + e] = 0.f;
+    }
+
+    const int t_first = (KSPLIT == 1 ? 0 : wave);
+    constexpr int TSTEP = (KSPLIT == 1 ? 1 : KSPLIT);
+    prefetch(t_first);
+    for (int t = t_first; t < ntiles; t += TSTEP) {
+        stage();
+        prefetch(t + TSTEP);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        // ---- S^T tile: 32 keys x 32 queries, K = D
+        f32x16a sacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const float4 kf = *reinterpret_cast<const float4*>(Ks + fi * KLD + 8 * j + 4 * fh);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[j].x, sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[j].y, sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[j].z, sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[j].w, sacc, 0, 0, 0);
+        }
+        // sacc[r] = S[key k0 + (r&3) + 8*(r>>2) + 4*fh][query fi]
+        const int k0 = t * 32;
+        if (bias) {
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    sacc[4 * rq + e] += bias[min(k0 + 8 * rq + 4 * fh + e, p.Nk - 1)];
+        }
+        if (k0 + 32 > p.Nk) {                      // ragged last tile (wave-uniform)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (k0 + (r & 3) + 8 * (r >> 2) + 4 * fh >= p.Nk) sacc[r] = -INFINITY;
+        }
+        float mx = sacc[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[r]);
+        {
+            auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));       // the other 16 keys of this query
+        }
+        const float mn = fmaxf(m_run, mx);
+        const float alpha = __expf(m_run - mn);
+        m_run = mn;
+        float rsum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            sacc[r] = __expf(sacc[r] - mn);
+            rsum += sacc[r];
+        }
+        l_run = l_run * alpha + rsum;
+#pragma unroll
+        for (int c = 0; c < DT; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[c][r] *= alpha;
+        // ---- O^T += V^T P^T: register r of sacc is the B operand (keys k, k+4 in the two lane halves)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+#pragma unroll
+            for (int c = 0; c < DT; ++c) {
+                const float4 vf = *reinterpret_cast<const float4*>(Vt + (c * 32 + fi) * VLD + 8 * rq + 4 * fh);
+                oacc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.x, sacc[4 * rq + 0], oacc[c], 0, 0, 0);
+                oacc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.y, sacc[4 * rq + 1], oacc[c], 0, 0, 0);
+                oacc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.z, sacc[4 * rq + 2], oacc[c], 0, 0, 0);
+                oacc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.w, sacc[4 * rq + 3], oacc[c], 0, 0, 0);
+            }
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // ---- merge the key splits (same queries, same lane layout) through LDS
+    if constexpr (KSPLIT > 1) {
+        __syncthreads();                           // every wave is done with its slab
+        float* mrg = smem;                         // [KSPLIT-1][64][MSZ]
+        if (wave > 0) {
+            float* dst = mrg + ((wave - 1) * 64 + lane) * MSZ;
+            dst[0] = m_run;
+            dst[1] = l_run;
+#pragma unroll
+            for (int c = 0; c < DT; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dst[2 + 16 * c + r] = oacc[c][r];
+        }
+        __syncthreads();
+        if (wave > 0) return;
+        float mt = m_run;
+#pragma unroll
+        for (int w = 0; w < KSPLIT - 1; ++w) mt = fmaxf(mt, mrg[(w * 64 + lane) * MSZ]);
+        const float a0 = (m_run == -INFINITY) ? 0.f : __expf(m_run - mt);
+        l_run *= a0;
+#pragma unroll
+        for (int c = 0; c < DT; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[c][r] *= a0;
+#pragma unroll
+        for (int w = 0; w < KSPLIT - 1; ++w) {
+            const float* src = mrg + (w * 64 + lane) * MSZ;
+            const float mw = src[0];
+            const float aw = (mw == -INFINITY) ? 0.f : __expf(mw - mt);
+            l_run += src[1] * aw;
+#pragma unroll
+            for (int c = 0; c < DT; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[c][r] += src[2 + 16 * c + r] * aw;
+        }
+    }
+    // ---- finish: add the two lane halves' shares of l, normalise, store O[q][d] (4 consecutive d per register quad)
+    {
+        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
+        l_run = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
+    const float inv = 1.0f / l_run;
+    const int qr = q0 + fi;
+    if (qr < p.Nq) {
+        float* O = p.o + (size_t)b * p.bso + hoff + (size_t)qr * p.ldo;
+#pragma unroll
+        for (int c = 0; c < DT; ++c)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int d0 = c * 32 + 8 * rq + 4 * fh;
+                if (d0 < D)
+                    *reinterpret_cast<float4*>(O + d0) = make_float4(oacc[c][4 * rq] * inv, oacc[c][4 * rq + 1] * inv,
+                                                                     oacc[c][4 * rq + 2] * inv, oacc[c][4 * rq + 3] * inv);
+            }
+    }
+}
+
+template <int D, int KSPLIT>
+static int launch_t(const AttnParams& p, int B, hipStream_t s) {
+    constexpr int DT = (D + 31) / 32;
+    constexpr int SLAB = 32 * (D + 4) + DT * 32 * 36;
+    constexpr int MRG = (KSPLIT - 1) * 64 * (DT * 16 + 2);
+    const size_t bytes = sizeof(float) * (4 * SLAB > MRG ? 4 * SLAB : MRG);
+    static bool attr_set = false;
+    if (!attr_set) {
+        AED_CHECK_HIP(hipFuncSetAttribute((const void*)attention_t_kernel<D, KSPLIT>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        attr_set = true;
+    }
+    dim3 grid(aed_cdiv(p.Nq, KSPLIT == 1 ? 128 : 32), p.H, B);
+    hipLaunchKernelGGL((attention_t_kernel<D, KSPLIT>), grid, dim3(256), bytes, s, p);
+    return 0;
+}
+
 template <int D>
 static int launch_split(const AttnParams& p, int B, hipStream_t s) {
     constexpr int KLD = D + 4, VLD = KV_TILE + 4;
@@ -442,7 +692,7 @@ static int launch_split(const AttnParams& p, int B, hipStream_t s) {
 
 // slots: p0=q p1=k p2=v p3=bias(or null) p4=out
 //        i0=B i1=H i2=Nq i3=Nk i4=D i5=ldq i6=ldk i7=ldv i8=ldo i9=ld_bias
-//        i10=bsq i11=bsk i12=bsv i13=bso (elements) i14=variant (0 auto: split-KV when Nk > 64; 1 forces single-pass) ; f0=scale
+//        i10=bsq i11=bsk i12=bsv i13=bso (elements) i14=variant (0 auto: transposed-score kernel when Nk > 64; 1 forces single-pass; 2 forces split-KV) ; f0=scale
 int launch_attention(const aed_op* op, hipStream_t s) {
     const int32_t* i = op->i;
     AttnParams p;
@@ -455,6 +705,25 @@ int launch_attention(const aed_op* op, hipStream_t s) {
     p.scale = op->f[0];
     AED_REQUIRE(p.ldq % 4 == 0 && p.ldk % 4 == 0 && p.ldv % 4 == 0, "attention: row strides must be multiples of 4");
     AED_REQUIRE(p.Nq > 0 && p.Nk > 0, "attention: empty sequence");
+    AED_REQUIRE(p.ldo % 4 == 0, "attention: output row stride must be a multiple of 4");
+    if (p.Nk > KV_TILE && i[14] != 1 && i[14] != 2) {
+        // transposed-score kernel (i14 = 2 forces the older split-KV kernel for A/B runs).  Few workgroups (U-Net batch 2):
+        // the 4 waves of a workgroup split the keys; many: each wave takes its own query tile.
+        const long wg_ksplit1 = (long)aed_cdiv(p.Nq, 128) * p.H * i[0];
+        const bool ks4 = wg_ksplit1 < 2L * aed_num_cus();
+        int rc = 0;
+        switch (i[4]) {
+            case 32: rc = ks4 ? launch_t<32, 4>(p, i[0], s) : launch_t<32, 1>(p, i[0], s); break;
+            case 48: rc = ks4 ? launch_t<48, 4>(p, i[0], s) : launch_t<48, 1>(p, i[0], s); break;
+            case 64: rc = ks4 ? launch_t<64, 4>(p, i[0], s) : launch_t<64, 1>(p, i[0], s); break;
+            case 80: rc = ks4 ? launch_t<80, 4>(p, i[0], s) : launch_t<80, 1>(p, i[0], s); break;
+            case 16: rc = ks4 ? launch_t<16, 4>(p, i[0], s) : launch_t<16, 1>(p, i[0], s); break;
+            default: AED_REQUIRE(false, "attention: unsupported head dim %d (16/32/48/64/80)", i[4]);
+        }
+        if (rc) return rc;
+        AED_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
     if (p.Nk > KV_TILE && i[14] != 1) {        // split-KV variant (i14 = 1 forces the single-pass kernel)
         int rc = 0;
         switch (i[4]) {

@@ -31,6 +31,7 @@ struct CGParams {
     int ln_mode;             // 1: A rows are LayerNorm inputs; W has gamma folded in, rowvec = sum_k W'[n,k], bias = W.beta (+bias)
     float ln_eps;
     int C1, lda2, a_bs2;     // two-source A: channel c < C1 comes from A (lda, a_bs), c >= C1 from A2 (lda2, a_bs2) at c - C1
+    int late_epilogue;       // A/B switch (op flag 2): fetch bias / residual after the reduction instead of up front
     int geglu;               // 1: W rows are packed [32 value | 32 gate] per 32 output features; out = value * gelu(gate)
 };
 

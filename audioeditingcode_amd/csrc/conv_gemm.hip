@@ -597,6 +597,7 @@ int cg_fill_params(const aed_op* op, CGParams& p, int bkt) {
     p.rowvec = (const float*)op->p[5];
     p.ws = (float*)op->p[6];
     p.dbg = (op->flags & 1) ? (long long*)op->p[7] : nullptr;
+    p.late_epilogue = (op->flags & 2) ? 1 : 0;
     const int32_t* i = op->i;
     p.M = i[0]; p.N = i[1]; p.K = i[2]; p.lda = i[3]; p.ldc = i[4]; p.ldr = i[5]; p.ld_rv = i[6];
     p.IH = i[7]; p.IW = i[8]; p.OH = i[9]; p.OW = i[10]; p.Cin = i[11]; p.KH = i[12]; p.KW = i[13];

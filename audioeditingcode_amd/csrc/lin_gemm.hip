@@ -131,7 +131,7 @@ __global__ __launch_bounds__(64 * NW) void lin_gemm_kernel(CGParams p) {
         e_bias[b] = p.bias ? p.bias[no] : 0.f;
         e_sum[b] = LN ? p.rowvec[no] : 0.f;
     }
-    if (simple && p.res != nullptr) {
+    if (simple && p.res != nullptr && !p.late_epilogue) {
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(64 * NW) void lin_gemm_kernel(CGParams p) {
                     if (no >= p.N) continue;
                     float val = v[b];
                     if constexpr (LN) val = rstd * (val - mean * e_sum[b]);
-                    val += e_bias[b] + e_res[a][i][b];
+                    val += e_bias[b] + (p.late_epilogue && p.res ? p.res[(size_t)mo * p.ldr + no] : e_res[a][i][b]);
                     if (p.out_act != AED_ACT_NONE) val = aed_apply_act(val, p.out_act, p.out_p);
                     p.C[(size_t)mo * p.ldc + no] = val;
                 }

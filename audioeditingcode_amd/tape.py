@@ -25,6 +25,7 @@ ATTN_VARIANT = int(os.environ.get("AED_ATTN_VARIANT", "0"))      # 0 auto (split
 GN_VARIANT = 0                                                   # (round-1 A/B switch; one kernel generation remains)
 # 1 (default): small contractions go to the latency-regime kernels of lin_gemm.hip; 0: round-1 routing (A/B runs)
 LIN_MODE = int(os.environ.get("AED_LIN_MODE", "1"))
+LATE_EPILOGUE = int(os.environ.get("AED_LATE_EPILOGUE", "0"))     # A/B: lin_gemm fetches the residual after its reduction
 # measured (tile, ksplit) per (M, N, K, geglu), filled from tools/tile_sweep.py runs (see tile_table.py); the
 # environment override "M,N,K,g:tile[:ksplit];..." is what the sweep tool itself uses
 try:
@@ -192,7 +193,7 @@ class Tape:
         n_out = N // 2 if geglu else N
         idx = self._add(L.OP_CONV_GEMM, i, [in_slope, out_p, out_div, ln_eps],
                         [x, w, bias, out, res, rowvec, None, None, x2, None], name=name, flops=2 * M * N * K,
-                        nbytes=4 * (B * IH * IW * Cin + N * K + M * n_out))
+                        nbytes=4 * (B * IH * IW * Cin + N * K + M * n_out), flags=2 if LATE_EPILOGUE else 0)
         if ksplit > 1:
             self._ws_need = max(self._ws_need, ksplit * M * N)
             self._ws_ops.append(idx)

@@ -139,9 +139,22 @@ def test_attention(B, H, Nq, Nk, D, masked):
 
 
 @pytest.mark.parametrize("B,H,Nq,Nk,D,masked", [(1, 2, 40, 200, 16, False), (1, 1, 33, 97, 80, True)])
-def test_attention_split_kv_ragged(B, H, Nq, Nk, D, masked):
-    """split-KV kernel with key counts that are not a multiple of its 128-key round"""
+def test_attention_ragged_long_keys(B, H, Nq, Nk, D, masked):
+    """long-key kernels with key / query counts that are not multiples of their tiles"""
     _attention_case(B, H, Nq, Nk, D, masked, variant=0)
+    _attention_case(B, H, Nq, Nk, D, masked, variant=2)
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk,D,masked", [(16, 8, 512, 512, 32, False), (32, 8, 256, 256, 48, True),
+                                                 (40, 8, 128, 100, 64, True)])
+def test_attention_transposed_kernel_throughput_mode(B, H, Nq, Nk, D, masked):
+    """enough workgroups that every wave takes its own query tile (KSPLIT = 1; U-Net batch 2G of the inversion)"""
+    _attention_case(B, H, Nq, Nk, D, masked, variant=0)
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk,D,masked", [(2, 8, 1024, 1024, 32, False), (2, 8, 256, 256, 48, False)])
+def test_attention_split_kv_kernel_kept_for_ab(B, H, Nq, Nk, D, masked):
+    _attention_case(B, H, Nq, Nk, D, masked, variant=2)
 
 
 def _attention_case(B, H, Nq, Nk, D, masked, variant):

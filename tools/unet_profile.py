@@ -2,7 +2,7 @@
 weights): eager time, hipGraph replay time, HIP-event pair per op, and a JSON dump of every op's shape + time.
 
     PYTHONPATH=. python tools/unet_profile.py <B> [variant ...]
-variant = comma list of lin=0|1, geglu=0|1, two=0|1, attn=0|2, gn=0|1  (default: the package defaults), e.g.
+variant = comma list of lin=0|1, geglu=0|1, two=0|1, late=0|1, merge=0|1  (default: the package defaults), e.g.
     python tools/unet_profile.py 2 lin=0,geglu=0,two=0 "" attn=2 gn=1"""
 import collections
 import json
@@ -21,14 +21,16 @@ fam = configs.FAMILIES["audioldm2"]
 sd = weights.random_state_dict(weights.unet_param_shapes(fam["unet"]), seed=0)
 packed = PackedUNetWeights(sd, "cuda:0")
 DEFAULTS = dict(lin=tape_mod.LIN_MODE, geglu=int(unet_mod.FUSE_GEGLU), two=int(unet_mod.TWO_SOURCE),
-                attn=tape_mod.ATTN_VARIANT, gn=tape_mod.GN_VARIANT)
+                attn=tape_mod.ATTN_VARIANT, gn=tape_mod.GN_VARIANT, late=tape_mod.LATE_EPILOGUE,
+                merge=int(unet_mod.MERGE_FF2_PROJ))
 st = torch.cuda.Stream()
 os.makedirs("gpurun_out", exist_ok=True)
 for spec in variants:
     v = dict(DEFAULTS)
     v.update({k: int(x) for k, x in (kv.split("=") for kv in spec.split(",") if kv)})
     tape_mod.LIN_MODE, tape_mod.ATTN_VARIANT, tape_mod.GN_VARIANT = v["lin"], v["attn"], v["gn"]
-    tag = "_".join(f"{k}{v[k]}" for k in ("lin", "geglu", "two", "attn", "gn"))
+    tape_mod.LATE_EPILOGUE, unet_mod.MERGE_FF2_PROJ = v["late"], bool(v["merge"])
+    tag = "_".join(f"{k}{v[k]}" for k in ("lin", "geglu", "two", "late", "merge"))
     eng = UNetEngine(fam["unet"], packed, "cuda:0", B, 256, 16, ctx_len0=8, ctx_len1=16, fuse_geglu=bool(v["geglu"]),
                      two_source=bool(v["two"]))
     g = torch.Generator().manual_seed(1)

@@ -30,7 +30,7 @@ for spec in variants:
     v.update({k: int(x) for k, x in (kv.split("=") for kv in spec.split(",") if kv)})
     tape_mod.LIN_MODE, tape_mod.ATTN_VARIANT, tape_mod.GN_VARIANT = v["lin"], v["attn"], v["gn"]
     tape_mod.LATE_EPILOGUE, unet_mod.MERGE_FF2_PROJ = v["late"], bool(v["merge"])
-    tag = "_".join(f"{k}{v[k]}" for k in ("lin", "geglu", "two", "late", "merge"))
+    tag = "_".join(f"{k}{v[k]}" for k in ("lin", "geglu", "two", "late", "merge", "attn"))
     eng = UNetEngine(fam["unet"], packed, "cuda:0", B, 256, 16, ctx_len0=8, ctx_len1=16, fuse_geglu=bool(v["geglu"]),
                      two_source=bool(v["two"]))
     g = torch.Generator().manual_seed(1)

@@ -663,7 +663,7 @@ static void launch_generic(const CGParams& p, hipStream_t s) {
     hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WR, WC, true, 1, 32, false>), grid, dim3(256), 0, s, p);
 }
 
-// tile_cfg: 0 auto, 1 = 128x128, 2 = 128x64, 4 = 64x64, 5 = 128x32, 6 = 32x128, 7 = wave-split-K 32x32
+// tile_cfg: 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x128, 4 = 64x64, 5 = 128x32, 6 = 32x128, 7 = wave-split-K 32x32
 // i[30] = 1 forces the 32-wide K chunk (A/B testing)
 int launch_conv_gemm(const aed_op* op, hipStream_t s) {
     CGParams p;
@@ -672,7 +672,6 @@ int launch_conv_gemm(const aed_op* op, hipStream_t s) {
     const bool generic = (Cin % 32 != 0) || (i[3] % 4 != 0) || ((uintptr_t)op->p[0] % 16 != 0) ||
                          ((uintptr_t)op->p[1] % 16 != 0);
     int cfg = i[29];
-    if (cfg == 3) cfg = 2;
     if (cfg >= 10) {                 // latency-regime kernels (lin_gemm.hip)
         int rc = cg_fill_params(op, p, 32);
         if (rc) return rc;
@@ -689,18 +688,19 @@ int launch_conv_gemm(const aed_op* op, hipStream_t s) {
         else cfg = 4;
         if (N < 64 && cfg != 5) cfg = 5;
     }
-    if (generic && (cfg == 1 || cfg == 2)) cfg = 4;     // the scalar-gather path only exists for the small tiles
+    if (generic && (cfg == 1 || cfg == 2 || cfg == 3)) cfg = 4;     // the scalar-gather path only exists for the small tiles
     // K chunk: 32 (two LDS stages of a 128x128 tile = 72 KB -> two blocks per CU); 64 for the 64x64 tile when the
     // channel count allows (half the barriers, still two blocks per CU)
     const bool bk64 = !generic && (Cin % 64 == 0) && i[30] != 1 && cfg == 4;
     int rc = cg_fill_params(op, p, cfg == 7 ? 8 : (bk64 ? 64 : 32));
     if (rc) return rc;
     const bool plain = p.in_act == 0 && p.ln_mode == 0;
-    if (p.geglu) AED_REQUIRE(cfg == 1, "conv_gemm: the GEGLU epilogue exists for the 128x128 tile (cfg %d)", cfg);
+    if (p.geglu) AED_REQUIRE(cfg == 1 || cfg == 3, "conv_gemm: the GEGLU epilogue needs 64-wide wave tiles: 128x128 or 64x128 (cfg %d)", cfg);
     if (p.C1 > 0) AED_REQUIRE(!generic && cfg != 7, "conv_gemm: two-source A needs the vector path of a tiled kernel");
     switch (cfg) {
         case 1: launch_cfg<128, 128, 2, 2, 2, 32>(p, plain, s); break;
         case 2: launch_cfg<128, 64, 2, 2, 2, 32>(p, plain, s); break;
+        case 3: launch_cfg<64, 128, 2, 2, 2, 32>(p, plain, s); break;      // 2x more workgroups than 128x128, same 64-wide wave tiles
         case 4:
             if (generic) launch_generic<64, 64, 2, 2>(p, s);
             else if (bk64) launch_cfg<64, 64, 2, 2, 2, 64>(p, plain, s);

@@ -23,6 +23,7 @@ CU_COUNT = 256          # MI355X; tiling heuristics target this, overridable for
 FORCE_BK = int(os.environ.get("AED_FORCE_BK", "0"))
 ATTN_VARIANT = int(os.environ.get("AED_ATTN_VARIANT", "0"))      # 0 auto (split-KV when Nk > 64), 1 forces single-pass
 GN_VARIANT = 0                                                   # (round-1 A/B switch; one kernel generation remains)
+GN_FORCE_SMALL = int(os.environ.get("AED_GN_FORCE_SMALL", "0"))    # A/B: always take the single-launch GroupNorm when it fits
 # 1 (default): small contractions go to the latency-regime kernels of lin_gemm.hip; 0: round-1 routing (A/B runs)
 LIN_MODE = int(os.environ.get("AED_LIN_MODE", "1"))
 LATE_EPILOGUE = int(os.environ.get("AED_LATE_EPILOGUE", "0"))     # A/B: lin_gemm fetches the residual after its reduction
@@ -215,7 +216,11 @@ class Tape:
         ldx2 = x2.stride(-2) if x2 is not None else 0
         C1 = C1 if x2 is not None else 0
         variant = GN_VARIANT if variant is None else variant
-        if HW * (C // G) <= 65536 and B * G >= 32 and B * HW * C <= (1 << 22):
+        # single launch, one block per (group, batch item) -- unless a group's channels are a sliver of each row
+        # (< 32 B contiguous at >= 2048 rows: every 128-byte line is fetched for 16 useful bytes and the 64 blocks crawl;
+        # measured 25-48 us at the U-Net's level 0 against ~2 x 5 us for the coalesced stats + apply pair)
+        sliver = (C // G) < 8 and HW >= 2048 and not GN_FORCE_SMALL
+        if HW * (C // G) <= 65536 and B * G >= 32 and B * HW * C <= (1 << 22) and not sliver:
             # small map: one launch, one block per (group, batch item) -- latency, not bandwidth, is the cost
             # (variant 1 = second-generation kernel with batched loads, see norm.hip)
             self._add(L.OP_GN_SMALL, [B, HW, C, G, ldx, ldy, act, variant, C1, ldx2], [eps], [x, gamma, beta, out, x2],

@@ -120,7 +120,7 @@ REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
 
 
 def test_default_line_has_the_contract_keys():
-    out = _run(["--steps", "2", "--warmup", "1", "--no-cpu-baseline"], [2, 40])
+    out = _run(["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--group", "20"], [2, 40])
     assert all(k in out for k in REQUIRED)
     assert out["n_gpus"] == 1 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
     assert out["dtype"] == "f32" and out["vs_baseline"] is None and out["higher_is_better"] is True
@@ -134,8 +134,8 @@ def test_default_line_has_the_contract_keys():
 
 
 def test_sequential_schedule_and_multi_clip_mode():
-    out = _run(["--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--schedule", "sequential"], [2, 40])
+    out = _run(["--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--schedule", "sequential", "--group", "20"], [2, 40])
     assert "value_batched_inversion" in out and "reference order" in out["config"]["workload"]
-    out = _run(["--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--clips-per-gpu", "2"], [4, 40])
+    out = _run(["--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--clips-per-gpu", "2", "--group", "20"], [4, 40])
     assert out["config"]["clips_per_gpu_per_step"] == 2 and out["config"]["gathered_latents"] == [[2, 8, 256, 16]]
     assert set(out["roofline"]["by_batch"]) == {"unet_batch_4", "unet_batch_40"}

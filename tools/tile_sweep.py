@@ -57,9 +57,9 @@ def candidates(M, N, K, taps, geglu, generic):
     if generic:
         return [(0, 0)]
     if geglu:
-        c = [(13, 1), (14, 1), (15, 1), (17, 1), (1, 1)]
+        c = [(13, 1), (14, 1), (15, 1), (17, 1), (1, 1), (3, 1)]
     else:
-        c = [(10, 1), (11, 1), (12, 1), (18, 1), (19, 1), (13, 1), (15, 1), (16, 1), (17, 1), (4, 1), (1, 1), (2, 1)]
+        c = [(10, 1), (11, 1), (12, 1), (18, 1), (19, 1), (13, 1), (15, 1), (16, 1), (17, 1), (4, 1), (1, 1), (2, 1), (3, 1)]
         t4 = -(-M // 64) * -(-N // 64)
         if t4 < 256 and K >= 256:          # legacy split-K + reduce
             nch = -(-K // 32)
@@ -68,7 +68,7 @@ def candidates(M, N, K, taps, geglu, generic):
             c.append((7, max(1, -(-K // 1024))))
     big = M * N >= 4096 * 1024
     if big:                                 # throughput regime: the 32x32 lin tiles only add L2 traffic
-        c = [x for x in c if x[0] in (1, 2, 4, 15, 17)]
+        c = [x for x in c if x[0] in (1, 2, 3, 4, 15, 17)]
     return c
 
 

@@ -124,8 +124,8 @@ class Tape:
                     if t <= cus and K >= 512:
                         return 11, 1
                     return 10, 1
-                if blocks(64, 64) <= 4 * cus:
-                    return 15, 1
+                # (beyond ~1000 32x32 tiles the LDS-staged block tiles win every measured shape: the 64x64 lin tile was
+                # 10-20 % behind them at M = 5120 and is only kept for the GEGLU shapes above)
         if geglu:
             return 1, 1
         if (not LIN_MODE) and vector_ok and N > 32 and M > 32 and blocks(64, 64) <= 192 and K <= 2560 and K % 8 == 0:
@@ -138,6 +138,8 @@ class Tape:
             cfg, bm, bn = 1, 128, 128
         elif N >= 64 and blocks(128, 64) >= 2 * cus:
             cfg, bm, bn = 2, 128, 64
+        elif N >= 128 and blocks(64, 128) >= cus:
+            cfg, bm, bn = 3, 64, 128
         elif N < 64:
             cfg, bm, bn = 5, 128, 32
         else:

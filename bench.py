@@ -135,6 +135,41 @@ def cpu_config1_anchor(T, cores):
                 seconds=dt, clips_per_sec=1.0 / dt, finite=bool(torch.isfinite(w_e).all()))
 
 
+def clip_phases(m, fn, wave, src, tgt, neg, args):
+    """Wall time of every phase of one clip (device sync after each); the edit loop also as HIP-event time."""
+    from audioeditingcode_amd.ddm_inversion.inversion_utils import inversion_forward_process, inversion_reverse_process
+    acc = {}
+
+    def tick(label, t_prev):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        acc[label] = round(1e3 * (t - t_prev), 2)
+        return t
+    torch.manual_seed(4242)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    with torch.inference_mode():
+        mel, _, _ = fn.mel_spectrogram(wave)
+        x0 = mel[0].T[:1024][None, None].contiguous()
+        t = tick("stft_mel", t)
+        w0 = m.vae_encode(x0)
+        t = tick("vae_encode", t)
+        _, zs, wts, _ = inversion_forward_process(m, w0, etas=1.0, prompts=src, cfg_scales=[3.0],
+                                                  num_inference_steps=args.T, numerical_fix=True,
+                                                  schedule=args.schedule, timestep_group=args.group)
+        t = tick("inversion (text enc + x_t draws + U-Net loop)", t)
+        w_e, _ = inversion_reverse_process(m, xT=wts, tstart=torch.tensor([args.tstart]), etas=1.0, prompts=tgt,
+                                           neg_prompts=neg, cfg_scales=[12.0], zs=zs[:args.tstart])
+        t = tick("edit (text enc + U-Net loop)", t)
+        acc["edit loop on the device (HIP events)"] = round(m.editor(256, 16).last_loop_ms(), 2)
+        x0_dec = m.vae_decode(w_e)
+        t = tick("vae_decode", t)
+        m.decode_to_mel(x0_dec)
+        m.decode_to_mel(x0)
+        tick("vocoder x2", t)
+    return acc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -276,6 +311,15 @@ def main():
     # replayed n times between one event pair -> forward_ms (what the loops actually pay per U-Net call, no per-launch
     # event overhead); (2) one eager pass with an event pair per op gives every op's share; the family's time inside the
     # graph is forward_ms * (family share).  rocprofv3 --kernel-trace of the same command (profiles/) must agree.
+    # ---- where one clip's time goes (one extra clip, not part of the metric, with a device sync after every phase)
+    phases = None
+    if rank == 0 and NC == 1:
+        try:                    # reported-only leg: the headline line must survive a failure here
+            phases = clip_phases(m, fn, clip_wave(777), src, tgt, neg, args)
+            log(f"phases of one clip [ms]: {phases}")
+        except Exception as e:
+            log(f"phase timing failed: {e!r}")
+
     roof = None
     if rank == 0:
         ed = m.editor(256, 16)
@@ -375,7 +419,7 @@ def main():
                           "clips_per_gpu_per_step": NC, "parallelism": f"clip-dp{world}",
                           "weights_broadcast_s": t_bcast if world > 1 else 0.0,
                           "gathered_latents": None if gathered is None else [list(g.shape) for g in gathered][:2]},
-               "roofline": roof, "cpu_baseline": base}
+               "roofline": roof, "cpu_baseline": base, "phases_ms_one_clip": phases}
         out.update(extra)
         print(json.dumps(out))
 

@@ -32,6 +32,13 @@ struct CGParams {
     float ln_eps;
     int C1, lda2, a_bs2;     // two-source A: channel c < C1 comes from A (lda, a_bs), c >= C1 from A2 (lda2, a_bs2) at c - C1
     int late_epilogue;       // A/B switch (op flag 2): fetch bias / residual after the reduction instead of up front
+    // per-batch-item operands (cross-attention folded into two skinny GEMMs, see unet.py): W, bias and rowvec advance by
+    // these element strides with the batch item of the output row; vec_ld = stride between consecutive n in bias/rowvec
+    int w_bs, vec_bs, vec_ld;
+    // grouped softmax epilogue: out = softmax over each run of sm_group consecutive columns of (val * sm_scale + kbias[b][n % sm_group])
+    int sm_group;
+    float sm_scale;
+    const float* kbias;
     int geglu;               // 1: W rows are packed [32 value | 32 gate] per 32 output features; out = value * gelu(gate)
 };
 

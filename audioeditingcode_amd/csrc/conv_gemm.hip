@@ -608,7 +608,10 @@ int cg_fill_params(const aed_op* op, CGParams& p, int bkt) {
     p.ln_mode = i[31]; p.ln_eps = op->f[3];
     p.C1 = i[32]; p.lda2 = i[33]; p.a_bs2 = i[34]; p.geglu = i[35];
     p.A2 = (const float*)op->p[8];
-    p.stats = (float*)op->p[9];
+    p.stats = nullptr;
+    p.sm_group = i[36]; p.w_bs = i[37]; p.vec_ld = i[38] > 0 ? i[38] : 1; p.vec_bs = i[39];
+    p.sm_scale = op->f[4];
+    p.kbias = (const float*)op->p[9];
     p.rpb = p.OH * p.OW;
     p.nchunks = (p.K + bkt - 1) / bkt;
     p.vIH = p.IH << p.up;
@@ -695,6 +698,8 @@ int launch_conv_gemm(const aed_op* op, hipStream_t s) {
     int rc = cg_fill_params(op, p, cfg == 7 ? 8 : (bk64 ? 64 : 32));
     if (rc) return rc;
     const bool plain = p.in_act == 0 && p.ln_mode == 0;
+    AED_REQUIRE(p.sm_group == 0 && p.w_bs == 0 && p.vec_bs == 0 && p.vec_ld == 1,
+                "conv_gemm: per-batch weights / grouped softmax exist only in the lin_gemm kernels (tile >= 10)");
     if (p.geglu) AED_REQUIRE(cfg == 1 || cfg == 3, "conv_gemm: the GEGLU epilogue needs 64-wide wave tiles: 128x128 or 64x128 (cfg %d)", cfg);
     if (p.C1 > 0) AED_REQUIRE(!generic && cfg != 7, "conv_gemm: two-source A needs the vector path of a tiled kernel");
     switch (cfg) {

@@ -99,11 +99,13 @@ __global__ __launch_bounds__(64 * NW) void lin_gemm_kernel(CGParams p) {
             aoff2[j] = (unsigned)mm * (unsigned)p.lda2 + lseg;
         }
     }
+    // batch item of this tile's rows (per-batch weights / vectors; a tile never straddles batch items there)
+    const int bt = (p.w_bs | p.vec_bs) ? min(m0, p.M - 1) / p.rpb : 0;
     unsigned woff[PW];
 #pragma unroll
     for (int j = 0; j < PW; ++j) {
         const int n = min(n0 + lrow + 8 * j, p.N - 1);      // rows past N compute garbage columns that are never stored
-        woff[j] = (unsigned)n * (unsigned)p.K + lseg;
+        woff[j] = (unsigned)bt * (unsigned)p.w_bs + (unsigned)n * (unsigned)p.K + lseg;
     }
     const int vIH = p.vIH, vIW = p.vIW;
     // running (tap, channel) position of the next chunk to prefetch
@@ -128,8 +130,9 @@ __global__ __launch_bounds__(64 * NW) void lin_gemm_kernel(CGParams p) {
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
         const int no = min(n0 + b * 32 + col, p.N - 1);
-        e_bias[b] = p.bias ? p.bias[no] : 0.f;
-        e_sum[b] = LN ? p.rowvec[no] : 0.f;
+        const size_t vo = (size_t)bt * p.vec_bs + (size_t)no * p.vec_ld;
+        e_bias[b] = p.bias ? p.bias[vo] : 0.f;
+        e_sum[b] = LN ? p.rowvec[vo] : 0.f;
     }
     if (simple && p.res != nullptr && !p.late_epilogue) {
 #pragma unroll
@@ -367,6 +370,23 @@ __global__ __launch_bounds__(64 * NW) void lin_gemm_kernel(CGParams p) {
                     const size_t orow = (size_t)b0 * p.out_bs + (mo - b0 * p.rpb);
                     p.C[orow * p.ldc + (n0 >> 1) + b * 16 + col] = val * gelu_exact(gate);
                 }
+            } else if (p.sm_group > 0) {
+                // grouped softmax (cross-attention scores: one group = the keys of one head).  All lanes of a group share
+                // the row (col = lane & 31, groups are aligned runs of 8/16/32 lanes), N is a multiple of 32 here.
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    const int no = n0 + b * 32 + col;
+                    float val = v[b];
+                    if constexpr (LN) val = rstd * (val - mean * e_sum[b]);
+                    val = (val + e_bias[b]) * p.sm_scale;
+                    if (p.kbias) val += p.kbias[(size_t)bt * p.sm_group + (no & (p.sm_group - 1))];
+                    float mx = val;
+                    for (int o = p.sm_group >> 1; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+                    const float e = __expf(val - mx);
+                    float sum = e;
+                    for (int o = p.sm_group >> 1; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+                    p.C[(size_t)mo * p.ldc + no] = e / sum;
+                }
             } else if (simple) {
 #pragma unroll
                 for (int b = 0; b < TN; ++b) {
@@ -434,6 +454,12 @@ int launch_lin_gemm(const CGParams& p, int cfg, hipStream_t s) {
     if (p.C1 > 0)
         AED_REQUIRE(p.A2 && p.C1 % 32 == 0 && p.C1 < p.Cin && p.lda2 % 4 == 0 && ((uintptr_t)p.A2 % 16) == 0,
                     "lin_gemm: bad two-source split C1=%d of Cin=%d", p.C1, p.Cin);
+    if (p.w_bs || p.vec_bs || p.sm_group)
+        AED_REQUIRE(p.rpb % 64 == 0 && p.M % p.rpb == 0, "lin_gemm: per-batch operands need 64-row aligned batch items");
+    if (p.sm_group)
+        AED_REQUIRE((p.sm_group == 8 || p.sm_group == 16 || p.sm_group == 32) && p.N % 32 == 0 && !p.res && !p.geglu &&
+                        p.o_mul == 1 && p.o_add == 0 && p.out_bs == p.rpb && p.accumulate == 0,
+                    "lin_gemm: grouped softmax needs groups of 8/16/32 columns, N %% 32 == 0 and a plain row layout");
     if (p.geglu)
         AED_REQUIRE(p.N % 64 == 0 && (cfg == 13 || cfg == 14 || cfg == 15 || cfg == 17) && !p.res && p.out_act == 0 &&
                         p.o_mul == 1 && p.o_add == 0 && (p.ln_mode || !p.rowvec),

@@ -130,12 +130,21 @@ class EditEngine:
             e0, b0 = _pad_ctx(groups, eng.L0, "ehs0", "mask0")
             eng.set_conditioning(ehs0=e0, bias0=b0)
 
+    @staticmethod
+    def _round_len(n):
+        """Padded context length: the next power of two in [8, 32] (padding keys carry an exactly-zero weight, PAD_BIAS),
+        so the folded cross-attention's per-head softmax groups fit a 32-column tile; longer contexts stay as they are."""
+        for p2 in (8, 16, 32):
+            if n <= p2:
+                return p2
+        return n
+
     def _ctx_lens(self, groups):
         if self.kind == "audioldm":
             return 0, 0
         if self.kind == "audioldm2":
-            return groups[0].ehs0.shape[1], max(g.ehs1.shape[1] for g in groups)
-        return max(g.ehs0.shape[1] for g in groups), 0
+            return groups[0].ehs0.shape[1], self._round_len(max(g.ehs1.shape[1] for g in groups))
+        return self._round_len(max(g.ehs0.shape[1] for g in groups)), 0
 
     @torch.inference_mode()
     def to_nhwc(self, x, out=None):

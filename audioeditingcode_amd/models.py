@@ -213,7 +213,50 @@ class PipelineWrapper(torch.nn.Module):
         draw order, arithmetic on the device."""
         ed = self.editor(x0.shape[-2], x0.shape[-1])
         x = x0.reshape(1, *x0.shape[-3:])
-        return ed.sample_xts(x)[:, 0]
+        noise = self._take_prefetched_noise(tuple(x.shape), num_inference_steps)
+        nxt = getattr(self, "next_noise_seed", None)
+        if nxt is not None:            # a serving loop announced the next clip's seed: draw its noise under this clip
+            self.next_noise_seed = None
+            self.prefetch_noise(nxt, x.shape, num_inference_steps)
+        return ed.sample_xts(x, noise=noise)[:, 0]
+
+    # ------------------------------------------------------------------ x_t noise prefetch (serving loops)
+    def prefetch_noise(self, seed: int, shape, num_inference_steps: int) -> None:
+        """Draw the T x_t noise maps of the NEXT clip on a host thread while the current clip runs on the GPU.
+
+        Same generator algorithm, same seed, same draw order as the in-line path (`torch.manual_seed(seed)` followed by
+        one `randn` per timestep, models.py:76-81): a fresh CPU `torch.Generator` seeded with `seed` yields the identical
+        stream, and one `randn` of T stacked shapes equals T sequential draws (both pinned by tests).  The ~40 ms of
+        single-threaded CPU RNG per 10 s clip then overlap the previous clip's edit loop.  The buffer is consumed by
+        the next `sample_xts_from_x0` call with the same shape / T and ONLY if the global CPU generator is in the state
+        `torch.manual_seed(seed)` leaves it in (so a caller that seeded differently gets the in-line draws)."""
+        import threading
+        shape = (1, *tuple(shape)[-3:])
+        box = {"seed": int(seed), "shape": shape, "T": int(num_inference_steps), "noise": None}
+
+        def work():
+            g = torch.Generator().manual_seed(int(seed))
+            n = torch.randn((int(num_inference_steps), *shape), generator=g, dtype=torch.float32)
+            box["state_after"] = g.get_state()
+            box["noise"] = n.pin_memory() if torch.cuda.is_available() else n
+        box["thread"] = threading.Thread(target=work, daemon=True)
+        box["thread"].start()
+        self._noise_box = box
+
+    def _take_prefetched_noise(self, shape, num_inference_steps):
+        box = getattr(self, "_noise_box", None)
+        if box is None:
+            return None
+        self._noise_box = None
+        box["thread"].join()
+        if box["shape"] != tuple(shape) or box["T"] != int(num_inference_steps):
+            return None
+        # only valid if the caller's global generator sits exactly where manual_seed(seed) puts it
+        ref = torch.Generator().manual_seed(box["seed"])
+        if not torch.equal(torch.get_rng_state(), ref.get_state()):
+            return None
+        torch.set_rng_state(box["state_after"])        # the global generator ends where the in-line draws would leave it
+        return box["noise"]
 
     def get_zs_from_xts(self, xt, xtm1, noise_pred, t, eta: float = 0, numerical_fix: bool = True, **kwargs):
         c = step_coefficients(self.model.scheduler, int(t), eta=eta)

@@ -155,7 +155,7 @@ class Tape:
              dil_h=1, dil_w=1, up=0, lda=None, a_bs=None, res=None, rowvec=None, ld_rv=0, in_act=0, in_slope=0.0,
              out_act=0, out_p=0.0, accumulate=0, out_div=1.0, o_mul=1, o_add=0, o_len=None, out_bs=None,
              ldc=None, ldr=None, ksplit=0, tile=0, ln_rowsum=None, ln_eps=1e-5, x2=None, C1=0, lda2=None, a_bs2=None,
-             geglu=0, name="conv"):
+             geglu=0, w_bs=0, vec_ld=1, vec_bs=0, sm_group=0, sm_scale=1.0, kbias=None, name="conv"):
         """Implicit-GEMM conv (AED_OP_CONV_GEMM).  x: [B,IH,IW,>=Cin] view, w: [N, KH*KW*Cin].
         x2/C1: two-source A -- channels [0,C1) of every tap come from x, [C1,Cin) from x2 (a concat that is never
         materialised).  geglu: w rows are packed [32 value | 32 gate] per 32 features and out[:, f] =
@@ -179,6 +179,11 @@ class Tape:
         auto_tile, auto_split = self.pick_tile(M, N, K, vector_ok=vec_ok, geglu=bool(geglu), lin_ok=lin_ok)
         tile = tile or auto_tile
         ksplit = ksplit or auto_split
+        if w_bs or vec_bs or sm_group or vec_ld != 1:
+            # per-batch weights / grouped softmax (cross-attention as two skinny GEMMs): lin_gemm kernels only
+            assert lin_ok and KH * KW == 1 and (OH * OW) % 64 == 0, "per-batch operands need the lin_gemm path"
+            if tile < 10:
+                tile = 10
         if tile >= 10:
             ksplit = 1
         ln_mode = 0
@@ -192,10 +197,10 @@ class Tape:
             tile = 4
         i = [M, N, K, lda, ldc, ldr or 0, ld_rv, IH, IW, OH, OW, Cin, KH, KW, stride, pad_h, pad_w, dil_h, dil_w, up,
              a_bs, o_mul, o_add, o_len, out_bs, in_act, out_act, accumulate, ksplit, tile, FORCE_BK, ln_mode,
-             C1 if x2 is not None else 0, lda2 or 0, a_bs2 or 0, int(bool(geglu))]
+             C1 if x2 is not None else 0, lda2 or 0, a_bs2 or 0, int(bool(geglu)), sm_group, w_bs, vec_ld, vec_bs]
         n_out = N // 2 if geglu else N
-        idx = self._add(L.OP_CONV_GEMM, i, [in_slope, out_p, out_div, ln_eps],
-                        [x, w, bias, out, res, rowvec, None, None, x2, None], name=name, flops=2 * M * N * K,
+        idx = self._add(L.OP_CONV_GEMM, i, [in_slope, out_p, out_div, ln_eps, sm_scale],
+                        [x, w, bias, out, res, rowvec, None, None, x2, kbias], name=name, flops=2 * M * N * K,
                         nbytes=4 * (B * IH * IW * Cin + N * K + M * n_out), flags=2 if LATE_EPILOGUE else 0)
         if ksplit > 1:
             self._ws_need = max(self._ws_need, ksplit * M * N)

@@ -27,6 +27,7 @@ from .weights import ctx_dims_per_block, _per_block
 FUSE_GEGLU = os.environ.get("AED_FUSE_GEGLU", "1") != "0"
 TWO_SOURCE = os.environ.get("AED_TWO_SOURCE", "1") != "0"
 MERGE_FF2_PROJ = os.environ.get("AED_MERGE_FF2_PROJ", "1") != "0"
+FOLD_XATTN = os.environ.get("AED_FOLD_XATTN", "1") != "0"
 
 
 def geglu_pack_index(dff):
@@ -63,9 +64,29 @@ class PackedUNetWeights:
         self.wd[name + ".rowsum"] = self._dev(wf.float().double().sum(1).float())
         self.wd[name + ".t"] = self._dev(t.float())
 
+    def ensure_folded_cross_attention(self, base, H):
+        """Per-head operands of the folded cross-attention of module `base` (= "...attn2"; see
+        UNetEngine._folded_cross_attention), folded in fp64 on the host, built on first use.  For head h of width D:
+          xq[h]  [C, D]   = (gamma o Wq_h)^T        -> G'[b,(h,j),:] = k_h[b,j] . xq[h]^T  (scores = LN-folded x . G'^T)
+          xs[h]  [2, D]   = (Wq_h gamma, Wq_h beta) -> (sum_c G', G . beta): the two LayerNorm-fold vectors of that GEMM
+          xo[h]  [C, D]   = Wo[:, hD:(h+1)D]        -> VO[b,(h,j),:] = v_h[b,j] . xo[h]^T  (out = P . VO + bo)"""
+        if base + ".xq" in self.wd:
+            return
+        nrm = base.rsplit(".", 1)[0] + ".norm2"
+        wq = self._sd[base + ".to_q.weight"].double()
+        wo = self._sd[base + ".to_out.0.weight"].double()
+        g, bta = self._sd[nrm + ".weight"].double(), self._sd[nrm + ".bias"].double()
+        C = wq.shape[0]
+        D = C // H
+        wqh = wq.reshape(H, D, C)                                        # [h, d, c] = Wq[hD+d, c]
+        self.wd[base + ".xq"] = self._dev((wqh * g[None, None, :]).permute(0, 2, 1).float())       # [H, C, D]
+        self.wd[base + ".xs"] = self._dev(torch.stack([(wqh * g).sum(2), (wqh * bta).sum(2)], 1).float())  # [H, 2, D]
+        self.wd[base + ".xo"] = self._dev(wo.reshape(C, H, D).permute(1, 0, 2).float())           # [H, C, D]
+
     def _pack(self, sd):
         """Re-lay weights: conv [O,I,kh,kw] -> [O, kh*kw*I]; fuse q/k/v; concatenate temb projections."""
         wd = self.wd
+        self._sd = sd
         temb_w, temb_b, self.temb_off = [], [], {}
         off = 0
         for k, v in sd.items():
@@ -141,6 +162,8 @@ class UNetEngine:
         self.two_source = TWO_SOURCE if two_source is None else two_source
         # FF2 and the site's proj_out as one GEMM over [f | t2] with host-folded weights (one dependent launch less)
         self.merge_ff2_proj = MERGE_FF2_PROJ and self.two_source
+        # cross-attention over the (short, per-prompt constant) text keys folded into two skinny GEMMs (latency regime)
+        self.fold_xattn = FOLD_XATTN
         # GroupNorm(+SiLU) inside the conv A-loader is implemented and parity-tested but OFF by default: measured
         # on MI355X it is a wash at U-Net batch 2 (11.53 vs 11.51 ms/forward) and 5 % slower at batch 32
         # (77.8 vs 73.8 ms): the loader's 9x-per-tap SiLU recompute costs more than the saved launch + round trip.
@@ -252,10 +275,54 @@ class UNetEngine:
             self.ctx_tape.linear(ctx.view(B * Lk, cdim), wd[b + ".attn2.kv.weight"], None, kv, M=B * Lk, K=cdim,
                                  N=2 * C, name=b + ".attn2.kv")
             bias = self.bias0 if which == 0 else self.bias1
+            if self._fold_xattn_ok(C, N, heads, Lk, F):
+                return self._folded_cross_attention(p, b, t1, kv, Lk, bias, C, N, heads, x, dest)
             self._attn(b + ".attn2", t1 if F else ln, C, N, heads, o, kv=kv, Lk=Lk, bias=bias, ln=F)
         t2 = self.tmp("t_2", M, C)
         tp.linear(o, wd[b + ".attn2.to_out.0.weight"], wd[b + ".attn2.to_out.0.bias"], t2, M=M, K=C, N=C, res=t1,
                   name=b + ".attn2.to_out")
+        return self._ff_and_out(p, b, t2, ln, C, M, x, dest)
+
+    def _fold_xattn_ok(self, C, N, heads, Lk, F):
+        """Folded cross-attention: latency regime only (lin_gemm kernels), LayerNorm fold on, key count a power of two
+        <= 32 (one softmax group per head inside a 32-column tile), 64-row aligned batch items."""
+        return (self.fold_xattn and F and Lk in (8, 16, 32) and N % 64 == 0 and (heads * Lk) % 32 == 0 and
+                self.B * N <= 4096 and C % 32 == 0)
+
+    def _folded_cross_attention(self, p, b, t1, kv, Lk, kbias, C, N, heads, x, dest):
+        """Cross-attention over a SHORT, per-prompt-constant key set as two skinny GEMMs (exact algebra, no attention
+        launch, ~C/(heads*Lk) x fewer FLOPs than q-projection + to_out):
+            scores[m,(h,j)] = LN(t1)[m] . Wq_h^T k_h[j]      = LN-folded  t1[m] . G'[b]^T
+            t2[m]           = sum_(h,j) softmax_j(scores)[m,(h,j)] . (v_h[j] Wo_h^T) + bo + t1[m]
+        G' = gamma o (k_h Wq_h) and VO = v_h Wo_h^T depend only on the prompt: they are built once per set_conditioning
+        on the context tape (8 small GEMMs per operand, one per head) and indexed per batch item by the lin_gemm kernels."""
+        tp, ct, wd, B = self.tape, self.ctx_tape, self.wd, self.B
+        base = b + ".attn2"
+        self.weights.ensure_folded_cross_attention(base, heads)
+        HL, D, M = heads * Lk, C // heads, B * N
+        G = ct.alloc(B, HL, C)
+        gs = ct.alloc(B, HL, 2)
+        VO = ct.alloc(B, HL, C)
+        VOt = ct.alloc(B, C, HL)
+        for h in range(heads):
+            kh, vh = kv[:, h * D:], kv[:, C + h * D:]
+            sc = dict(B=B, IH=Lk, IW=1, Cin=D, OH=Lk, OW=1, lda=2 * C, a_bs=Lk * 2 * C, o_add=h * Lk, o_len=HL, out_bs=HL)
+            ct.conv(kh, wd[base + ".xq"][h], None, G, N=C, ldc=C, name=base + f".G.h{h}", **sc)
+            ct.conv(kh, wd[base + ".xs"][h], None, gs, N=2, ldc=2, name=base + f".gs.h{h}", **sc)
+            ct.conv(vh, wd[base + ".xo"][h], None, VO, N=C, ldc=C, name=base + f".VO.h{h}", **sc)
+        ct.transpose(VO, VOt, Bt=B, R=HL, C=C, name=base + ".VOt")
+        P = self.tmp("t_p", M, HL)
+        gsf = gs.view(-1)
+        tp.conv(t1, G, gsf[1:], P, B=B, IH=N, IW=1, Cin=C, OH=N, OW=1, N=HL, ln_rowsum=gsf, w_bs=HL * C, vec_ld=2,
+                vec_bs=HL * 2, sm_group=Lk, sm_scale=D ** -0.5, kbias=kbias, name=base + ".scores+softmax")
+        t2 = self.tmp("t_2", M, C)
+        tp.conv(P, VOt, wd[base + ".to_out.0.bias"], t2, B=B, IH=N, IW=1, Cin=HL, OH=N, OW=1, N=C, res=t1, w_bs=C * HL,
+                name=base + ".PV+to_out")
+        return self._ff_and_out(p, b, t2, None, C, M, x, dest)
+
+    def _ff_and_out(self, p, b, t2, ln, C, M, x, dest):
+        tp, wd = self.tape, self.wd
+        F = self.fuse_ln
         if not F:
             tp.layernorm(t2, wd[b + ".norm3.weight"], wd[b + ".norm3.bias"], ln, M=M, C=C, name=b + ".norm3")
         f = self.tmp("t_f", M, 4 * C)

@@ -277,6 +277,11 @@ def main():
         adist.barrier()
         t0 = time.perf_counter()
         for i in range(K):
+            # the x_t noise of clip i+1 (40 ms of single-threaded CPU RNG) is drawn on a host thread while clip i runs on
+            # the GPU -- same generator, seed and draw order (PipelineWrapper.prefetch_noise); clip 0 draws in line, so
+            # all K draws happen inside the timed region
+            if NC == 1 and hasattr(m, "prefetch_noise"):
+                m.next_noise_seed = 2000 + i + 1 if i + 1 < K else None
             lat.append(step(2000 + i, waves[i]))
         local_lat = torch.cat(lat, 0)
         gathered = adist.gather_to_rank0(local_lat)

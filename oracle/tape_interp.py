@@ -85,10 +85,32 @@ def conv_gemm(op):
         rstd = 1.0 / torch.sqrt(var + ln_eps)
     if in_act:
         A = _act(A, in_act, in_slope)
-    W = _f32(p[1], N * K).reshape(N, K)
-    acc = A.double() @ W.double().T                                             # independent of the MFMA k-order
-    bias = _f32(p[2], N)
-    if ln_mode:
+    sm_group, w_bs, vec_ld, vec_bs = int(i[36]), int(i[37]), max(1, int(i[38])), int(i[39])
+    batched = bool(w_bs or vec_bs or vec_ld != 1 or sm_group)
+    if batched:
+        # per-batch-item weights / vectors and the grouped softmax epilogue (cross-attention as two skinny GEMMs)
+        Wb = _f32(p[1], (nb - 1) * w_bs + N * K).as_strided((nb, N, K), (w_bs, K, 1)).double()
+        acc = torch.einsum("mk,mnk->mn", A.double(), Wb[b])
+        vec = lambda ptr: None if not ptr else _f32(ptr, (nb - 1) * vec_bs + (N - 1) * vec_ld + 1).as_strided(  # noqa: E731
+            (nb, N), (vec_bs, vec_ld)).double()[b]
+        bias_m, sn_m = vec(p[2]), vec(p[5])
+        if ln_mode:
+            val = rstd.double()[:, None] * (acc - mean.double()[:, None] * sn_m) + bias_m
+        else:
+            val = acc if bias_m is None else acc + bias_m
+        if sm_group:
+            val = val * float(f[4])
+            if p[9]:
+                kb = _f32(p[9], nb * sm_group).reshape(nb, sm_group).double()
+                val = val + kb[b].repeat(1, N // sm_group)
+            val = torch.softmax(val.reshape(M, N // sm_group, sm_group), -1).reshape(M, N)
+    else:
+        W = _f32(p[1], N * K).reshape(N, K)
+        acc = A.double() @ W.double().T                                         # independent of the MFMA k-order
+        bias = _f32(p[2], N)
+    if batched:
+        pass
+    elif ln_mode:
         sn = _f32(p[5], N)
         val = rstd.double()[:, None] * (acc - mean.double()[:, None] * sn.double()[None, :]) + bias.double()[None, :]
     else:

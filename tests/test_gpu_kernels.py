@@ -389,3 +389,38 @@ def test_groupnorm_two_source(C1, C2, HW, B, variant):
                  variant=variant)
     run(tp)
     assert (out.cpu() - ref).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("tile", [10, 11, 13, 15])
+@pytest.mark.parametrize("Lk", [8, 16])
+def test_lin_gemm_per_batch_weights_and_grouped_softmax(tile, Lk):
+    """The two skinny GEMMs of the folded cross-attention: (1) LayerNorm-folded scores with per-batch-item weights and
+    interleaved (rowsum, bias) vectors + per-head softmax over Lk columns with a key mask; (2) P . VO^T + bias +
+    residual with per-batch-item weights."""
+    B, N, C, H = 3, 128, 96, 4
+    HL, M = H * Lk, B * N
+    x = rnd(M, C, seed=1) * 1.5 + 0.2
+    ga, be = 1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3)
+    G = rnd(B, HL, C, seed=4, scale=0.2)                       # per batch item: k_h . Wq_h
+    kb = torch.zeros(B, Lk)
+    kb[1, Lk // 2:] = -10000.0
+    kb[2, -1] = -1.0e30
+    Gp = G * ga                                                # gamma folded
+    gs = torch.stack([Gp.double().sum(-1).float(), (G.double() @ be.double()).float()], -1).contiguous()   # [B, HL, 2]
+    tp = Tape(DEV)
+    P = tp.alloc(M, HL)
+    gsd = gs.to(DEV).view(-1)
+    tp.conv(x.to(DEV), Gp.contiguous().to(DEV), gsd[1:], P, B=B, IH=N, IW=1, Cin=C, OH=N, OW=1, N=HL, ln_rowsum=gsd,
+            w_bs=HL * C, vec_ld=2, vec_bs=HL * 2, sm_group=Lk, sm_scale=0.25, kbias=kb.to(DEV), tile=tile)
+    VOt = rnd(B, C, HL, seed=5, scale=0.3)
+    bo, res = rnd(C, seed=6), rnd(M, C, seed=7)
+    out = tp.alloc(M, C)
+    tp.conv(P, VOt.to(DEV), bo.to(DEV), out, B=B, IH=N, IW=1, Cin=HL, OH=N, OW=1, N=C, res=res.to(DEV), w_bs=C * HL,
+            tile=tile)
+    run(tp)
+    xn = F.layer_norm(x, (C,), ga, be).view(B, N, C)
+    sc = torch.einsum("bnc,bkc->bnk", xn, G) * 0.25 + kb.repeat(1, H)[:, None, :]
+    Pr = torch.softmax(sc.view(B, N, H, Lk), -1).view(B, N, HL)
+    assert (P.cpu().view(B, N, HL) - Pr).abs().max() < 2e-5
+    ref = torch.einsum("bnk,bck->bnc", Pr, VOt) + bo + res.view(B, N, C)
+    assert (out.cpu().view(B, N, C) - ref).abs().max() < 5e-5

@@ -11,8 +11,10 @@ from oracle import unet as ounet                                # noqa: E402
 DEV = "cuda:0"
 
 
-def _run_case(fam, B, H, W, L0, L1, t, seed=0, use_ehs=True):
+def _run_case(fam, B, H, W, L0, L1, t, seed=0, use_ehs=True, heads=None, want_folded=0):
     cfg = fam["unet"]
+    if heads is not None:
+        cfg["attention_head_dim"] = heads
     sd = weights.random_state_dict(weights.unet_param_shapes(cfg), seed=seed)
     g = torch.Generator().manual_seed(seed + 1)
     x = torch.randn(B, cfg["in_channels"], H, W, generator=g)
@@ -40,6 +42,7 @@ def _run_case(fam, B, H, W, L0, L1, t, seed=0, use_ehs=True):
     eng.set_timestep(t)
     eng.forward()
     torch.cuda.synchronize()
+    assert sum(1 for o in eng.tape.ops if o.code == 1 and o.i[36] > 0) >= want_folded
     got = eng.eps.cpu().permute(0, 3, 1, 2)
     hs = eng.h_space.cpu().permute(0, 3, 1, 2)
     ref, ref_h, _ = ounet.unet_forward(cfg, sd, x, torch.tensor(t), **okw)
@@ -83,3 +86,13 @@ def test_full_audioldm_s_unet_matches_oracle():
     assert ((hs - ref_h).norm() / ref_h.norm()).item() < 1e-4
     n_params = sum(v.numel() for v in weights.random_state_dict(weights.unet_param_shapes(fam["unet"]), seed=0).values())
     assert abs(n_params / 1e6 - 185.0) < 1.0, n_params                      # in-tree twin: 185.0 M
+
+
+@pytest.mark.parametrize("kind,L0,L1", [("audioldm2", 8, 16), ("tango", 16, 0)])
+def test_folded_cross_attention_unet_matches_oracle(kind, L0, L1):
+    """the folded cross-attention (two skinny GEMMs with per-batch weights and a grouped softmax, lin_gemm kernels) inside
+    a whole tiny U-Net against the oracle's q-proj -> softmax(QK^T)V -> to_out, ragged key masks included"""
+    fam = configs.tiny_family(kind)
+    got, ref, hs, ref_h, _ = _run_case(fam, B=2, H=32, W=16, L0=L0, L1=L1, t=401, heads=4, want_folded=4)
+    assert (hs - ref_h).abs().max().item() < 2e-4 * max(1.0, ref_h.abs().max().item())
+    assert (got - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item())

@@ -18,9 +18,11 @@ def _cpu_executor(monkeypatch):
     monkeypatch.setattr(Tape, "run", tape_interp.run_tape)
 
 
-def _unet_case(kind, B=2, H=16, W=16, L0=6, L1=5, t=501, seed=0, use_ehs=True):
+def _unet_case(kind, B=2, H=16, W=16, L0=6, L1=5, t=501, seed=0, use_ehs=True, heads=None, want_folded=0):
     fam = configs.tiny_family(kind)
     cfg = fam["unet"]
+    if heads is not None:
+        cfg["attention_head_dim"] = heads
     sd = weights.random_state_dict(weights.unet_param_shapes(cfg), seed=seed)
     g = torch.Generator().manual_seed(seed + 1)
     x = torch.randn(B, cfg["in_channels"], H, W, generator=g)
@@ -46,6 +48,8 @@ def _unet_case(kind, B=2, H=16, W=16, L0=6, L1=5, t=501, seed=0, use_ehs=True):
     eng.x_in.copy_(x.permute(0, 2, 3, 1))
     eng.set_timestep(t)
     eng.forward()
+    n_fold = sum(1 for o in eng.tape.ops if o.code == 1 and o.i[36] > 0)
+    assert n_fold >= want_folded, (n_fold, want_folded)
     ref, ref_h, _ = ounet.unet_forward(cfg, sd, x, torch.tensor(t), **okw)
     return eng.eps.permute(0, 3, 1, 2), ref, eng.h_space.permute(0, 3, 1, 2), ref_h
 
@@ -53,6 +57,16 @@ def _unet_case(kind, B=2, H=16, W=16, L0=6, L1=5, t=501, seed=0, use_ehs=True):
 @pytest.mark.parametrize("kind,use_ehs", [("audioldm2", True), ("audioldm", False), ("tango", True)])
 def test_unet_tape_wiring_matches_oracle(kind, use_ehs):
     got, ref, hs, ref_h = _unet_case(kind, use_ehs=use_ehs)
+    assert (hs - ref_h).abs().max().item() < 1e-4 * max(1.0, ref_h.abs().max().item())
+    assert (got - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("kind,L0,L1", [("audioldm2", 8, 16), ("tango", 16, 0)])
+def test_folded_cross_attention_matches_oracle(kind, L0, L1):
+    """Cross-attention over the short, per-prompt-constant text keys as two skinny GEMMs (scores + grouped softmax,
+    then P.VO + bias + residual) with per-head operands built on the context tape: exact algebra, so the U-Net output
+    still matches the oracle's q-projection -> softmax(QK^T) V -> to_out; ragged key masks included."""
+    got, ref, hs, ref_h = _unet_case(kind, H=32, W=16, L0=L0, L1=L1, heads=4, want_folded=4)
     assert (hs - ref_h).abs().max().item() < 1e-4 * max(1.0, ref_h.abs().max().item())
     assert (got - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
 

@@ -247,3 +247,31 @@ def test_product_tape_executor_fails_loudly_without_gpu():
     tp.axpby(x, y, numel=32, a=2.0, b=0.0)
     with pytest.raises(Exception):
         tp.run()
+
+
+def test_prefetched_noise_equals_inline_draws(cpu_stack):
+    """PipelineWrapper.prefetch_noise: the x_t noise drawn ahead on a host thread is bit-identical to the in-line draws
+    (same generator algorithm / seed / order), the global generator ends in the same state, and a caller that seeded
+    differently silently gets the in-line path."""
+    T = 6
+    m = _model(T)
+    w0 = torch.randn(1, 8, 16, 16, generator=torch.Generator().manual_seed(2)) * 0.5
+    torch.manual_seed(31)
+    ref = m.sample_xts_from_x0(w0, T)
+    after = torch.randn(3)
+    m.prefetch_noise(31, w0.shape, T)
+    torch.manual_seed(31)
+    got = m.sample_xts_from_x0(w0, T)
+    assert torch.equal(got, ref) and torch.equal(torch.randn(3), after)
+    m.prefetch_noise(31, w0.shape, T)
+    torch.manual_seed(32)                                   # other seed: the prefetched buffer must not be used
+    other = m.sample_xts_from_x0(w0, T)
+    assert not torch.equal(other, ref)
+    torch.manual_seed(32)
+    assert torch.equal(other, m.sample_xts_from_x0(w0, T))
+    m.next_noise_seed = 31                                  # announced seed -> drawn under the current clip
+    torch.manual_seed(5)
+    m.sample_xts_from_x0(w0, T)
+    assert m._noise_box["seed"] == 31
+    torch.manual_seed(31)
+    assert torch.equal(m.sample_xts_from_x0(w0, T), ref)

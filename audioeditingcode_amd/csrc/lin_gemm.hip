@@ -385,7 +385,7 @@ __global__ __launch_bounds__(64 * NW) void lin_gemm_kernel(CGParams p) {
                     const float e = __expf(val - mx);
                     float sum = e;
                     for (int o = p.sm_group >> 1; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-                    p.C[(size_t)mo * p.ldc + no] = e / sum;
+                    if (no < p.N) p.C[(size_t)mo * p.ldc + no] = e / sum;      // (a 64-wide tile may overhang N = 32)
                 }
             } else if (simple) {
 #pragma unroll

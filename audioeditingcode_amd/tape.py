@@ -83,6 +83,8 @@ class Tape:
             if torch.is_tensor(v):
                 self.keep.append(v)         # the record holds a raw pointer: keep the storage alive
         self.ops.append(op)
+        # `flops` is ALGORITHMIC work (what the reference's formulation of the op costs: SURVEY 8d); ops that execute
+        # fewer (the folded cross-attention) pass it explicitly, the executed count is kept beside it
         self.meta.append(dict(name=name or L.OP_NAMES[code], code=code, flops=flops, bytes=nbytes))
         self._arr = None
         return len(self.ops) - 1
@@ -155,7 +157,7 @@ class Tape:
              dil_h=1, dil_w=1, up=0, lda=None, a_bs=None, res=None, rowvec=None, ld_rv=0, in_act=0, in_slope=0.0,
              out_act=0, out_p=0.0, accumulate=0, out_div=1.0, o_mul=1, o_add=0, o_len=None, out_bs=None,
              ldc=None, ldr=None, ksplit=0, tile=0, ln_rowsum=None, ln_eps=1e-5, x2=None, C1=0, lda2=None, a_bs2=None,
-             geglu=0, w_bs=0, vec_ld=1, vec_bs=0, sm_group=0, sm_scale=1.0, kbias=None, name="conv"):
+             geglu=0, w_bs=0, vec_ld=1, vec_bs=0, sm_group=0, sm_scale=1.0, kbias=None, alg_flops=None, name="conv"):
         """Implicit-GEMM conv (AED_OP_CONV_GEMM).  x: [B,IH,IW,>=Cin] view, w: [N, KH*KW*Cin].
         x2/C1: two-source A -- channels [0,C1) of every tap come from x, [C1,Cin) from x2 (a concat that is never
         materialised).  geglu: w rows are packed [32 value | 32 gate] per 32 features and out[:, f] =
@@ -200,7 +202,8 @@ class Tape:
              C1 if x2 is not None else 0, lda2 or 0, a_bs2 or 0, int(bool(geglu)), sm_group, w_bs, vec_ld, vec_bs]
         n_out = N // 2 if geglu else N
         idx = self._add(L.OP_CONV_GEMM, i, [in_slope, out_p, out_div, ln_eps, sm_scale],
-                        [x, w, bias, out, res, rowvec, None, None, x2, kbias], name=name, flops=2 * M * N * K,
+                        [x, w, bias, out, res, rowvec, None, None, x2, kbias], name=name,
+                        flops=2 * M * N * K if alg_flops is None else alg_flops,
                         nbytes=4 * (B * IH * IW * Cin + N * K + M * n_out), flags=2 if LATE_EPILOGUE else 0)
         if ksplit > 1:
             self._ws_need = max(self._ws_need, ksplit * M * N)

@@ -314,10 +314,11 @@ class UNetEngine:
         P = self.tmp("t_p", M, HL)
         gsf = gs.view(-1)
         tp.conv(t1, G, gsf[1:], P, B=B, IH=N, IW=1, Cin=C, OH=N, OW=1, N=HL, ln_rowsum=gsf, w_bs=HL * C, vec_ld=2,
-                vec_bs=HL * 2, sm_group=Lk, sm_scale=D ** -0.5, kbias=kbias, name=base + ".scores+softmax")
+                vec_bs=HL * 2, sm_group=Lk, sm_scale=D ** -0.5, kbias=kbias, name=base + ".scores+softmax",
+                alg_flops=2 * M * C * C + 4 * M * Lk * C)       # what it replaces: q projection + QK^T + PV
         t2 = self.tmp("t_2", M, C)
         tp.conv(P, VOt, wd[base + ".to_out.0.bias"], t2, B=B, IH=N, IW=1, Cin=HL, OH=N, OW=1, N=C, res=t1, w_bs=C * HL,
-                name=base + ".PV+to_out")
+                name=base + ".PV+to_out", alg_flops=2 * M * C * C)                  # what it replaces: to_out
         return self._ff_and_out(p, b, t2, None, C, M, x, dest)
 
     def _ff_and_out(self, p, b, t2, ln, C, M, x, dest):

@@ -19,10 +19,11 @@ class aed_op(ctypes.Structure):
 OP_NOP, OP_CONV_GEMM, OP_GN_STATS, OP_GN_APPLY, OP_LAYERNORM, OP_ATTENTION, OP_GEGLU, OP_COPY2D, \
     OP_TIME_EMBED, OP_SOFTMAX_ROWS, OP_TRANSPOSE, OP_AXPBY, OP_INVERT_STEP, OP_REVERSE_STEP, OP_DDIM_STEP, \
     OP_ADVANCE, OP_REFLECT_PAD, OP_MAGNITUDE, OP_NCHW_TO_NHWC, OP_NHWC_TO_NCHW, OP_SPLITK_REDUCE, \
-    OP_GN_SCALE_SHIFT, OP_GN_SMALL = range(23)
+    OP_GN_SCALE_SHIFT, OP_GN_SMALL, OP_XATTN_FOLD = range(24)
 OP_NAMES = ["nop", "conv_gemm", "gn_stats", "gn_apply", "layernorm", "attention", "geglu", "copy2d", "time_embed",
             "softmax_rows", "transpose", "axpby", "invert_step", "reverse_step", "ddim_step", "advance",
-            "reflect_pad", "magnitude", "nchw_to_nhwc", "nhwc_to_nchw", "splitk_reduce", "gn_scale_shift", "gn_small"]
+            "reflect_pad", "magnitude", "nchw_to_nhwc", "nhwc_to_nchw", "splitk_reduce", "gn_scale_shift", "gn_small",
+            "xattn_fold"]
 ACT_NONE, ACT_SILU, ACT_LEAKY, ACT_TANH, ACT_LOGCLAMP = range(5)
 COEF_STRIDE = 8
 

@@ -48,6 +48,7 @@ int launch_advance(const aed_op* op, hipStream_t s);
 int launch_reflect_pad(const aed_op* op, hipStream_t s);
 int launch_magnitude(const aed_op* op, hipStream_t s);
 int launch_layout(const aed_op* op, hipStream_t s);
+int launch_xattn_fold(const aed_op* op, hipStream_t s);
 
 int aed_num_cus();
 

@@ -415,3 +415,58 @@ int launch_magnitude(const aed_op* op, hipStream_t s) {
     AED_CHECK_HIP(hipGetLastError());
     return 0;
 }
+
+// ------------------------------------------------------------------------------------ folded cross-attention operands
+// Once per prompt set (context tape), per transformer block with text cross-attention (unet.py
+// UNetEngine._folded_cross_attention; reference math: attention over encoder_hidden_states, models.py:806-894):
+//   G  [b, h*Lk+j, c]  = sum_d k[b,j,hD+d] * xq[h][c][d]     xq = (gamma o Wq_h)^T       (scores = LN-folded x . G^T)
+//   gs [b, h*Lk+j, 0/1] = sum_d k[b,j,hD+d] * xs[h][0/1][d]   xs = (Wq_h gamma, Wq_h beta) (the LayerNorm-fold vectors)
+//   VOt[b, c, h*Lk+j]  = sum_d v[b,j,hD+d] * xo[h][c][d]     xo = Wo[:, hD:(h+1)D]        (out = P . VO + bo)
+// One thread per (b, hj, c); D-long dot products, a few MFLOP in total -- launch count, not arithmetic, is the cost.
+__global__ __launch_bounds__(256) void xattn_fold_kernel(const float* __restrict__ kv, const float* __restrict__ xq,
+                                                          const float* __restrict__ xs, const float* __restrict__ xo,
+                                                          float* __restrict__ G, float* __restrict__ gs,
+                                                          float* __restrict__ VOt, int B, int Lk, int H, int C, int D,
+                                                          int ldkv) {
+    const int HL = H * Lk;
+    const size_t total = (size_t)B * HL * C;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int c = (int)(idx % C);
+        const int hj = (int)((idx / C) % HL);
+        const int b = (int)(idx / ((size_t)C * HL));
+        const int h = hj / Lk, j = hj - h * Lk;
+        const float* k = kv + (size_t)(b * Lk + j) * ldkv + h * D;
+        const float* v = k + C;
+        const float* wq = xq + ((size_t)h * C + c) * D;
+        const float* wo = xo + ((size_t)h * C + c) * D;
+        float g = 0.f, o = 0.f;
+        for (int d = 0; d < D; d += 4) {
+            const float4 k4 = *reinterpret_cast<const float4*>(k + d), v4 = *reinterpret_cast<const float4*>(v + d);
+            const float4 q4 = *reinterpret_cast<const float4*>(wq + d), o4 = *reinterpret_cast<const float4*>(wo + d);
+            g += k4.x * q4.x + k4.y * q4.y + k4.z * q4.z + k4.w * q4.w;
+            o += v4.x * o4.x + v4.y * o4.y + v4.z * o4.z + v4.w * o4.w;
+        }
+        G[idx] = g;
+        VOt[((size_t)b * C + c) * HL + hj] = o;
+        if (c < 2) {
+            const float* ws = xs + ((size_t)h * 2 + c) * D;
+            float s_ = 0.f;
+            for (int d = 0; d < D; ++d) s_ += k[d] * ws[d];
+            gs[((size_t)b * HL + hj) * 2 + c] = s_;
+        }
+    }
+}
+// slots: p0=kv [B*Lk, ldkv] (k | v halves of width C) p1=xq [H,C,D] p2=xs [H,2,D] p3=xo [H,C,D] p4=G [B,H*Lk,C]
+//        p5=gs [B,H*Lk,2] p6=VOt [B,C,H*Lk] ; i0=B i1=Lk i2=H i3=C i4=D i5=ldkv
+int launch_xattn_fold(const aed_op* op, hipStream_t s) {
+    const int32_t* i = op->i;
+    for (int k = 0; k < 7; ++k) AED_REQUIRE(op->p[k] != nullptr, "xattn_fold: null pointer (slot %d)", k);
+    AED_REQUIRE(i[3] == i[2] * i[4] && i[4] % 4 == 0 && i[5] % 4 == 0 && i[5] >= 2 * i[3],
+                "xattn_fold: C=%d must be H*D (H=%d, D=%d multiple of 4), ldkv=%d >= 2C", i[3], i[2], i[4], i[5]);
+    const size_t total = (size_t)i[0] * i[2] * i[1] * i[3];
+    hipLaunchKernelGGL(xattn_fold_kernel, dim3(grid_for(total)), dim3(256), 0, s, (const float*)op->p[0],
+                       (const float*)op->p[1], (const float*)op->p[2], (const float*)op->p[3], (float*)op->p[4],
+                       (float*)op->p[5], (float*)op->p[6], i[0], i[1], i[2], i[3], i[4], i[5]);
+    AED_CHECK_HIP(hipGetLastError());
+    return 0;
+}

@@ -266,6 +266,11 @@ class Tape:
                   nbytes=4 * B * H * D * (2 * Nq + 2 * Nk))
         return out
 
+    def xattn_fold(self, kv, xq, xs, xo, G, gs, VOt, *, B, Lk, H, C, D, name="xattn_fold"):
+        """Per-prompt operands of the folded cross-attention (AED_OP_XATTN_FOLD; see elementwise.hip)."""
+        self._add(L.OP_XATTN_FOLD, [B, Lk, H, C, D, kv.stride(-2)], [], [kv, xq, xs, xo, G, gs, VOt], name=name,
+                  flops=0, nbytes=4 * (2 * B * H * Lk * C))
+
     def geglu(self, h, out, *, M, Dff, name="geglu"):
         self._add(L.OP_GEGLU, [M, Dff, h.stride(-2), out.stride(-2)], [], [h, out], name=name, nbytes=12 * M * Dff)
         return out

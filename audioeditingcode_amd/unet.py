@@ -295,22 +295,16 @@ class UNetEngine:
             scores[m,(h,j)] = LN(t1)[m] . Wq_h^T k_h[j]      = LN-folded  t1[m] . G'[b]^T
             t2[m]           = sum_(h,j) softmax_j(scores)[m,(h,j)] . (v_h[j] Wo_h^T) + bo + t1[m]
         G' = gamma o (k_h Wq_h) and VO = v_h Wo_h^T depend only on the prompt: they are built once per set_conditioning
-        on the context tape (8 small GEMMs per operand, one per head) and indexed per batch item by the lin_gemm kernels."""
+        on the context tape (one small launch per block, AED_OP_XATTN_FOLD) and indexed per batch item by the lin_gemm kernels."""
         tp, ct, wd, B = self.tape, self.ctx_tape, self.wd, self.B
         base = b + ".attn2"
         self.weights.ensure_folded_cross_attention(base, heads)
         HL, D, M = heads * Lk, C // heads, B * N
         G = ct.alloc(B, HL, C)
         gs = ct.alloc(B, HL, 2)
-        VO = ct.alloc(B, HL, C)
         VOt = ct.alloc(B, C, HL)
-        for h in range(heads):
-            kh, vh = kv[:, h * D:], kv[:, C + h * D:]
-            sc = dict(B=B, IH=Lk, IW=1, Cin=D, OH=Lk, OW=1, lda=2 * C, a_bs=Lk * 2 * C, o_add=h * Lk, o_len=HL, out_bs=HL)
-            ct.conv(kh, wd[base + ".xq"][h], None, G, N=C, ldc=C, name=base + f".G.h{h}", **sc)
-            ct.conv(kh, wd[base + ".xs"][h], None, gs, N=2, ldc=2, name=base + f".gs.h{h}", **sc)
-            ct.conv(vh, wd[base + ".xo"][h], None, VO, N=C, ldc=C, name=base + f".VO.h{h}", **sc)
-        ct.transpose(VO, VOt, Bt=B, R=HL, C=C, name=base + ".VOt")
+        ct.xattn_fold(kv, wd[base + ".xq"], wd[base + ".xs"], wd[base + ".xo"], G, gs, VOt, B=B, Lk=Lk, H=heads, C=C, D=D,
+                      name=base + ".fold")
         P = self.tmp("t_p", M, HL)
         gsf = gs.view(-1)
         tp.conv(t1, G, gsf[1:], P, B=B, IH=N, IW=1, Cin=C, OH=N, OW=1, N=HL, ln_rowsum=gsf, w_bs=HL * C, vec_ld=2,

@@ -60,6 +60,8 @@ enum aed_opcode {
     AED_OP_SPLITK_REDUCE = 20,
     AED_OP_GN_SCALE_SHIFT = 21, /* GroupNorm stats -> per-(batch,channel) scale/shift vectors [B,2,C]         */
     AED_OP_GN_SMALL = 22,     /* single-launch GroupNorm(+SiLU) for small feature maps (K4)       */
+    AED_OP_XATTN_FOLD = 23,   /* per-prompt operands of the folded cross-attention: G' = k_h.(gamma o Wq_h), its two
+                                 LayerNorm-fold vectors, VO^T = (v_h.Wo_h^T)^T -- once per prompt, not per step      */
     AED_OP_COUNT
 };
 

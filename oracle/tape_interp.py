@@ -363,6 +363,19 @@ def magnitude(op):
     mag[:, :cut] = torch.sqrt(ft[:, :cut] ** 2 + ft[:, cut:] ** 2)
 
 
+def xattn_fold(op):
+    B, Lk, H, C, D, ldkv = [int(op.i[k]) for k in range(6)]
+    HL = H * Lk
+    kv = _f32(op.p[0], (B * Lk - 1) * ldkv + 2 * C).as_strided((B, Lk, 2 * C), (Lk * ldkv, ldkv, 1)).double()
+    k, v = kv[..., :C].reshape(B, Lk, H, D), kv[..., C:].reshape(B, Lk, H, D)
+    xq = _f32(op.p[1], H * C * D).reshape(H, C, D).double()
+    xs = _f32(op.p[2], H * 2 * D).reshape(H, 2, D).double()
+    xo = _f32(op.p[3], H * C * D).reshape(H, C, D).double()
+    _f32(op.p[4], B * HL * C).reshape(B, H, Lk, C).copy_(torch.einsum("bjhd,hcd->bhjc", k, xq).float())
+    _f32(op.p[5], B * HL * 2).reshape(B, H, Lk, 2).copy_(torch.einsum("bjhd,hsd->bhjs", k, xs).float())
+    _f32(op.p[6], B * C * HL).reshape(B, C, H, Lk).copy_(torch.einsum("bjhd,hcd->bchj", v, xo).float())
+
+
 def nop(op):
     return
 
@@ -370,7 +383,7 @@ def nop(op):
 DISPATCH = {0: nop, 1: conv_gemm, 2: gn_stats, 3: gn_apply, 4: layernorm, 5: attention, 6: geglu, 7: copy2d,
             8: time_embed, 9: softmax_rows, 10: transpose, 11: axpby, 12: invert_step, 13: reverse_step,
             14: reverse_step, 15: advance, 16: reflect_pad, 17: magnitude, 18: transpose, 19: transpose, 20: nop,
-            21: gn_scale_shift, 22: gn_small}
+            21: gn_scale_shift, 22: gn_small, 23: xattn_fold}
 
 
 def run_tape(tape, start=0, end=None):

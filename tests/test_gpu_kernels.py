@@ -424,3 +424,21 @@ def test_lin_gemm_per_batch_weights_and_grouped_softmax(tile, Lk):
     assert (P.cpu().view(B, N, HL) - Pr).abs().max() < 2e-5
     ref = torch.einsum("bnk,bck->bnc", Pr, VOt) + bo + res.view(B, N, C)
     assert (out.cpu().view(B, N, C) - ref).abs().max() < 5e-5
+
+
+@pytest.mark.parametrize("B,Lk,H,D", [(2, 8, 8, 80), (3, 16, 4, 48), (2, 32, 2, 16)])
+def test_xattn_fold_operands(B, Lk, H, D):
+    """per-prompt operands of the folded cross-attention vs einsum"""
+    C, HL = H * D, H * Lk
+    kv = rnd(B * Lk, 2 * C + 8, seed=1)
+    xq, xs, xo = rnd(H, C, D, seed=2, scale=0.2), rnd(H, 2, D, seed=3, scale=0.2), rnd(H, C, D, seed=4, scale=0.2)
+    tp = Tape(DEV)
+    G, gs, VOt = tp.alloc(B, HL, C), tp.alloc(B, HL, 2), tp.alloc(B, C, HL)
+    kvd = kv.to(DEV)
+    tp.xattn_fold(kvd[:, :2 * C], xq.to(DEV), xs.to(DEV), xo.to(DEV), G, gs, VOt, B=B, Lk=Lk, H=H, C=C, D=D)
+    run(tp)
+    k = kv[:, :C].reshape(B, Lk, H, D)
+    v = kv[:, C:2 * C].reshape(B, Lk, H, D)
+    assert (G.cpu().view(B, H, Lk, C) - torch.einsum("bjhd,hcd->bhjc", k, xq)).abs().max() < 2e-5
+    assert (gs.cpu().view(B, H, Lk, 2) - torch.einsum("bjhd,hsd->bhjs", k, xs)).abs().max() < 2e-5
+    assert (VOt.cpu().view(B, C, H, Lk) - torch.einsum("bjhd,hcd->bchj", v, xo)).abs().max() < 2e-5

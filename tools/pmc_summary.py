@@ -50,7 +50,7 @@ order = sorted(agg, key=lambda k: -(g(k, "FETCH_SIZE") + g(k, "SQ_BUSY_CYCLES"))
 tot_f = tot_w = 0.0
 n_gemm = 0
 for k in order:
-    n = max(cnt[k].values())
+    n = cnt[k].get("FETCH_SIZE") or min(cnt[k].values())      # a counter present in two passes must not double the count
     f = g(k, "FETCH_SIZE") * 2 * 1024 / 1e6
     w = g(k, "WRITE_SIZE") * 1024 / 1e6
     mb = g(k, "SQ_VALU_MFMA_BUSY_CYCLES")
@@ -72,11 +72,14 @@ if n_gemm:
 if out_json:
     h = hashlib.sha1()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for f_ in sorted(glob.glob(os.path.join(root, "audioeditingcode_amd", "csrc", "*.h*"))):
-        h.update(open(f_, "rb").read())
-    alg = float(sys.argv[sys.argv.index("--alg-bytes") + 1]) if "--alg-bytes" in sys.argv else None
+    for f_ in ("conv_gemm.hip", "lin_gemm.hip", "cg_params.h", "aed_common.h"):     # same file set as bench.csrc_hash()
+        h.update(open(os.path.join(root, "audioeditingcode_amd", "csrc", f_), "rb").read())
+    # --alg-total-bytes: the sum tools/pmc_forward.py prints ("algorithmic bytes", all forwards of the profiled command);
+    # measured and algorithmic are divided by the SAME launch count so their ratio is the ratio of the totals
+    alg_tot = float(sys.argv[sys.argv.index("--alg-total-bytes") + 1]) if "--alg-total-bytes" in sys.argv else None
     json.dump(dict(csrc_hash=h.hexdigest()[:12], counters="rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, "
                    "separate passes", measured_bytes_per_launch=1e6 * (tot_f + tot_w) / max(1, n_gemm),
-                   algorithmic_bytes_per_launch=alg, launches=n_gemm,
+                   algorithmic_bytes_per_launch=(alg_tot / max(1, n_gemm) if alg_tot else None),
+                   measured_over_algorithmic=(1e6 * (tot_f + tot_w) / alg_tot if alg_tot else None), launches=n_gemm,
                    source=f"tools/pmc_forward.py via tools/pmc_summary.py ({os.path.basename(d.rstrip('/'))})"),
               open(out_json, "w"), indent=1)

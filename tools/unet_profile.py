@@ -22,7 +22,7 @@ sd = weights.random_state_dict(weights.unet_param_shapes(fam["unet"]), seed=0)
 packed = PackedUNetWeights(sd, "cuda:0")
 DEFAULTS = dict(lin=tape_mod.LIN_MODE, geglu=int(unet_mod.FUSE_GEGLU), two=int(unet_mod.TWO_SOURCE),
                 attn=tape_mod.ATTN_VARIANT, gn=tape_mod.GN_FORCE_SMALL, late=tape_mod.LATE_EPILOGUE,
-                merge=int(unet_mod.MERGE_FF2_PROJ), fold=int(unet_mod.FOLD_XATTN))
+                merge=int(unet_mod.MERGE_FF2_PROJ), fold=int(unet_mod.FOLD_XATTN), gnreg=1 - tape_mod.GN_VARIANT)
 st = torch.cuda.Stream()
 os.makedirs("gpurun_out", exist_ok=True)
 for spec in variants:
@@ -30,7 +30,8 @@ for spec in variants:
     v.update({k: int(x) for k, x in (kv.split("=") for kv in spec.split(",") if kv)})
     tape_mod.LIN_MODE, tape_mod.ATTN_VARIANT, tape_mod.GN_FORCE_SMALL = v["lin"], v["attn"], v["gn"]
     tape_mod.LATE_EPILOGUE, unet_mod.MERGE_FF2_PROJ, unet_mod.FOLD_XATTN = v["late"], bool(v["merge"]), bool(v["fold"])
-    tag = "_".join(f"{k}{v[k]}" for k in ("lin", "geglu", "two", "late", "merge", "attn", "gn", "fold"))
+    tape_mod.GN_VARIANT = 1 - v["gnreg"]
+    tag = "_".join(f"{k}{v[k]}" for k in ("lin", "geglu", "two", "late", "merge", "attn", "gn", "fold", "gnreg"))
     eng = UNetEngine(fam["unet"], packed, "cuda:0", B, 256, 16, ctx_len0=8, ctx_len1=16, fuse_geglu=bool(v["geglu"]),
                      two_source=bool(v["two"]))
     g = torch.Generator().manual_seed(1)

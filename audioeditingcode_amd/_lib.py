@@ -19,13 +19,14 @@ class aed_op(ctypes.Structure):
 OP_NOP, OP_CONV_GEMM, OP_GN_STATS, OP_GN_APPLY, OP_LAYERNORM, OP_ATTENTION, OP_GEGLU, OP_COPY2D, \
     OP_TIME_EMBED, OP_SOFTMAX_ROWS, OP_TRANSPOSE, OP_AXPBY, OP_INVERT_STEP, OP_REVERSE_STEP, OP_DDIM_STEP, \
     OP_ADVANCE, OP_REFLECT_PAD, OP_MAGNITUDE, OP_NCHW_TO_NHWC, OP_NHWC_TO_NCHW, OP_SPLITK_REDUCE, \
-    OP_GN_SCALE_SHIFT, OP_GN_SMALL, OP_XATTN_FOLD = range(24)
+    OP_GN_SCALE_SHIFT, OP_GN_SMALL, OP_XATTN_FOLD, OP_ROTARY, OP_SNAKE, OP_SA_STEP, OP_GAUSS_SAMPLE = range(28)
 OP_NAMES = ["nop", "conv_gemm", "gn_stats", "gn_apply", "layernorm", "attention", "geglu", "copy2d", "time_embed",
             "softmax_rows", "transpose", "axpby", "invert_step", "reverse_step", "ddim_step", "advance",
             "reflect_pad", "magnitude", "nchw_to_nhwc", "nhwc_to_nchw", "splitk_reduce", "gn_scale_shift", "gn_small",
-            "xattn_fold"]
+            "xattn_fold", "rotary", "snake", "sa_step", "gauss_sample"]
 ACT_NONE, ACT_SILU, ACT_LEAKY, ACT_TANH, ACT_LOGCLAMP = range(5)
 COEF_STRIDE = 8
+SA_COEF_STRIDE = 12
 
 _lib = None
 
@@ -61,12 +62,15 @@ def lib():
         L.aed_get_zs_from_xts.argtypes = [vp, vp, vp, vp, vp, cf, ci, fp, ci, ci, vp, vp, ctypes.c_int64, vp]
         L.aed_reverse_step_with_custom_noise.argtypes = [vp, vp, vp, vp, cf, ci, fp, ci, vp, vp, ctypes.c_int64, vp]
         L.aed_sample_xts_from_x0.argtypes = [vp, vp, vp, vp, vp, ci, ctypes.c_int64, vp]
+        L.aed_sa_get_zs_from_xts.argtypes = [vp, vp, vp, vp, cf, fp, vp, ci, vp, vp, ctypes.c_int64, vp]
+        L.aed_sa_reverse_step_with_custom_noise.argtypes = [vp, vp, vp, cf, fp, vp, vp, vp, ctypes.c_int64, vp]
         for name in ("aed_launch", "aed_tape_run", "aed_tape_profile", "aed_graph_begin", "aed_graph_end",
                      "aed_graph_launch", "aed_graph_destroy", "aed_event_create", "aed_event_record",
                      "aed_event_elapsed_ms", "aed_event_destroy", "aed_get_zs_from_xts",
-                     "aed_reverse_step_with_custom_noise", "aed_sample_xts_from_x0", "aed_device_info"):
+                     "aed_reverse_step_with_custom_noise", "aed_sample_xts_from_x0", "aed_device_info",
+                     "aed_sa_get_zs_from_xts", "aed_sa_reverse_step_with_custom_noise"):
             getattr(L, name).restype = ci
-        if L.aed_version() != 2:
+        if L.aed_version() != 3:
             raise AedError("libaed.so ABI version mismatch")
         _lib = L
     return _lib
@@ -75,7 +79,8 @@ def lib():
 EXPORTS = ["aed_version", "aed_last_error", "aed_device_info", "aed_launch", "aed_tape_run", "aed_tape_profile",
            "aed_graph_begin", "aed_graph_end", "aed_graph_launch", "aed_graph_destroy", "aed_event_create",
            "aed_event_record", "aed_event_elapsed_ms", "aed_event_destroy", "aed_get_zs_from_xts",
-           "aed_reverse_step_with_custom_noise", "aed_sample_xts_from_x0"]
+           "aed_reverse_step_with_custom_noise", "aed_sample_xts_from_x0", "aed_sa_get_zs_from_xts",
+           "aed_sa_reverse_step_with_custom_noise"]
 
 
 def check(rc, what=""):

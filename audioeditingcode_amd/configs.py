@@ -48,6 +48,23 @@ VOCODER_AUDIOLDM = dict(model_in_dim=64, sampling_rate=16000, upsample_initial_c
 STFT_AUDIOLDM = dict(filter_length=1024, hop_length=160, win_length=1024, n_mel_channels=64, sampling_rate=16000,
                      mel_fmin=0, mel_fmax=8000)
 
+# ---- Stable Audio Open 1.0 (StableAudWrapper, models.py:1051-1354; BASELINE config 5).  Public configs restated from
+# memory ([unverified]); a local checkpoint's config.json files win.
+DIT_STABLE_AUDIO = dict(sample_size=1024, in_channels=64, out_channels=64, num_layers=24, attention_head_dim=64,
+                        num_attention_heads=24, num_key_value_attention_heads=12, cross_attention_dim=768,
+                        time_proj_dim=256, global_states_input_dim=1536, cross_attention_input_dim=768)
+OOBLECK_STABLE_AUDIO = dict(encoder_hidden_size=128, downsampling_ratios=[2, 4, 4, 8, 8],
+                            channel_multiples=[1, 2, 4, 8, 16], decoder_channels=128, decoder_input_channels=64,
+                            audio_channels=2, sampling_rate=44100)
+SCHEDULER_COSINE_DPM = dict(sigma_min=0.3, sigma_max=500.0, sigma_data=1.0, sigma_schedule="exponential",
+                            num_train_timesteps=1000, solver_order=2, prediction_type="v_prediction", rho=7.0,
+                            solver_type="midpoint", lower_order_final=True, euler_at_final=False,
+                            final_sigmas_type="zero")
+PROJECTION_STABLE_AUDIO = dict(text_encoder_dim=768, conditioning_dim=768, min_value=0, max_value=512,
+                               number_embedding_internal_dim=256)
+STFT_STABLE_AUDIO = dict(filter_length=1024, hop_length=160, win_length=1024, n_mel_channels=64, sampling_rate=44100,
+                         mel_fmin=0, mel_fmax=22050)           # models.py:1105-1115 (spectrogram plots only)
+
 FAMILIES = {
     "audioldm2": dict(unet=UNET_AUDIOLDM2, vae=VAE_AUDIOLDM, vocoder=VOCODER_AUDIOLDM, scheduler=SCHEDULER,
                       stft=STFT_AUDIOLDM, ctx=dict(kind="audioldm2", gpt2_dim=768, gpt2_len=8, t5_dim=1024)),
@@ -55,6 +72,9 @@ FAMILIES = {
                      stft=STFT_AUDIOLDM, ctx=dict(kind="audioldm", clap_dim=512)),
     "tango": dict(unet=UNET_TANGO, vae=VAE_AUDIOLDM, vocoder=VOCODER_AUDIOLDM, scheduler=SCHEDULER,
                   stft=STFT_AUDIOLDM, ctx=dict(kind="tango", t5_dim=1024)),
+    "stable_audio": dict(dit=DIT_STABLE_AUDIO, oobleck=OOBLECK_STABLE_AUDIO, scheduler=SCHEDULER_COSINE_DPM,
+                         projection=PROJECTION_STABLE_AUDIO, stft=STFT_STABLE_AUDIO,
+                         ctx=dict(kind="stable_audio", t5_dim=768, max_length=128)),
 }
 
 
@@ -66,8 +86,10 @@ def family_of(model_id):
         return "audioldm2"
     if "audioldm" in model_id:
         return "audioldm"
-    raise NotImplementedError(f"{model_id}: only the AudioLDM / AudioLDM2 / TANGO wrappers are in scope "
-                              f"(Stable Audio is SURVEY 8f row 4; image models are out of scope)")
+    if "stable-audio" in model_id:
+        return "stable_audio"
+    raise NotImplementedError(f"{model_id}: only the AudioLDM / AudioLDM2 / TANGO / Stable Audio wrappers are in scope "
+                              f"(image models are out of scope)")
 
 
 def get_family(model_id):
@@ -87,6 +109,15 @@ def get_family(model_id):
 def tiny_family(kind="audioldm2"):
     """Reduced-width family with the same graph, for parity tests that must run in seconds."""
     fam = copy.deepcopy(FAMILIES[kind])
+    if kind == "stable_audio":
+        fam["dit"].update(sample_size=32, in_channels=8, out_channels=8, num_layers=2, attention_head_dim=32,
+                          num_attention_heads=4, num_key_value_attention_heads=2, cross_attention_dim=64,
+                          time_proj_dim=64, global_states_input_dim=128, cross_attention_input_dim=64)
+        fam["oobleck"].update(encoder_hidden_size=32, downsampling_ratios=[2, 4], channel_multiples=[1, 2],
+                              decoder_channels=32, decoder_input_channels=8, sampling_rate=800)
+        fam["projection"].update(text_encoder_dim=64, conditioning_dim=64, max_value=8, number_embedding_internal_dim=16)
+        fam["ctx"].update(t5_dim=64, max_length=6)
+        return fam
     u = fam["unet"]
     u["block_out_channels"] = [32, 64, 96, 128] if kind != "tango" else [32, 64, 128, 128]
     if kind == "audioldm2":

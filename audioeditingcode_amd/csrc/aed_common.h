@@ -49,6 +49,10 @@ int launch_reflect_pad(const aed_op* op, hipStream_t s);
 int launch_magnitude(const aed_op* op, hipStream_t s);
 int launch_layout(const aed_op* op, hipStream_t s);
 int launch_xattn_fold(const aed_op* op, hipStream_t s);
+int launch_rotary(const aed_op* op, hipStream_t s);
+int launch_snake(const aed_op* op, hipStream_t s);
+int launch_sa_step(const aed_op* op, hipStream_t s);
+int launch_gauss_sample(const aed_op* op, hipStream_t s);
 
 int aed_num_cus();
 

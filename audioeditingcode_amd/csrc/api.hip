@@ -33,6 +33,7 @@ static launcher_t g_table[AED_OP_COUNT] = {
     launch_time_embed, launch_softmax_rows, launch_transpose, launch_axpby, launch_invert_step,
     launch_reverse_step, launch_ddim_step, launch_advance, launch_reflect_pad, launch_magnitude,
     launch_layout, launch_layout, launch_splitk_reduce, launch_gn_scale_shift, launch_gn_small, launch_xattn_fold,
+    launch_rotary, launch_snake, launch_sa_step, launch_gauss_sample,
 };
 
 extern "C" {

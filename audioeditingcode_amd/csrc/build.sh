@@ -11,6 +11,7 @@ hipcc $FLAGS -c lin_gemm.hip -o obj/lin_gemm.o & pids+=($!)
 hipcc $FLAGS -c attention.hip -o obj/attention.o & pids+=($!)
 hipcc $FLAGS -c norm.hip -o obj/norm.o & pids+=($!)
 hipcc $FLAGS -ffp-contract=off -c elementwise.hip -o obj/elementwise.o & pids+=($!)
+hipcc $FLAGS -ffp-contract=off -c stable_audio.hip -o obj/stable_audio.o & pids+=($!)
 hipcc $FLAGS -c api.hip -o obj/api.o & pids+=($!)
 for p in "${pids[@]}"; do wait $p; done
 hipcc --offload-arch=$ARCH -shared -fPIC obj/*.o -o ../libaed.so

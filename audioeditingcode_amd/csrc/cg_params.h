@@ -39,7 +39,8 @@ struct CGParams {
     int sm_group;
     float sm_scale;
     const float* kbias;
-    int geglu;               // 1: W rows are packed [32 value | 32 gate] per 32 output features; out = value * gelu(gate)
+    int geglu;               // W rows are packed [32 value | 32 gate] per 32 output features; 1: out = value * gelu(gate)
+                             // (GEGLU), 2: out = value * silu(gate) (SwiGLU, the Stable Audio DiT's feed-forward)
 };
 
 __device__ __forceinline__ float in_transform(float v, int act, float slope) {
@@ -49,6 +50,7 @@ __device__ __forceinline__ float in_transform(float v, int act, float slope) {
 }
 
 __device__ __forceinline__ float gelu_exact(float g) { return 0.5f * g * (1.0f + erff(g * 0.70710678118654752440f)); }
+__device__ __forceinline__ float glu_gate(float g, int kind) { return kind == 2 ? g / (1.0f + expf(-g)) : gelu_exact(g); }
 
 // general (one element per call) epilogue: bias, per-batch row vector, residual, activation, accumulate, row scatter
 __device__ __forceinline__ void store_out(const CGParams& p, int m, int n, float v) {

@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 1) void conv_gemm
                         if (m < p.M) {
                             const int bb = m / p.rpb;
                             const unsigned row = (unsigned)bb * (unsigned)p.out_bs + (unsigned)(m - bb * p.rpb);
-                            p.C[row * (unsigned)p.ldc + nf] = val * gelu_exact(gate);
+                            p.C[row * (unsigned)p.ldc + nf] = val * glu_gate(gate, p.geglu);
                         }
                     }
                 }

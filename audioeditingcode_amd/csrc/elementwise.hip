@@ -43,27 +43,34 @@ int launch_geglu(const aed_op* op, hipStream_t s) {
 // captured graph can walk the xts trajectory (inversion_utils.py:78 `xt = xts[idx+1]`).
 __global__ __launch_bounds__(256) void copy2d_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows,
                                                       int cols, int lds_, int ldd, int vec, const int* state,
-                                                      int idx_off, int idx_mul, long idx_stride) {
-    if (state) src += (size_t)(idx_off + idx_mul * state[0]) * (size_t)idx_stride;
+                                                      int idx_off, int idx_mul, long idx_stride, const float* coef,
+                                                      int c_mul, int c_off, int c_stride, int c_col) {
+    const int st = state ? state[0] : 0;
+    if (state) src += (size_t)(idx_off + idx_mul * st) * (size_t)idx_stride;
+    // optional per-step scale read from a device coefficient table (Stable Audio: scheduler.scale_model_input)
+    const float sc = coef ? coef[(size_t)(st * c_mul + c_off) * c_stride + c_col] : 1.0f;
     if (vec) {
         const int q = cols >> 2;
         const size_t total = (size_t)rows * q;
         for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
             const int r = (int)(e / q);
             const int c = (int)(e - (size_t)r * q) * 4;
-            *reinterpret_cast<float4*>(dst + (size_t)r * ldd + c) =
-                *reinterpret_cast<const float4*>(src + (size_t)r * lds_ + c);
+            float4 v = *reinterpret_cast<const float4*>(src + (size_t)r * lds_ + c);
+            if (coef) { v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc; }
+            *reinterpret_cast<float4*>(dst + (size_t)r * ldd + c) = v;
         }
     } else {
         const size_t total = (size_t)rows * cols;
         for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
             const int r = (int)(e / cols);
             const int c = (int)(e - (size_t)r * cols);
-            dst[(size_t)r * ldd + c] = src[(size_t)r * lds_ + c];
+            const float v = src[(size_t)r * lds_ + c];
+            dst[(size_t)r * ldd + c] = coef ? v * sc : v;
         }
     }
 }
-// slots: p0=src p1=dst p2=state(nullable) ; i0=rows i1=cols i2=ld_src i3=ld_dst i4=idx_off i5=idx_mul i6=idx_stride
+// slots: p0=src p1=dst p2=state(nullable) p3=coef table (nullable) ; i0=rows i1=cols i2=ld_src i3=ld_dst i4=idx_off
+//        i5=idx_mul i6=idx_stride ; scale = coef[(state*i7 + i8)*i9 + i10]
 int launch_copy2d(const aed_op* op, hipStream_t s) {
     const int32_t* i = op->i;
     AED_REQUIRE(op->p[0] && op->p[1], "copy2d: null pointer");
@@ -71,7 +78,7 @@ int launch_copy2d(const aed_op* op, hipStream_t s) {
                     ((uintptr_t)op->p[1] % 16 == 0) && (i[6] % 4 == 0);
     hipLaunchKernelGGL(copy2d_kernel, dim3(grid_for((size_t)i[0] * i[1] / (vec ? 4 : 1))), dim3(256), 0, s,
                        (const float*)op->p[0], (float*)op->p[1], i[0], i[1], i[2], i[3], vec, (const int*)op->p[2],
-                       i[4], i[5], (long)i[6]);
+                       i[4], i[5], (long)i[6], (const float*)op->p[3], i[7], i[8], i[9], i[10]);
     AED_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -79,13 +86,15 @@ int launch_copy2d(const aed_op* op, hipStream_t s) {
 // ------------------------------------------------------------------------------------ timestep embedding
 __global__ void time_embed_kernel(float* out, const long long* tt, const int* state, const float* freqs,
                                   const int* row_tidx, int B, int dim, int flip, int ld, int t_imm, int tgroup,
-                                  float shift, float max_period) {
+                                  float shift, float max_period, int float_table) {
     const int half = dim / 2;
     const int s = state ? state[0] : 0;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < B * half; e += gridDim.x * blockDim.x) {
         const int b = e / half, i = e - b * half;
         // row b of a timestep-batched call uses table entry s*tgroup + row_tidx[b]
-        const float t = (float)(tt ? tt[s * tgroup + (row_tidx ? row_tidx[b] : 0)] : (long long)t_imm);
+        const int ti = s * tgroup + (row_tidx ? row_tidx[b] : 0);
+        // (float_table: the table holds fp32 values -- Stable Audio's continuous timesteps, already times 2*pi)
+        const float t = !tt ? (float)t_imm : float_table ? reinterpret_cast<const float*>(tt)[ti] : (float)tt[ti];
         // freqs (host table, computed exactly as diffusers' Timesteps does) keeps t*freq bit-identical
         const float fr = freqs ? freqs[i] : expf(-logf(max_period) * (float)i / ((float)half - shift));
         const float arg = t * fr;
@@ -97,14 +106,14 @@ __global__ void time_embed_kernel(float* out, const long long* tt, const int* st
 }
 // slots: p0=out[B,dim] p1=timesteps(int64 dev, nullable) p2=state(int32 dev, nullable) p3=freqs[dim/2] (nullable)
 //        p4=row_tidx(int32[B], nullable)   i5 = timesteps per call (tgroup, default 1)
-//        i0=B i1=dim i2=flip_sin_to_cos i3=ld i4=t_imm ; f0=freq_shift f1=max_period
+//        i0=B i1=dim i2=flip_sin_to_cos i3=ld i4=t_imm i6=1: p1 is a float32 table ; f0=freq_shift f1=max_period
 int launch_time_embed(const aed_op* op, hipStream_t s) {
     const int32_t* i = op->i;
     AED_REQUIRE(op->p[0] && i[1] % 2 == 0, "time_embed: bad args");
     hipLaunchKernelGGL(time_embed_kernel, dim3(aed_cdiv(i[0] * i[1] / 2, 256)), dim3(256), 0, s, (float*)op->p[0],
                        (const long long*)op->p[1], (const int*)op->p[2], (const float*)op->p[3], (const int*)op->p[4],
                        i[0], i[1], i[2], i[3], i[4], i[5] > 0 ? i[5] : 1, op->f[0],
-                       op->f[1] > 0.f ? op->f[1] : 10000.0f);
+                       op->f[1] > 0.f ? op->f[1] : 10000.0f, i[6]);
     AED_CHECK_HIP(hipGetLastError());
     return 0;
 }

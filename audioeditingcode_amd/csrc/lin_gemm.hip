@@ -368,7 +368,7 @@ __global__ __launch_bounds__(64 * NW) void lin_gemm_kernel(CGParams p) {
                     gate += e_bias[b + 1];
                     const int b0 = mo / p.rpb;
                     const size_t orow = (size_t)b0 * p.out_bs + (mo - b0 * p.rpb);
-                    p.C[orow * p.ldc + (n0 >> 1) + b * 16 + col] = val * gelu_exact(gate);
+                    p.C[orow * p.ldc + (n0 >> 1) + b * 16 + col] = val * glu_gate(gate, p.geglu);
                 }
             } else if (p.sm_group > 0) {
                 // grouped softmax (cross-attention scores: one group = the keys of one head).  All lanes of a group share

@@ -262,16 +262,88 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const float* __restrict__
         }
     }
 }
-// slots: p0=x p1=gamma p2=beta p3=y p4=x2(or null) ; i0=B i1=HW i2=C i3=G i4=ldx i5=ldy i6=act i7=(unused)
+// Register-resident form for slices of at most 256*U float4 (every U-Net GroupNorm at levels 1-3 at batch 2): the slice is
+// loaded ONCE, reduced, normalised from registers and stored -- no second read of the activation, one latency chain less
+// (same arithmetic and summation order as gn_small_kernel: per-thread partial sums in element order, fp64 block combine).
+template <int U>
+__global__ __launch_bounds__(256) void gn_small_reg_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ y,
+                                                            int HW, int C, int G, int ldx, int ldy, float eps, int act,
+                                                            const float* __restrict__ x2, int C1, int ldx2) {
+    __shared__ double rs[4], rss[4];
+    const int tid = threadIdx.x, g = blockIdx.x, b = blockIdx.y;
+    const int cpg = C / G, cpg4 = cpg >> 2;
+    const size_t rb = (size_t)b * HW;
+    float* yb = y + (size_t)b * HW * ldy + g * cpg;
+    const int total = HW * cpg4;
+    float4 v[U], ga[U], be[U];
+    int rowv[U], jv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int e = min(tid + 256 * u, total - 1);
+        rowv[u] = e / cpg4;
+        jv[u] = e - rowv[u] * cpg4;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        v[u] = *reinterpret_cast<const float4*>(gn_src(x, x2, C1, ldx, ldx2, rb + rowv[u], g * cpg + 4 * jv[u]));
+        ga[u] = *reinterpret_cast<const float4*>(gamma + g * cpg + 4 * jv[u]);
+        be[u] = *reinterpret_cast<const float4*>(beta + g * cpg + 4 * jv[u]);
+    }
+    float s = 0.f, ss = 0.f;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (tid + 256 * u < total) {
+            s += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+            ss += (v[u].x * v[u].x + v[u].y * v[u].y) + (v[u].z * v[u].z + v[u].w * v[u].w);
+        }
+    }
+    double ds = (double)s, dss = (double)ss;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { ds += __shfl_xor(ds, o, 64); dss += __shfl_xor(dss, o, 64); }
+    if ((tid & 63) == 0) { rs[tid >> 6] = ds; rss[tid >> 6] = dss; }
+    __syncthreads();
+    ds = (rs[0] + rs[1]) + (rs[2] + rs[3]);
+    dss = (rss[0] + rss[1]) + (rss[2] + rss[3]);
+    const double n = (double)HW * (double)cpg;
+    const double dmean = ds / n;
+    double var = dss / n - dmean * dmean;
+    if (var < 0.0) var = 0.0;
+    const float mean = (float)dmean;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (tid + 256 * u >= total) continue;
+        float4 w = v[u];
+        w.x = (w.x - mean) * rstd * ga[u].x + be[u].x;
+        w.y = (w.y - mean) * rstd * ga[u].y + be[u].y;
+        w.z = (w.z - mean) * rstd * ga[u].z + be[u].z;
+        w.w = (w.w - mean) * rstd * ga[u].w + be[u].w;
+        if (act == AED_ACT_SILU) {
+            w.x = w.x / (1.0f + expf(-w.x));
+            w.y = w.y / (1.0f + expf(-w.y));
+            w.z = w.z / (1.0f + expf(-w.z));
+            w.w = w.w / (1.0f + expf(-w.w));
+        }
+        *reinterpret_cast<float4*>(yb + (size_t)rowv[u] * ldy + 4 * jv[u]) = w;
+    }
+}
+// slots: p0=x p1=gamma p2=beta p3=y p4=x2(or null) ; i0=B i1=HW i2=C i3=G i4=ldx i5=ldy i6=act i7=1: never register-resident (A/B)
 //        i8=C1 i9=ldx2 (two-source rows, see gn_src) ; f0=eps
 int launch_gn_small(const aed_op* op, hipStream_t s) {
     const int32_t* i = op->i;
     AED_REQUIRE(op->p[0] && op->p[1] && op->p[2] && op->p[3], "gn_small: null pointer");
     AED_REQUIRE(i[2] % (4 * i[3]) == 0 && i[4] % 4 == 0 && i[5] % 4 == 0, "gn_small: C=%d G=%d", i[2], i[3]);
     AED_REQUIRE(!op->p[4] || (i[8] > 0 && i[8] < i[2] && i[8] % 4 == 0 && i[9] % 4 == 0), "gn_small: bad two-source split");
-    hipLaunchKernelGGL(gn_small_kernel<4>, dim3(i[3], i[0]), dim3(256), 0, s, (const float*)op->p[0],
-                       (const float*)op->p[1], (const float*)op->p[2], (float*)op->p[3], i[1], i[2], i[3], i[4], i[5],
-                       op->f[0], i[6], (const float*)op->p[4], i[8], i[9]);
+    const int total4 = i[1] * (i[2] / i[3] / 4);        // float4 per (group, batch item) slice
+#define GN_ARGS (const float*)op->p[0], (const float*)op->p[1], (const float*)op->p[2], (float*)op->p[3], i[1], i[2], i[3], \
+                i[4], i[5], op->f[0], i[6], (const float*)op->p[4], i[8], i[9]
+    const dim3 grid(i[3], i[0]);
+    if (i[7] != 1 && total4 <= 256 * 2) hipLaunchKernelGGL(gn_small_reg_kernel<2>, grid, dim3(256), 0, s, GN_ARGS);
+    else if (i[7] != 1 && total4 <= 256 * 4) hipLaunchKernelGGL(gn_small_reg_kernel<4>, grid, dim3(256), 0, s, GN_ARGS);
+    else if (i[7] != 1 && total4 <= 256 * 8) hipLaunchKernelGGL(gn_small_reg_kernel<8>, grid, dim3(256), 0, s, GN_ARGS);
+    else hipLaunchKernelGGL(gn_small_kernel<4>, grid, dim3(256), 0, s, GN_ARGS);
+#undef GN_ARGS
     AED_CHECK_HIP(hipGetLastError());
     return 0;
 }

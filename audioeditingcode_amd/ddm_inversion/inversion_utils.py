@@ -74,6 +74,9 @@ def inversion_forward_process(model, x0: torch.Tensor, etas: Optional[float] = N
                               timestep_group: int = 8) -> Tuple:
     if len(prompts) > 1 and extract_h_space:
         raise NotImplementedError("How do you split cfg_scales for hspace? TODO")
+    if getattr(model, "kind", None) == "stable_audio":
+        return _sa_forward(model, x0, prompts, cfg_scales, num_inference_steps, numerical_fix, duration, first_order,
+                           schedule, timestep_group, extract_h_space or extract_skipconns)
     if extract_h_space or extract_skipconns:
         return _forward_with_taps(model, x0, etas, prompts, cfg_scales, num_inference_steps, cutoff_points,
                                   numerical_fix, extract_h_space, extract_skipconns)
@@ -161,6 +164,10 @@ def inversion_reverse_process(model, xT: torch.Tensor, tstart: torch.Tensor, fix
                               first_order: bool = False, extra_info: Optional[List] = None) -> Tuple:
     batch_size = len(prompts)
     tstart = torch.as_tensor(tstart).reshape(-1).cpu()
+    if getattr(model, "kind", None) == "stable_audio":
+        return _sa_reverse(model, xT, tstart, prompts, neg_prompts, cfg_scales, zs, duration, first_order, extra_info,
+                           any(v is not None for v in (hspace_add, hspace_replace, skipconns_replace,
+                                                       zero_out_resconns)) or extract_h_space or extract_skipconns)
     hooks = any(v is not None for v in (hspace_add, hspace_replace, skipconns_replace, zero_out_resconns)) \
         or extract_h_space or extract_skipconns
     uneven = bool((tstart.max() - tstart).any())
@@ -250,3 +257,61 @@ def _reverse_with_hooks(model, xT, tstart, fix_alpha, etas, prompts, neg_prompts
     if extract_skipconns:
         return xt, zs, torch.concat(hspaces, axis=0), skipconns
     return xt, zs
+
+
+# ------------------------------------------------------------------------------------------------ Stable Audio Open
+def _sa_single_prompt(prompts, what):
+    if len(prompts) != 1:
+        # the reference's DiT call concatenates a batch-1 global token to the batch-P sequence (models.py:1345-1349 into
+        # StableAudioDiTModel.forward): more than one prompt fails there as well
+        raise NotImplementedError(f"Stable Audio: one {what} prompt per call (got {len(prompts)})")
+
+
+def _sa_forward(model, x0, prompts, cfg_scales, T, numerical_fix, duration, first_order, schedule, group, taps):
+    """inversion_forward_process for StableAudWrapper (inversion_utils.py:52-144 on the 3-D latent): returns
+    (xt, zs [T,C,L], xts [T+1,C,L], extra_info) with extra_info[idx] = the data prediction of the previous step
+    ([1,C,L]; None for idx = T-1), which inversion_reverse_process needs to re-seed the second-order solver."""
+    if taps:
+        raise NotImplementedError("Stable Audio has no h-space / skip-connection taps (models.py:1354 returns None)")
+    _sa_single_prompt(prompts, "source")
+    sched = model.model.scheduler
+    has_src = prompts[0] != ""
+    if has_src:
+        hs, _, mask = model.encode_text(prompts)
+    uhs, _, umask = model.encode_text([""], negative=True)
+    model.setup_extra_inputs(x0, init_timestep=sched.timesteps[0], audio_end_in_s=duration)
+    ctx_src = model.assemble_context(hs, mask) if has_src else None
+    ctx_unc = model.assemble_context(uhs, umask)
+    ed = model.editor()
+    xts0 = model.sample_xts_from_x0(x0, num_inference_steps=T).unsqueeze(1)
+    zs, xts, extra = ed.invert(x0.reshape(1, *x0.shape[-2:]), ctx_src, ctx_unc, model.audio_duration_embeds,
+                               float(cfg_scales[0]), numerical_fix=numerical_fix, first_order=first_order, xts=xts0,
+                               mode=schedule, group=group)
+    zs_n, xts_n, extra_n = ed.to_cl(zs), ed.to_cl(xts), ed.to_cl(extra)
+    extra_info = [extra_n[i][None] for i in range(T - 1)] + [None]
+    return xts_n[1][None], zs_n, xts_n, extra_info
+
+
+def _sa_reverse(model, xT, tstart, prompts, neg_prompts, cfg_scales, zs, duration, first_order, extra_info, hooks):
+    """inversion_reverse_process for StableAudWrapper (inversion_utils.py:200-316 on the 3-D latent)."""
+    if hooks:
+        raise NotImplementedError("Stable Audio has no h-space / skip-connection hooks")
+    _sa_single_prompt(prompts, "target")
+    _sa_single_prompt(neg_prompts, "negative")
+    sched = model.model.scheduler
+    Z = zs.shape[0]
+    if int(tstart.max()) != Z:
+        raise NotImplementedError("Stable Audio: the edit starts at x_{tstart} with exactly tstart noise maps")
+    hs, _, mask = model.encode_text(prompts)
+    uhs, _, umask = model.encode_text(neg_prompts, negative=True)
+    model.setup_extra_inputs(xT[Z].unsqueeze(0), extra_info=extra_info, init_timestep=sched.timesteps[-Z],
+                             audio_end_in_s=duration)
+    ctx_tgt = model.assemble_context(hs, mask)
+    ctx_neg = model.assemble_context(uhs, umask)
+    ed = model.editor()
+    m1 = None
+    if extra_info is not None and extra_info[Z - 1] is not None:
+        m1 = ed.to_lc(extra_info[Z - 1].reshape(*xT.shape[-2:]))
+    w = ed.edit(ed.to_lc(xT), ed.to_lc(zs), Z, ctx_tgt, ctx_neg, model.audio_duration_embeds, float(cfg_scales[0]),
+                first_order=first_order, m1=m1)
+    return ed.to_cl(w)[None], zs

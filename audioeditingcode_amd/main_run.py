@@ -17,9 +17,11 @@ from .utils import load_audio, set_reproducability, synthetic_clip, write_wav
 
 
 def edit_clip(ldm_stable, x0, source_prompt, target_prompt, target_neg_prompt, cfg_src, cfg_tar, T, tstart,
-              mode="ours", eta=1.0, schedule="sequential", timestep_group=8, cutoff_points=None, fix_alpha=0.1):
-    """main_run.py:104-185 for one mel `x0` [1,1,T_mel,64]: returns (edited waveform, original-vocoded waveform,
-    edited latent).  `tstart`: int or one value per target prompt (main_run.py:104-110)."""
+              mode="ours", eta=1.0, schedule="sequential", timestep_group=8, cutoff_points=None, fix_alpha=0.1,
+              duration=None):
+    """main_run.py:104-185 for one mel `x0` [1,1,T_mel,64] (Stable Audio: one waveform [channels, n]): returns (edited
+    waveform, original-vocoded waveform, edited latent).  `tstart`: int or one value per target prompt
+    (main_run.py:104-110)."""
     tstart = [int(tstart)] if isinstance(tstart, (int, float)) else [int(t) for t in tstart]
     if len(tstart) != len(target_prompt):
         if len(tstart) == 1:
@@ -45,15 +47,18 @@ def edit_clip(ldm_stable, x0, source_prompt, target_prompt, target_neg_prompt, c
             wT = ddim_inversion(ldm_stable, w0, source_prompt, cfg_src[0], num_inference_steps=T, skip=int(skip[0]))
             w_edit = text2image_ldm_stable(ldm_stable, target_prompt, T, cfg_tar[0], wT, skip=int(skip[0]))
         else:
-            _, zs, wts, _ = inversion_forward_process(ldm_stable, w0, etas=eta, prompts=source_prompt,
-                                                      cfg_scales=cfg_src, num_inference_steps=T, numerical_fix=True,
-                                                      cutoff_points=cutoff_points, schedule=schedule,
-                                                      timestep_group=timestep_group)
+            _, zs, wts, extra_info = inversion_forward_process(
+                ldm_stable, w0, etas=eta, prompts=source_prompt, cfg_scales=cfg_src, num_inference_steps=T,
+                numerical_fix=True, cutoff_points=cutoff_points, schedule=schedule, timestep_group=timestep_group,
+                duration=duration)
             w_edit, _ = inversion_reverse_process(ldm_stable, xT=wts, tstart=tstart_t, fix_alpha=fix_alpha, etas=eta,
                                                   prompts=target_prompt, neg_prompts=target_neg_prompt,
                                                   cfg_scales=cfg_tar, zs=zs[:int(T - min(skip))],
-                                                  cutoff_points=cutoff_points)
+                                                  cutoff_points=cutoff_points, duration=duration,
+                                                  extra_info=extra_info)
         x0_dec = ldm_stable.vae_decode(w_edit)
+        if "stable-audio" in ldm_stable.model_id:                       # main_run.py:187-190: the VAE output IS the audio
+            return x0_dec.detach().clone().cpu().squeeze(0), x0.detach().clone().cpu(), w_edit
         if x0_dec.dim() < 4:
             x0_dec = x0_dec[None, :, :, :]
         audio = ldm_stable.decode_to_mel(x0_dec)
@@ -89,17 +94,19 @@ def main(argv=None):
     torch.cuda.set_device(args.device_num)
     ldm_stable = load_model(args.model_id, device, args.num_diffusion_steps, allow_synthetic=args.allow_synthetic or None)
     src = args.init_aud if args.init_aud else (synthetic_clip(), 16000)
-    x0, sr, duration = load_audio(src, ldm_stable.get_fn_STFT(), device=device, stft=True, model_sr=ldm_stable.get_sr())
+    sa = "stable-audio" in args.model_id
+    x0, sr, duration = load_audio(src, ldm_stable.get_fn_STFT(), device=device, stft=not sa, model_sr=ldm_stable.get_sr())
     t0 = time.time()
     audio, orig, _ = edit_clip(ldm_stable, x0, args.source_prompt, args.target_prompt, args.target_neg_prompt,
                                args.cfg_src, args.cfg_tar, args.num_diffusion_steps, args.tstart, args.mode,
-                               args.eta, args.schedule, cutoff_points=args.cutoff_points, fix_alpha=args.fix_alpha)
+                               args.eta, args.schedule, cutoff_points=args.cutoff_points, fix_alpha=args.fix_alpha,
+                               duration=duration)
     torch.cuda.synchronize()
     print(f"edited {duration:.1f} s clip in {time.time() - t0:.2f} s (weights: {ldm_stable.weights_source}; "
           f"text conditioning: {ldm_stable.conditioning_source})")
     os.makedirs(args.results_path, exist_ok=True)
-    write_wav(os.path.join(args.results_path, "edited.wav"), audio[0].numpy())
-    write_wav(os.path.join(args.results_path, "orig.wav"), orig[0].numpy())
+    write_wav(os.path.join(args.results_path, "edited.wav"), audio[0].numpy(), sr=sr)
+    write_wav(os.path.join(args.results_path, "orig.wav"), orig[0].numpy(), sr=sr)
 
 
 if __name__ == "__main__":

@@ -20,7 +20,8 @@ from . import _lib as L
 from . import configs, weights
 from .codec import STFTEngine, VAEDecoder, VAEEncoder, VocoderEngine
 from .editing import Conditioning, EditEngine
-from .scheduler import DDIMScheduler, step_coefficients
+from .scheduler import (CosineDPMSolverMultistepScheduler, DDIMScheduler, sa_step_coefficients, sa_step_orders,
+                        step_coefficients)
 from .tape import Tape
 from .unet import PackedUNetWeights, UNetEngine
 
@@ -453,6 +454,272 @@ class TangoWrapper(PipelineWrapper):
         t5, mask = _SyntheticText.t5(prompts, self.family["ctx"]["t5_dim"])
         return t5.to(self.device), None, mask.to(self.device)
 
+class StableAudWrapper(PipelineWrapper):
+    """StableAudWrapper of the reference (models.py:1051-1354): Stable Audio Open 1.0 -- DiT backbone on a 3-D latent
+    [1, 64, 1024], CosineDPMSolver++ (SDE, order 2) inversion / edit, Oobleck VAE on raw 44.1 kHz stereo.  Same method
+    names and argument meaning; every tensor-valued method runs in libaed.so.  `self.model` has no `unet` attribute,
+    which is how the reference's loops pick the 3-D expands (inversion_utils.py:88-89)."""
+    family_name = "stable_audio"
+
+    def __init__(self, model_id: str, device: torch.device, double_precision: bool = False,
+                 token: Optional[str] = None, seed: int = 0, state_dicts: Optional[Dict] = None,
+                 allow_synthetic: Optional[bool] = None, *args, **kwargs) -> None:
+        torch.nn.Module.__init__(self)
+        if allow_synthetic is None:
+            allow_synthetic = os.environ.get("AED_ALLOW_SYNTHETIC") == "1" or model_id.startswith("tiny/")
+        self.synthetic_ok = bool(allow_synthetic)
+        self.text_encoders = None
+        self.conditioning_source = "unset"
+        if double_precision:
+            raise NotImplementedError("double_precision=True: the native path is fp32 (the reference's default)")
+        self.model_id, self.device, self.double_precision, self.token = model_id, torch.device(device), False, token
+        self._require_device()
+        L.lib()
+        self.family = configs.get_family(model_id)
+        self.kind = "stable_audio"
+        ckpt = weights.find_checkpoint(model_id) if state_dicts is None else None
+        if state_dicts is not None:
+            dit_sd, vae_sd, proj_sd = state_dicts["transformer"], state_dicts["vae"], state_dicts["projection_model"]
+            self.weights_source = "caller-provided state dicts"
+        elif ckpt is not None:
+            comp = weights.load_stable_audio_checkpoint(ckpt)
+            self.family["dit"], dit_sd = comp["transformer"]
+            self.family["oobleck"], vae_sd = comp["vae"]
+            self.family["projection"], proj_sd = comp["projection_model"]
+            if "scheduler" in comp:
+                self.family["scheduler"] = comp["scheduler"]
+            self.weights_source = ckpt
+            try:
+                from .text_encoders import TextEncoders
+                self.text_encoders = TextEncoders.from_pretrained(ckpt, "stable_audio", device=self.device)
+                self.conditioning_source = f"transformers text encoder from {ckpt}"
+            except (FileNotFoundError, OSError, ImportError) as e:
+                if not self.synthetic_ok:
+                    raise L.AedError(f"{ckpt}: DiT/VAE weights were found but the text-conditioning components could "
+                                     f"not be loaded ({e}); pass allow_synthetic=True to run with stand-ins.") from e
+        else:
+            if not self.synthetic_ok:
+                raise L.AedError(f"no checkpoint for '{model_id}' on disk (weights.find_checkpoint) and none can be "
+                                 f"downloaded here. Seeded-random weights are for benchmarks and parity tests only: "
+                                 f"pass allow_synthetic=True to load_model, set AED_ALLOW_SYNTHETIC=1, or use "
+                                 f"--allow_synthetic on the CLIs.")
+            dit_sd = weights.random_state_dict(weights.dit_param_shapes(self.family["dit"]), seed=seed)
+            vae_sd = weights.random_state_dict(weights.oobleck_param_shapes(self.family["oobleck"]), seed=seed + 1)
+            proj_sd = weights.random_state_dict(weights.projection_param_shapes(self.family["projection"]), seed=seed + 2)
+            self.weights_source = f"seeded-random(seed={seed})"
+        self.state_dicts = dict(transformer=dit_sd, vae=vae_sd, projection_model=proj_sd)
+        from .stable_audio import PackedDiTWeights
+        self.dit_weights = PackedDiTWeights(dit_sd, self.family["dit"], self.device)
+        if self.text_encoders is None:
+            from .text_encoders import StableAudioProjection
+            self._projection = StableAudioProjection(**self.family["projection"])
+            self._projection.load_diffusers_state_dict(proj_sd)
+        dcfg, ocfg = self.family["dit"], self.family["oobleck"]
+        hop = 1
+        for r in ocfg["downsampling_ratios"]:
+            hop *= r
+        self.model = SimpleNamespace(
+            scheduler=None,
+            transformer=SimpleNamespace(config=SimpleNamespace(**dcfg)),
+            vae=SimpleNamespace(hop_length=hop, config=SimpleNamespace(sampling_rate=ocfg["sampling_rate"],
+                                                                       audio_channels=ocfg["audio_channels"])),
+            rotary_embed_dim=dcfg["attention_head_dim"] // 2)
+        self._engines = {}
+        self._editor = None
+        self.waveform_start, self.waveform_end = 0, dcfg["sample_size"] * hop
+        self.seconds_start_hidden_states = self.seconds_end_hidden_states = self.audio_duration_embeds = None
+        self._hist = None
+
+    # ------------------------------------------------------------------ engines
+    def editor(self, *unused):
+        from .stable_audio import StableAudioEditEngine
+        if self._editor is None:
+            self._editor = StableAudioEditEngine(self.family["dit"], self.dit_weights, self.model.scheduler, self.device)
+        self._editor.sched = self.model.scheduler
+        return self._editor
+
+    def load_scheduler(self) -> None:
+        self.model.scheduler = CosineDPMSolverMultistepScheduler.from_config(self.family["scheduler"])
+
+    def get_sr(self) -> int:
+        return self.model.vae.config.sampling_rate
+
+    def get_noise_shape(self, x0: torch.Tensor, num_steps: int) -> Tuple[int, int, int]:
+        c = self.model.transformer.config
+        return (num_steps, c.in_channels, int(c.sample_size))
+
+    # ------------------------------------------------------------------ conditioning (models.py:1069-1103, :1142-1165)
+    def encode_text(self, prompts: List[str], negative: bool = False):
+        enc = getattr(self, "text_encoders", None)
+        if enc is not None:
+            return enc.encode_stable_audio(prompts, self.device, negative=negative)
+        _require_synthetic_text(self)
+        c = self.family["ctx"]
+        S, dim = c["max_length"], c["t5_dim"]
+        e = torch.zeros(len(prompts), S, dim)
+        mask = torch.zeros(len(prompts), S, dtype=torch.long)
+        for i, p in enumerate(prompts):
+            n = min(len(p.split()) + 1, S)
+            e[i] = torch.randn(S, dim, generator=_prompt_generator(p, "t5-sa"))      # non-zero at padded positions too
+            mask[i, :n] = 1
+        if negative:
+            e = torch.where(mask.to(torch.bool).unsqueeze(2), e, 0.0)
+        e = self._projection(text_hidden_states=e).text_hidden_states
+        if prompts == [""]:
+            return torch.zeros_like(e).to(self.device), None, None
+        m = mask.unsqueeze(-1).to(e.dtype)
+        return (e * m * m).to(self.device), None, mask.to(self.device)
+
+    def _encode_duration(self, start, end):
+        enc = getattr(self, "text_encoders", None)
+        if enc is not None:
+            return enc.encode_duration(start, end, self.device)
+        with torch.no_grad():
+            out = self._projection(start_seconds=[float(start)], end_seconds=[float(end)])
+        return out.seconds_start_hidden_states.to(self.device), out.seconds_end_hidden_states.to(self.device)
+
+    def assemble_context(self, encoder_hidden_states, encoder_attention_mask):
+        """The DiT's cross-attention input of unet_forward (models.py:1340-1343)."""
+        ctx = torch.cat([encoder_hidden_states.to(self.device), self.seconds_start_hidden_states,
+                         self.seconds_end_hidden_states], dim=1)
+        return torch.zeros_like(ctx) if encoder_attention_mask is None else ctx
+
+    def setup_extra_inputs(self, x: torch.Tensor, init_timestep: torch.Tensor, extra_info=None,
+                           audio_start_in_s: float = 0, audio_end_in_s: Optional[float] = None) -> None:
+        c, v = self.model.transformer.config, self.model.vae
+        max_len = c.sample_size * v.hop_length / v.config.sampling_rate
+        if audio_end_in_s is None:
+            audio_end_in_s = max_len
+        if audio_end_in_s - audio_start_in_s > max_len:
+            raise ValueError(f"The total audio length requested ({audio_end_in_s - audio_start_in_s}s) is longer than "
+                             f"the model maximum possible length ({max_len}). Make sure that "
+                             f"'audio_end_in_s-audio_start_in_s<={max_len}'.")
+        self.waveform_start = int(audio_start_in_s * v.config.sampling_rate)
+        self.waveform_end = int(audio_end_in_s * v.config.sampling_rate)
+        self.seconds_start_hidden_states, self.seconds_end_hidden_states = self._encode_duration(audio_start_in_s,
+                                                                                                  audio_end_in_s)
+        self.audio_duration_embeds = torch.cat([self.seconds_start_hidden_states, self.seconds_end_hidden_states], dim=2)
+        s = self.model.scheduler
+        s._init_step_index(init_timestep)
+        t_to_idx = {float(t): k for k, t in enumerate(s.timesteps)}
+        idx = len(s.timesteps) - t_to_idx[float(init_timestep)] - 1
+        s.model_outputs = [None, extra_info[idx] if extra_info is not None else None]
+        s.lower_order_nums = min(s.step_index, s.config.solver_order)
+
+    # ------------------------------------------------------------------ VAE (models.py:1117-1140)
+    def get_fn_STFT(self):
+        return _FnSTFT(self)
+
+    def vae_encode(self, x: torch.Tensor, generator=None) -> torch.Tensor:
+        from .stable_audio import OobleckEncoder
+        x = x.unsqueeze(0)
+        c, v = self.model.transformer.config, self.model.vae
+        n = int(c.sample_size * v.hop_length)
+        if x.shape[1] == 1 and v.config.audio_channels == 2:
+            x = x.repeat(1, 2, 1)
+        audio = x.new_zeros((1, v.config.audio_channels, n))
+        audio[:, :, : min(x.shape[-1], n)] = x[:, :, :n]
+        enc = self._cached(("oob_enc", n), lambda: OobleckEncoder(self.family["oobleck"], self.state_dicts["vae"],
+                                                                   self.device, 1, n))
+        lat = self.family["oobleck"]["decoder_input_channels"]
+        noise = torch.randn((1, lat, c.sample_size), generator=generator, dtype=torch.float32)   # posterior .sample()
+        z = enc(audio.transpose(1, 2), noise.transpose(1, 2))                                     # [1, Lz, lat]
+        return z.transpose(1, 2).contiguous()
+
+    def vae_decode(self, x: torch.Tensor) -> torch.Tensor:
+        from .stable_audio import OobleckDecoder
+        dec = self._cached(("oob_dec", x.shape[-1]), lambda: OobleckDecoder(self.family["oobleck"], self.state_dicts["vae"],
+                                                                            self.device, 1, x.shape[-1]))
+        aud = dec(x.to(self.device, torch.float32).transpose(1, 2)).transpose(1, 2).contiguous()   # [1, Ca, L]
+        return aud[:, :, self.waveform_start:self.waveform_end]
+
+    # ------------------------------------------------------------------ loops' primitives
+    def sample_xts_from_x0(self, x0: torch.Tensor, num_inference_steps: int = 50) -> torch.Tensor:
+        """x_t = x0 + n * sigma_t, independent noise per step drawn on the CPU generator in the reference's order
+        (models.py:1186-1207); returns [T+1, C, L] on the device."""
+        return self.editor().sample_xts(x0.reshape(1, *x0.shape[-2:]))[:, 0]
+
+    def _coef(self, first_order):
+        s = self.model.scheduler
+        i = s.step_index
+        order = sa_step_orders(s, i, 1, s.lower_order_nums, first_order)[0]
+        return i, order
+
+    def _history(self, like, order):
+        s = self.model.scheduler
+        if self._hist is None or self._hist.shape != like.shape:
+            self._hist = torch.zeros_like(like)
+        if order == 2:
+            self._hist.copy_(s.model_outputs[-1])
+        return self._hist
+
+    def get_zs_from_xts(self, xt, xtm1, data_pred, t, numerical_fix: bool = True, first_order: bool = False, **kwargs):
+        """models.py:1209-1271; `data_pred` is the (guided) model output.  The scheduler bookkeeping the reference does
+        by hand (history shift, lower_order_nums, step index) is kept on `self.model.scheduler` so host-driven callers
+        see the same state."""
+        s = self.model.scheduler
+        if s.step_index is None:
+            s._init_step_index(t)
+        i, order = self._coef(first_order)
+        zero_z = (i == len(s.timesteps) - 1) and s.config.final_sigmas_type == "zero"
+        c = sa_step_coefficients(s, i, order, zero_z=zero_z)
+        cf = (ctypes.c_float * L.SA_COEF_STRIDE)(*c.tolist())
+        xt, v = xt.contiguous(), data_pred.contiguous()
+        xtm1 = xtm1.contiguous().clone()
+        z = torch.empty_like(xt)
+        hist = self._history(xt, order)
+        prev = s.model_outputs[-1]
+        L.check(L.lib().aed_sa_get_zs_from_xts(xt.data_ptr(), xtm1.data_ptr(), v.data_ptr(), None, 0.0, cf,
+                                               hist.data_ptr(), int(bool(numerical_fix)), z.data_ptr(), None, xt.numel(),
+                                               L.current_stream_ptr()), "aed_sa_get_zs_from_xts")
+        s.model_outputs = [prev, hist.clone()]
+        if s.lower_order_nums < s.config.solver_order:
+            s.lower_order_nums += 1
+        s._step_index += 1
+        return z, xtm1, s.model_outputs[-2]
+
+    def reverse_step_with_custom_noise(self, model_output, timestep, sample, variance_noise=None,
+                                       first_order: bool = False, **kwargs):
+        """models.py:1282-1329 with the noise supplied (the Brownian-tree branch for variance_noise=None is not built:
+        the editing loops always pass the inverted noise maps)."""
+        if variance_noise is None:
+            raise NotImplementedError("reverse_step_with_custom_noise without variance_noise (BrownianTreeNoiseSampler)")
+        s = self.model.scheduler
+        if s.step_index is None:
+            s._init_step_index(timestep)
+        i, order = self._coef(first_order)
+        c = sa_step_coefficients(s, i, order)
+        cf = (ctypes.c_float * L.SA_COEF_STRIDE)(*c.tolist())
+        v, x, zn = model_output.contiguous(), sample.contiguous(), variance_noise.contiguous()
+        hist = self._history(x, order)
+        prev_m = s.model_outputs[-1]
+        out = torch.empty_like(x)
+        L.check(L.lib().aed_sa_reverse_step_with_custom_noise(x.data_ptr(), v.data_ptr(), None, 0.0, cf, hist.data_ptr(),
+                                                              zn.data_ptr(), out.data_ptr(), x.numel(),
+                                                              L.current_stream_ptr()),
+                "aed_sa_reverse_step_with_custom_noise")
+        s.model_outputs = [prev_m, hist.clone()]
+        if s.lower_order_nums < s.config.solver_order:
+            s.lower_order_nums += 1
+        s._step_index += 1
+        return out
+
+    def unet_forward(self, sample, timestep, encoder_hidden_states, encoder_attention_mask=None,
+                     return_dict: bool = True, **kwargs):
+        """models.py:1331-1354: one DiT call; `sample` is already input-scaled by the caller (scale_model_input)."""
+        from .stable_audio import DiTEngine
+        B = sample.shape[0]
+        ctx = self.assemble_context(encoder_hidden_states, encoder_attention_mask)
+        eng = self._cached(("dit", B, ctx.shape[1]), lambda: DiTEngine(self.family["dit"], self.dit_weights, self.device,
+                                                                        B, ctx.shape[1]))
+        eng.set_conditioning(ctx.expand(B, -1, -1), self.audio_duration_embeds.reshape(1, -1).expand(B, -1))
+        eng.set_timestep(timestep)
+        eng.x_in.copy_(sample.to(self.device, torch.float32).transpose(1, 2))
+        out = eng.forward().transpose(1, 2).contiguous()
+        if not return_dict:
+            return (out,)
+        return UNet2DConditionOutput(sample=out), None, None
+
 
 def load_model(model_id: str, device: torch.device, num_diffusion_steps: int, double_precision: bool = False,
                token: Optional[str] = None, seed: int = 0, state_dicts: Optional[Dict] = None,
@@ -460,7 +727,8 @@ def load_model(model_id: str, device: torch.device, num_diffusion_steps: int, do
     """Substring dispatch + scheduler setup of models.py:1357-1374.  `allow_synthetic`: opt-in to seeded-random weights
     and stand-in text embeddings when no checkpoint is on disk (benchmarks / tests; see PipelineWrapper.__init__)."""
     fam = configs.family_of(model_id)
-    cls = {"tango": TangoWrapper, "audioldm2": AudioLDM2Wrapper, "audioldm": AudioLDMWrapper}[fam]
+    cls = {"tango": TangoWrapper, "audioldm2": AudioLDM2Wrapper, "audioldm": AudioLDMWrapper,
+           "stable_audio": StableAudWrapper}[fam]
     ldm_stable = cls(model_id=model_id, device=device, double_precision=double_precision, token=token, seed=seed,
                      state_dicts=state_dicts, allow_synthetic=allow_synthetic)
     ldm_stable.load_scheduler()

@@ -166,3 +166,150 @@ def coefficient_table(sched, timesteps, eta=1.0, kind="ddpm"):
     fn = {"ddpm": lambda t: step_coefficients(sched, t, eta), "ddim_next": lambda t: ddim_next_coefficients(sched, t),
           "ddim_prev": lambda t: ddim_prev_coefficients(sched, t)}[kind]
     return torch.stack([fn(int(t)) for t in timesteps]).contiguous()
+
+
+# =============================================================================================== Stable Audio Open
+class CosineDPMSolverMultistepScheduler:
+    """The scheduler duck type StableAudWrapper reads (/root/reference/code/models.py:1066-1068, :1142-1329): `.sigmas`,
+    `.timesteps` (float, atan(sigma)*2/pi), `.config.{solver_order,final_sigmas_type,lower_order_final,euler_at_final,
+    sigma_min,sigma_max,sigma_data}`, `.step_index`/`._step_index`, `.lower_order_nums`, `.model_outputs`,
+    `.scale_model_input`, `.convert_model_output`, `._init_step_index`, the two DPM-Solver++ update functions.
+    diffusers is un-vendored: restated from the published scheduler (exponential sigma schedule, EDM preconditioning,
+    sde-dpmsolver++ midpoint); host-side fp32 tables.  The native loops do not call the update methods -- they read
+    `sa_coefficient_table` -- the methods serve host-driven callers and keep the object drop-in."""
+
+    def __init__(self, sigma_min=0.3, sigma_max=500.0, sigma_data=1.0, sigma_schedule="exponential",
+                 num_train_timesteps=1000, solver_order=2, prediction_type="v_prediction", rho=7.0,
+                 solver_type="midpoint", lower_order_final=True, euler_at_final=False, final_sigmas_type="zero",
+                 **_ignored):
+        if solver_order not in (1, 2):
+            raise NotImplementedError(f"solver_order={solver_order}")
+        if prediction_type not in ("v_prediction", "epsilon"):
+            raise NotImplementedError(f"prediction_type={prediction_type}")
+        self.config = SimpleNamespace(sigma_min=sigma_min, sigma_max=sigma_max, sigma_data=sigma_data,
+                                      sigma_schedule=sigma_schedule, num_train_timesteps=num_train_timesteps,
+                                      solver_order=solver_order, prediction_type=prediction_type, rho=rho,
+                                      solver_type=solver_type, lower_order_final=lower_order_final,
+                                      euler_at_final=euler_at_final, final_sigmas_type=final_sigmas_type)
+        self.num_inference_steps = None
+        self.set_timesteps(num_train_timesteps)
+
+    @classmethod
+    def from_config(cls, cfg):
+        return cls(**{k: v for k, v in cfg.items() if not k.startswith("_")})
+
+    @property
+    def step_index(self):
+        return self._step_index
+
+    @property
+    def init_noise_sigma(self):
+        return (self.config.sigma_max ** 2 + 1) ** 0.5
+
+    def precondition_noise(self, sigma):
+        if not isinstance(sigma, torch.Tensor):
+            sigma = torch.tensor([sigma])
+        return sigma.atan() / np.pi * 2
+
+    def set_timesteps(self, num_inference_steps, device=None):
+        c = self.config
+        self.num_inference_steps = num_inference_steps
+        if c.sigma_schedule == "exponential":
+            sigmas = torch.linspace(np.log(c.sigma_min), np.log(c.sigma_max), num_inference_steps).exp().flip(0)
+        elif c.sigma_schedule == "karras":
+            ramp = torch.linspace(0, 1, num_inference_steps)
+            lo, hi = c.sigma_min ** (1 / c.rho), c.sigma_max ** (1 / c.rho)
+            sigmas = (hi + ramp * (lo - hi)) ** c.rho
+        else:
+            raise ValueError(f"sigma_schedule={c.sigma_schedule}")
+        sigmas = sigmas.to(torch.float32)
+        self.timesteps = self.precondition_noise(sigmas)
+        if device is not None:
+            self.timesteps = self.timesteps.to(device)
+        last = c.sigma_min if c.final_sigmas_type == "sigma_min" else 0.0
+        self.sigmas = torch.cat([sigmas, torch.tensor([last], dtype=torch.float32)])       # host table
+        self.model_outputs = [None] * c.solver_order
+        self.lower_order_nums = 0
+        self._step_index = None
+        self._begin_index = None
+        self.noise_sampler = None
+
+    def index_for_timestep(self, timestep, schedule_timesteps=None):
+        ts = self.timesteps if schedule_timesteps is None else schedule_timesteps
+        idx = (ts.cpu() == torch.as_tensor(timestep).cpu()).nonzero()
+        return idx[1 if len(idx) > 1 else 0].item()
+
+    def _init_step_index(self, timestep):
+        self._step_index = self.index_for_timestep(timestep) if self._begin_index is None else self._begin_index
+
+    def scale_model_input(self, sample, timestep):
+        if self.step_index is None:
+            self._init_step_index(timestep)
+        sigma = self.sigmas[self.step_index]
+        return sample * float(1 / ((sigma ** 2 + self.config.sigma_data ** 2) ** 0.5))
+
+    def convert_model_output(self, model_output, sample=None):
+        c = sa_step_coefficients(self, self.step_index, 1)
+        return float(c[1]) * sample + float(c[2]) * model_output
+
+    def dpm_solver_first_order_update(self, model_output, sample=None, noise=None):
+        c = sa_step_coefficients(self, self.step_index, 1)
+        return (float(c[3]) * sample + float(c[4]) * model_output) + float(c[5]) * noise
+
+    def multistep_dpm_solver_second_order_update(self, model_output_list, sample=None, noise=None):
+        c = sa_step_coefficients(self, self.step_index, 2)
+        m0, m1 = model_output_list[-1], model_output_list[-2]
+        D1 = float(c[6]) * (m0 - m1)
+        return ((float(c[3]) * sample + float(c[4]) * m0) + (0.5 * float(c[4])) * D1) + float(c[5]) * noise
+
+
+def sa_step_coefficients(sched, i, order, zero_z=False):
+    """One row of the AED_SA_COEF_STRIDE table (include/aed.h) for step index i, fp32 0-dim-tensor arithmetic in the
+    expression order of models.py:1238-1255 and the scheduler's precondition_* / update functions."""
+    from ._lib import SA_COEF_STRIDE
+    sig, sd = sched.sigmas, sched.config.sigma_data
+    s_s, s_t = sig[i], sig[i + 1]
+    c = torch.zeros(SA_COEF_STRIDE, dtype=torch.float32)
+    c[0] = 1 / ((s_s ** 2 + sd ** 2) ** 0.5)
+    c[1] = sd ** 2 / (s_s ** 2 + sd ** 2)
+    if sched.config.prediction_type == "v_prediction":
+        c[2] = -s_s * sd / (s_s ** 2 + sd ** 2) ** 0.5
+    else:
+        c[2] = s_s * sd / (s_s ** 2 + sd ** 2) ** 0.5
+    h = torch.log(s_s) - torch.log(s_t)
+    c[3] = s_t / s_s * torch.exp(-h)
+    c[4] = 1 - torch.exp(-2.0 * h)
+    c[5] = s_t * torch.sqrt(1.0 - torch.exp(-2 * h))
+    if order == 2:
+        h_0 = torch.log(sig[i - 1]) - torch.log(s_s)
+        c[6] = 1.0 / (h_0 / h)
+    c[7] = float(order)
+    c[8] = 1.0 if zero_z else 0.0
+    c[9] = (2 * np.pi * sched.timesteps[i].cpu().float())          # the DiT's Fourier-feature argument
+    return c
+
+
+def sa_step_orders(sched, start, n_steps, lower_order_nums, first_order=False):
+    """Solver order of each of `n_steps` consecutive steps from step index `start`, following the branch conditions of
+    models.py:1225-1242 / :1289-1319 (first order when forced, while no history exists, and at the final step)."""
+    cfgs = sched.config
+    n = len(sched.timesteps)
+    out = []
+    for i in range(start, start + n_steps):
+        final = (i == n - 1) and (cfgs.euler_at_final or (cfgs.lower_order_final and n < 15)
+                                  or cfgs.final_sigmas_type == "zero")
+        first = first_order or cfgs.solver_order == 1 or lower_order_nums < 1 or final
+        out.append(1 if first else 2)
+        if lower_order_nums < cfgs.solver_order:
+            lower_order_nums += 1
+    return out
+
+
+def sa_coefficient_table(sched, start, n_steps, lower_order_nums, first_order=False, invert=False):
+    """[n_steps, AED_SA_COEF_STRIDE]; `invert` marks the step whose noise is defined as zero (models.py:1235-1236)."""
+    n = len(sched.timesteps)
+    orders = sa_step_orders(sched, start, n_steps, lower_order_nums, first_order)
+    rows = [sa_step_coefficients(sched, start + k, orders[k],
+                                 zero_z=invert and (start + k == n - 1) and sched.config.final_sigmas_type == "zero")
+            for k in range(n_steps)]
+    return torch.stack(rows).contiguous()

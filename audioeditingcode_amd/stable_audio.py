@@ -1,0 +1,612 @@
+"""Stable Audio Open 1.0 on the op tape (SURVEY 8(f) row 4 / BASELINE config 5): the DiT backbone, the Oobleck VAE and
+the device-resident inversion / edit loops of StableAudWrapper (/root/reference/code/models.py:1051-1354).
+
+What the reference does per diffusion step (ddm_inversion/inversion_utils.py:74-129, :221-315 on the 3-D latent path):
+`scheduler.scale_model_input`, two batch-1 DiT calls through diffusers, the scheduler's `convert_model_output`, the
+history shuffle of `scheduler.model_outputs`, the SDE-DPM-Solver++ formula (models.py:1238-1255) and a host-side step
+counter.  Here one step is one fixed launch sequence -- scaled broadcast of x_t into the cond / uncond rows, the DiT op
+tape, ONE fused kernel for CFG + data prediction + solver update + history (AED_OP_SA_STEP) -- indexed on the device by a
+step counter and replayed as a hipGraph.
+
+The DiT graph (diffusers StableAudioDiTModel, un-vendored: restated, see oracle/stable_audio.py) on this engine:
+  * preprocess_conv (+identity) o proj_in and proj_out o postprocess_conv (+identity) are exact linear maps: folded into
+    one weight each on the host (fp64), so the prologue / epilogue are one GEMM each;
+  * every LayerNorm is folded into the GEMM that consumes it (row statistics gathered in the A loader);
+  * SwiGLU rides in the FF1 epilogue (packed [32 value | 32 gate] rows, the GEGLU machinery with a SiLU gate);
+  * grouped-query cross-attention = full-head attention over K/V projected with head-repeated weights -- per prompt, on
+    the context tape, not per step;
+  * rotary embedding: one in-place pass over q and k of the fused qkv buffer (AED_OP_ROTARY).
+Activations are channels-last ([B, L, C]); the reference's [B, C, L] only at the wrapper boundary.
+"""
+import math
+
+import torch
+
+from . import _lib as L
+from .scheduler import sa_coefficient_table
+from .tape import Tape
+from .unet import geglu_pack_index
+
+
+# =============================================================================================== DiT
+class PackedDiTWeights:
+    """Device-resident, engine-layout copy of a diffusers-named StableAudioDiTModel state dict."""
+
+    def __init__(self, sd, cfg, device):
+        self.device = torch.device(device)
+        self.cfg = cfg
+        self.wd = {}
+        self._pack(sd)
+
+    def _dev(self, t):
+        return t.contiguous().to(self.device, torch.float32)
+
+    def nbytes(self):
+        return sum(v.numel() * 4 for v in self.wd.values())
+
+    def _fold_ln(self, name, w, gamma, beta, bias):
+        w64, g64, b64 = w.double(), gamma.double(), beta.double()
+        wf = w64 * g64[None, :]
+        t = w64 @ b64
+        if bias is not None:
+            t = t + bias.double()
+        self.wd[name + ".weight"] = self._dev(wf.float())
+        self.wd[name + ".rowsum"] = self._dev(wf.float().double().sum(1).float())
+        self.wd[name + ".t"] = self._dev(t.float())
+
+    def _pack(self, sd):
+        cfg, wd = self.cfg, self.wd
+        H, KV, D = cfg["num_attention_heads"], cfg["num_key_value_attention_heads"], cfg["attention_head_dim"]
+        rep = H // KV
+        for k in ("time_proj.weight", "timestep_proj.0.weight", "timestep_proj.0.bias", "timestep_proj.2.weight",
+                  "timestep_proj.2.bias", "global_proj.0.weight", "global_proj.2.weight",
+                  "cross_attention_proj.0.weight", "cross_attention_proj.2.weight"):
+            wd[k] = self._dev(sd[k])
+        eye_in = torch.eye(cfg["in_channels"], dtype=torch.float64)
+        eye_out = torch.eye(cfg["out_channels"], dtype=torch.float64)
+        wpre = sd["preprocess_conv.weight"].double().reshape(cfg["in_channels"], cfg["in_channels"])
+        wpost = sd["postprocess_conv.weight"].double().reshape(cfg["out_channels"], cfg["out_channels"])
+        wd["in.weight"] = self._dev((sd["proj_in.weight"].double() @ (wpre + eye_in)).float())          # [C, cin]
+        wd["out.weight"] = self._dev(((wpost + eye_out) @ sd["proj_out.weight"].double()).float())       # [cout, C]
+        for i in range(cfg["num_layers"]):
+            p, b = f"transformer_blocks.{i}.", f"b{i}."
+            wqkv = torch.cat([sd[p + "attn1.to_q.weight"], sd[p + "attn1.to_k.weight"], sd[p + "attn1.to_v.weight"]], 0)
+            self._fold_ln(b + "qkv_ln", wqkv, sd[p + "norm1.weight"], sd[p + "norm1.bias"], None)
+            wd[b + "attn1.out.weight"] = self._dev(sd[p + "attn1.to_out.0.weight"])
+            self._fold_ln(b + "q2_ln", sd[p + "attn2.to_q.weight"], sd[p + "norm2.weight"], sd[p + "norm2.bias"], None)
+            dc = sd[p + "attn2.to_k.weight"].shape[1]
+            wk = sd[p + "attn2.to_k.weight"].reshape(KV, D, dc).repeat_interleave(rep, 0).reshape(H * D, dc)
+            wv = sd[p + "attn2.to_v.weight"].reshape(KV, D, dc).repeat_interleave(rep, 0).reshape(H * D, dc)
+            wd[b + "kv2.weight"] = self._dev(torch.cat([wk, wv], 0))                    # grouped-query heads repeated
+            wd[b + "attn2.out.weight"] = self._dev(sd[p + "attn2.to_out.0.weight"])
+            w1, b1 = sd[p + "ff.net.0.proj.weight"], sd[p + "ff.net.0.proj.bias"]
+            perm = geglu_pack_index(w1.shape[0] // 2)
+            self._fold_ln(b + "ff1g_ln", w1[perm], sd[p + "norm3.weight"], sd[p + "norm3.bias"], b1[perm])
+            wd[b + "ff2.weight"] = self._dev(sd[p + "ff.net.2.weight"])
+            wd[b + "ff2.bias"] = self._dev(sd[p + "ff.net.2.bias"])
+
+
+def rotary_tables(dim, n, theta=10000.0):
+    """cos / sin [n, dim/2] of get_1d_rotary_pos_embed(dim, n, use_real=True, repeat_interleave_real=False)
+    (models.py:1167-1172; the two halves of that table are equal, one is kept)."""
+    freqs = 1.0 / (theta ** (torch.arange(0, dim, 2)[: dim // 2].float() / dim))
+    ang = torch.outer(torch.arange(n).float(), freqs)
+    return ang.cos().contiguous(), ang.sin().contiguous()
+
+
+class DiTEngine:
+    """StableAudioDiTModel.forward for a fixed batch as an op tape.
+
+    Inputs (persistent device buffers): x_in [B, L, Cin] (already input-scaled), ctx_in [B, S, Dc_in] (text | seconds_start
+    | seconds_end states, all-zero rows for the unconditional pass, models.py:1340-1343), glob_in [B, Dg] (audio duration
+    embeds).  The continuous timestep of row b is read on the device: time_dev[state*tgroup + row_tidx[b]] (fp32 table of
+    2*pi*t, one entry per step of the loop).  Output: v [B, L, Cout]."""
+
+    def __init__(self, cfg, weights, device, batch, ctx_len, time_dev=None, state_dev=None, tgroup=1, rows_per_t=None):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        if not isinstance(weights, PackedDiTWeights):
+            weights = PackedDiTWeights(weights, cfg, device)
+        self.weights, self.wd = weights, weights.wd
+        self.B, self.S = batch, ctx_len
+        self.L = cfg["sample_size"]
+        self.time_dev, self.state_dev = time_dev, state_dev
+        self.tgroup = tgroup
+        self.rows_per_t = rows_per_t or batch
+        self.tape = Tape(device)
+        self.ctx_tape = Tape(device)
+        self._build()
+
+    def _build(self):
+        cfg, tp, ct, wd, B, Lz, S = self.cfg, self.tape, self.ctx_tape, self.wd, self.B, self.L, self.S
+        H, D = cfg["num_attention_heads"], cfg["attention_head_dim"]
+        C = H * D
+        cin, cout, dc = cfg["in_channels"], cfg["out_channels"], cfg["cross_attention_dim"]
+        dci, dg, tpd = cfg["cross_attention_input_dim"], cfg["global_states_input_dim"], cfg["time_proj_dim"]
+        dff = wd["b0.ff2.weight"].shape[1]
+        N1 = Lz + 1                                    # the global token is prepended to the sequence
+        M = B * N1
+        self.x_in = tp.alloc(B, Lz, cin, zero=True)
+        self.ctx_in = tp.alloc(B, S, dci, zero=True)
+        self.glob_in = tp.alloc(B, dg, zero=True)
+        self.v = tp.alloc(B, Lz, cout)
+
+        # ---- per-prompt tape: cross_attention_proj, global_proj, K/V of every block
+        ca1 = ct.alloc(B * S, dc)
+        ct.linear(self.ctx_in.view(B * S, dci), wd["cross_attention_proj.0.weight"], None, ca1, M=B * S, K=dci, N=dc,
+                  out_act=L.ACT_SILU, name="cross_attention_proj.0")
+        ca = ct.alloc(B * S, dc)
+        ct.linear(ca1, wd["cross_attention_proj.2.weight"], None, ca, M=B * S, K=dc, N=dc, name="cross_attention_proj.2")
+        g1 = ct.alloc(B, C)
+        ct.linear(self.glob_in, wd["global_proj.0.weight"], None, g1, M=B, K=dg, N=C, out_act=L.ACT_SILU,
+                  name="global_proj.0")
+        self.gproj = ct.alloc(B, C)
+        ct.linear(g1, wd["global_proj.2.weight"], None, self.gproj, M=B, K=C, N=C, name="global_proj.2")
+        kvs = []
+        for i in range(cfg["num_layers"]):
+            kv = ct.alloc(B * S, 2 * C)
+            ct.linear(ca, wd[f"b{i}.kv2.weight"], None, kv, M=B * S, K=dc, N=2 * C, name=f"b{i}.attn2.kv")
+            kvs.append(kv)
+
+        # ---- per-step tape
+        tfeat = tp.alloc(B, tpd)
+        self.row_tidx = (torch.arange(B, dtype=torch.int32) // max(1, self.rows_per_t)).to(self.device)
+        self.time_op = len(tp.ops)
+        if self.time_dev is None:                      # stand-alone use (tests, profiling): a one-entry table
+            self.time_dev = torch.zeros(1, dtype=torch.float32, device=self.device)
+        tp.time_embed(tfeat, B=B, dim=tpd, flip=True, timesteps=self.time_dev, state=self.state_dev,
+                      freqs=wd["time_proj.weight"], float_table=True, name="time_proj")
+        self._patch_time_op(tp.ops[self.time_op])
+        t1 = tp.alloc(B, C)
+        tp.linear(tfeat, wd["timestep_proj.0.weight"], wd["timestep_proj.0.bias"], t1, M=B, K=tpd, N=C,
+                  out_act=L.ACT_SILU, name="timestep_proj.0")
+        ha, hb = tp.alloc(B, N1, C), tp.alloc(B, N1, C)
+        # row (b, 0) = global_proj(duration embeds) + timestep_proj(time features)
+        tp.conv(t1, wd["timestep_proj.2.weight"], wd["timestep_proj.2.bias"], ha, B=B, IH=1, IW=1, Cin=C, OH=1, OW=1,
+                N=C, rowvec=self.gproj, ld_rv=C, o_len=N1, out_bs=N1, ldc=C, name="timestep_proj.2+global")
+        # rows (b, 1..L) = proj_in(preprocess_conv(x) + x), one folded GEMM
+        tp.conv(self.x_in, wd["in.weight"], None, ha, B=B, IH=Lz, IW=1, Cin=cin, OH=Lz, OW=1, N=C, o_add=1, o_len=N1,
+                out_bs=N1, ldc=C, name="preprocess+proj_in")
+        self.rot_cos, self.rot_sin = (t.to(self.device) for t in rotary_tables(D // 2, N1))
+        qkv = tp.alloc(M, 3 * C)
+        o = tp.alloc(M, C)
+        q2 = tp.alloc(M, C)
+        f = tp.alloc(M, dff)
+        h, hn = ha.view(M, C), hb.view(M, C)
+        for i in range(cfg["num_layers"]):
+            b = f"b{i}."
+            tp.linear(h, wd[b + "qkv_ln.weight"], wd[b + "qkv_ln.t"], qkv, M=M, K=C, N=3 * C,
+                      ln_rowsum=wd[b + "qkv_ln.rowsum"], name=b + "qkv+ln")
+            tp.rotary(qkv, self.rot_cos, self.rot_sin, M=M, N=N1, H=H, D=D, R=D // 2, nsec=2, sec_stride=C,
+                      name=b + "rotary")
+            tp.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], o, B=B, H=H, Nq=N1, Nk=N1, D=D, ldq=3 * C, ldk=3 * C,
+                         ldv=3 * C, ldo=C, bsq=N1 * 3 * C, bsk=N1 * 3 * C, bsv=N1 * 3 * C, bso=N1 * C, scale=D ** -0.5,
+                         name=b + "attn1.sdpa")
+            tp.linear(o, wd[b + "attn1.out.weight"], None, hn, M=M, K=C, N=C, res=h, name=b + "attn1.to_out")
+            h, hn = hn, h
+            tp.linear(h, wd[b + "q2_ln.weight"], wd[b + "q2_ln.t"], q2, M=M, K=C, N=C,
+                      ln_rowsum=wd[b + "q2_ln.rowsum"], name=b + "attn2.q+ln")
+            kv = kvs[i]
+            tp.attention(q2, kv, kv[:, C:], o, B=B, H=H, Nq=N1, Nk=S, D=D, ldq=C, ldk=2 * C, ldv=2 * C, ldo=C,
+                         bsq=N1 * C, bsk=S * 2 * C, bsv=S * 2 * C, bso=N1 * C, scale=D ** -0.5, name=b + "attn2.sdpa_x")
+            tp.linear(o, wd[b + "attn2.out.weight"], None, hn, M=M, K=C, N=C, res=h, name=b + "attn2.to_out")
+            h, hn = hn, h
+            tp.linear(h, wd[b + "ff1g_ln.weight"], wd[b + "ff1g_ln.t"], f, M=M, K=C, N=2 * dff,
+                      ln_rowsum=wd[b + "ff1g_ln.rowsum"], geglu=2, name=b + "ff1+ln+swiglu")
+            tp.linear(f, wd[b + "ff2.weight"], wd[b + "ff2.bias"], hn, M=M, K=dff, N=C, res=h, name=b + "ff2")
+            h, hn = hn, h
+        # v = postprocess_conv(y) + y with y = proj_out(h)[rows 1..L], one folded GEMM over the token rows
+        tp.conv(h.view(-1)[C:], wd["out.weight"], None, self.v, B=B, IH=Lz, IW=1, Cin=C, OH=Lz, OW=1, N=cout, lda=C,
+                a_bs=N1 * C, name="proj_out+postprocess")
+        tp.finalize()
+        ct.finalize()
+        self._patch_time_op(tp.finalize()[self.time_op])
+
+    def _patch_time_op(self, op):
+        """One timestep per group of `rows_per_t` batch rows, `tgroup` timesteps per call."""
+        op.p[4] = self.row_tidx.data_ptr()
+        op.i[5] = self.tgroup
+
+    @torch.inference_mode()
+    def set_conditioning(self, ctx, glob):
+        """ctx [B, S, Dc_in], glob [B, Dg] -> device buffers + the per-prompt tape (once per prompt set)."""
+        self.ctx_in.copy_(ctx.to(self.device, torch.float32).reshape(self.ctx_in.shape))
+        self.glob_in.copy_(glob.to(self.device, torch.float32).reshape(self.glob_in.shape))
+        self.ctx_tape.run()
+
+    def set_timestep(self, t):
+        """Stand-alone use: the continuous timestep of every row (a float, as in scheduler.timesteps)."""
+        self.time_dev[:1] = 2 * math.pi * torch.as_tensor(t, dtype=torch.float32).reshape(1)
+
+    @torch.inference_mode()
+    def forward(self):
+        self.tape.run()
+        return self.v
+
+
+# =============================================================================================== Oobleck VAE
+def _c1d(w):
+    return w.permute(0, 2, 1).reshape(w.shape[0], -1)          # Conv1d [Co, Ci, k] -> [Co, k*Ci] (tap-major rows)
+
+
+class _OobleckBase:
+    def __init__(self, cfg, sd, device, batch):
+        self.cfg, self.sd, self.B = cfg, sd, batch
+        self.device = torch.device(device)
+        self.tape = Tape(device)
+        self._tmp = {}
+        self._w = {}
+
+    def dev(self, t):
+        return t.contiguous().to(self.device, torch.float32)
+
+    def tmp(self, tag, *shape):
+        key = (tag, tuple(shape))
+        if key not in self._tmp:
+            self._tmp[key] = self.tape.alloc(*shape)
+        return self._tmp[key]
+
+    def snake(self, p, x, Lc, C, tag="sn"):
+        """Snake1d: host pre-computes a = exp(alpha), 1/(exp(beta) + 1e-9) once; one elementwise pass."""
+        if p not in self._w:
+            a = torch.exp(self.sd[p + ".alpha"].float()).reshape(-1)
+            ib = (torch.exp(self.sd[p + ".beta"].float()).reshape(-1) + 1e-9).reciprocal()
+            self._w[p] = (self.dev(a), self.dev(ib))
+        out = self.tmp(tag, self.B, Lc, C)
+        a, ib = self._w[p]
+        self.tape.snake(x, out, a, ib, rows=self.B * Lc, C=C, name=p)
+        return out
+
+    def conv(self, p, x, Lc, Cin, Cout, k, out, stride=1, dilation=1, pad=0, res=None, bias=True):
+        Lo = (Lc + 2 * pad - dilation * (k - 1) - 1) // stride + 1
+        w = self.dev(_c1d(self.sd[p + ".weight"]))
+        b = self.dev(self.sd[p + ".bias"]) if bias else None
+        self.tape.conv(x, w, b, out, B=self.B, IH=Lc, IW=1, Cin=Cin, OH=Lo, OW=1, N=Cout, KH=k, KW=1, stride=stride,
+                       pad_h=pad, dil_h=dilation, res=res, name=p)
+        return Lo
+
+    def res_unit(self, p, x, Lc, C, dilation, out):
+        """OobleckResidualUnit: x + conv1x1(snake(conv7_dilated(snake(x)))) (same length: pad = 3*dilation)."""
+        a = self.snake(p + ".snake1", x, Lc, C, "ru_a")
+        y = self.tmp("ru_y", self.B, Lc, C)
+        self.conv(p + ".conv1", a, Lc, C, C, 7, y, dilation=dilation, pad=3 * dilation)
+        a2 = self.snake(p + ".snake2", y, Lc, C, "ru_a2")
+        self.conv(p + ".conv2", a2, Lc, C, C, 1, out, res=x)
+        return out
+
+
+class OobleckEncoder(_OobleckBase):
+    """AutoencoderOobleck.encode: audio [B, L, Ca] (channels-last) -> moments [B, L/hop, 2*latent] (mean | scale)."""
+
+    def __init__(self, cfg, sd, device, batch, length):
+        super().__init__(cfg, sd, device, batch)
+        tp, B = self.tape, batch
+        hid, ca = cfg["encoder_hidden_size"], cfg["audio_channels"]
+        mult = [1] + list(cfg["channel_multiples"])
+        self.audio_in = tp.alloc(B, length, ca, zero=True)
+        Lc, ch = length, hid
+        h = tp.alloc(B, Lc, ch)
+        self.conv("encoder.conv1", self.audio_in, Lc, ca, ch, 7, h, pad=3)
+        for i, st in enumerate(cfg["downsampling_ratios"]):
+            p = f"encoder.block.{i}"
+            co = hid * mult[i + 1]
+            for j, dil in enumerate((1, 3, 9)):
+                d = tp.alloc(B, Lc, ch)
+                h = self.res_unit(f"{p}.res_unit{j + 1}", h, Lc, ch, dil, d)
+            a = self.snake(p + ".snake1", h, Lc, ch, "blk_a")
+            Lo = (Lc + 2 * math.ceil(st / 2) - 2 * st) // st + 1
+            d = tp.alloc(B, Lo, co)
+            self.conv(p + ".conv1", a, Lc, ch, co, 2 * st, d, stride=st, pad=math.ceil(st / 2))
+            h, Lc, ch = d, Lo, co
+        a = self.snake("encoder.snake1", h, Lc, ch, "blk_a")
+        lat2 = 2 * cfg["decoder_input_channels"]
+        self.moments = tp.alloc(B, Lc, lat2)
+        self.conv("encoder.conv2", a, Lc, ch, lat2, 3, self.moments, pad=1)
+        self.L_out = Lc
+        self.noise = tp.alloc(B, Lc, lat2 // 2, zero=True)
+        self.latent = tp.alloc(B, Lc, lat2 // 2)
+        self.sample_tape = Tape(device)
+        self.sample_tape.gauss_sample(self.moments.view(B * Lc, lat2), self.noise, self.latent, rows=B * Lc, C=lat2 // 2)
+        tp.finalize()
+        self.sample_tape.finalize()
+
+    @torch.inference_mode()
+    def __call__(self, audio_blc, noise_blc=None):
+        """Returns the sampled latent [B, Lz, latent] (posterior mean when noise is None)."""
+        self.audio_in.copy_(audio_blc.to(self.device, torch.float32).reshape(self.audio_in.shape))
+        self.tape.run()
+        if noise_blc is None:
+            return self.moments[..., : self.latent.shape[-1]].contiguous()
+        self.noise.copy_(noise_blc.to(self.device, torch.float32).reshape(self.noise.shape))
+        self.sample_tape.run()
+        return self.latent
+
+
+class OobleckDecoder(_OobleckBase):
+    """AutoencoderOobleck.decode: latent [B, Lz, latent] -> audio [B, Lz*hop, Ca]."""
+
+    def __init__(self, cfg, sd, device, batch, length):
+        super().__init__(cfg, sd, device, batch)
+        tp, B = self.tape, batch
+        dch, ca, lat = cfg["decoder_channels"], cfg["audio_channels"], cfg["decoder_input_channels"]
+        mult = [1] + list(cfg["channel_multiples"])
+        ratios = list(cfg["downsampling_ratios"])[::-1]
+        self.z_in = tp.alloc(B, length, lat, zero=True)
+        Lc, ch = length, dch * mult[-1]
+        h = tp.alloc(B, Lc, ch)
+        self.conv("decoder.conv1", self.z_in, Lc, lat, ch, 7, h, pad=3)
+        for i, st in enumerate(ratios):
+            p = f"decoder.block.{i}"
+            co = dch * mult[len(ratios) - i - 1]
+            a = self.snake(p + ".snake1", h, Lc, ch, "blk_a")
+            # ConvTranspose1d(k = 2*stride, stride, pad = ceil(stride/2)) as `stride` phase convolutions: phase r owns
+            # taps r, r+stride and writes output positions stride*q + r - pad (the HiFi-GAN recipe, codec.py)
+            k, pad = 2 * st, math.ceil(st / 2)
+            Lo = (Lc - 1) * st - 2 * pad + k
+            up = tp.alloc(B, Lo, co)
+            w = self.sd[p + ".conv_t1.weight"]                        # [Cin, Cout, k]
+            bias = self.dev(self.sd[p + ".conv_t1.bias"])
+            for r in range(st):
+                taps = list(range(r, k, st))
+                wr = self.dev(torch.stack([w[:, :, j] for j in taps], 0).permute(2, 0, 1).reshape(co, -1))
+                Q = Lc + len(taps) - 1
+                tp.conv(a, wr, bias, up, B=B, IH=Lc, IW=1, Cin=ch, OH=Q, OW=1, N=co, KH=len(taps), KW=1, pad_h=0,
+                        dil_h=-1, o_mul=st, o_add=r - pad, o_len=Lo, out_bs=Lo, name=f"{p}.conv_t1.phase{r}")
+            h, Lc, ch = up, Lo, co
+            for j, dil in enumerate((1, 3, 9)):
+                d = tp.alloc(B, Lc, ch)
+                h = self.res_unit(f"{p}.res_unit{j + 1}", h, Lc, ch, dil, d)
+        a = self.snake("decoder.snake1", h, Lc, ch, "blk_a")
+        self.audio = tp.alloc(B, Lc, ca)
+        self.conv("decoder.conv2", a, Lc, ch, ca, 7, self.audio, pad=3, bias=False)
+        self.L_out = Lc
+        tp.finalize()
+
+    @torch.inference_mode()
+    def __call__(self, z_blc):
+        self.z_in.copy_(z_blc.to(self.device, torch.float32).reshape(self.z_in.shape))
+        self.tape.run()
+        return self.audio
+
+
+# =============================================================================================== loops
+class StableAudioEditEngine:
+    """Device-resident inversion / edit loops of the Stable Audio wrapper for ONE clip and ONE prompt per pass (the
+    reference's DiT call cannot take more: its global token is batch 1, models.py:1345-1349).
+
+    DiT batch rows per timestep: [uncond | cond] (cond dropped for an empty source prompt, inversion_utils.py:86).
+    `mode="batched"` runs G timesteps per DiT call in the forward inversion -- legal for the same reason as in
+    editing.py: every x_t is drawn independently from x_0 (models.py:1186-1207), the solver history only enters the
+    elementwise step math, which stays sequential (G fused step kernels after each DiT call)."""
+
+    def __init__(self, dit_cfg, weights, scheduler, device):
+        self.cfg, self.sched, self.device = dit_cfg, scheduler, torch.device(device)
+        self.C, self.Lz = dit_cfg["in_channels"], dit_cfg["sample_size"]
+        self.weights = weights if isinstance(weights, PackedDiTWeights) else PackedDiTWeights(weights, dit_cfg, device)
+        self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        self.state = torch.zeros(4, dtype=torch.int32, device=self.device)
+        self._plans = {}
+        self.max_plans = 4
+
+    # ------------------------------------------------------------------ plumbing shared with editing.EditEngine
+    def _drop_plan(self, key):
+        old = self._plans.pop(key)
+        g = old.get("graph")
+        if g is not None:
+            if self.stream is not None:
+                self.stream.synchronize()
+            L.check(L.lib().aed_graph_destroy(g), "aed_graph_destroy")
+
+    def _get_plan(self, key):
+        plan = self._plans.pop(key, None)
+        if plan is not None:
+            self._plans[key] = plan
+            return plan
+        while self._plans and len(self._plans) >= self.max_plans:
+            self._drop_plan(next(iter(self._plans)))
+        return None
+
+    def clear_plans(self):
+        for key in list(self._plans):
+            self._drop_plan(key)
+
+    def _run_graph(self, body, steps, use_graph=True, plan=None):
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            if use_graph and steps > 1:
+                g = plan.get("graph") if plan is not None else None
+                if g is None:
+                    g = Tape.graph_capture(body)
+                    if plan is not None:
+                        plan["graph"] = g
+                ev0.record(self.stream)
+                for _ in range(steps):
+                    Tape.graph_replay(g)
+                ev1.record(self.stream)
+                if plan is None:
+                    self.stream.synchronize()
+                    L.check(L.lib().aed_graph_destroy(g), "aed_graph_destroy")
+            else:
+                ev0.record(self.stream)
+                for _ in range(steps):
+                    body()
+                ev1.record(self.stream)
+            self._last_events = (ev0, ev1)
+        cur.wait_stream(self.stream)
+
+    def last_loop_ms(self):
+        ev0, ev1 = self._last_events
+        ev1.synchronize()
+        return ev0.elapsed_time(ev1)
+
+    @torch.inference_mode()
+    def to_lc(self, x, out=None):
+        """[..., C, L] -> contiguous [..., L, C] on the device."""
+        lead = x.shape[:-2]
+        C, Lz = x.shape[-2:]
+        src = x.to(self.device, torch.float32).contiguous()
+        dst = out if out is not None else torch.empty(*lead, Lz, C, device=self.device, dtype=torch.float32)
+        tp = Tape(self.device)
+        tp.transpose(src, dst, Bt=max(1, math.prod(lead)), R=C, C=Lz)
+        tp.run()
+        return dst
+
+    @torch.inference_mode()
+    def to_cl(self, x):
+        lead = x.shape[:-2]
+        Lz, C = x.shape[-2:]
+        dst = torch.empty(*lead, C, Lz, device=self.device, dtype=torch.float32)
+        tp = Tape(self.device)
+        tp.transpose(x.contiguous(), dst, Bt=max(1, math.prod(lead)), R=Lz, C=C)
+        tp.run()
+        return dst
+
+    # ------------------------------------------------------------------ sample_xts_from_x0 (models.py:1186-1207)
+    @torch.inference_mode()
+    def sample_xts(self, x0, noise=None, generator=None):
+        """x0 [1, C, L]; noise [T, 1, C, L] drawn on the CPU generator in the reference's order (ascending t, one randn per
+        step) when not given.  Returns xts [T+1, 1, C, L] on the device: x_t = x0 + n * sigma_t."""
+        s = self.sched
+        T = s.num_inference_steps
+        x0 = x0.to(self.device, torch.float32).contiguous()
+        if noise is None:
+            noise = torch.stack([torch.randn(x0.shape, generator=generator, dtype=torch.float32) for _ in range(T)])
+        noise = noise.to(self.device, torch.float32).contiguous()
+        # row r <-> idx = r+1 <-> step index T - idx
+        sig = torch.stack([s.sigmas[T - (r + 1)] for r in range(T)]).to(self.device)
+        one = torch.ones(T, device=self.device, dtype=torch.float32)
+        xts = torch.empty((T + 1, *x0.shape), device=self.device, dtype=torch.float32)
+        xts[0] = x0
+        L.check(L.lib().aed_sample_xts_from_x0(x0.data_ptr(), noise.data_ptr(), one.data_ptr(), sig.data_ptr(),
+                                                xts[1:].data_ptr(), T, x0.numel(), L.current_stream_ptr()),
+                "aed_sample_xts_from_x0")
+        return xts
+
+    def _dit(self, B, S, tt, tgroup, rows_per_t):
+        return DiTEngine(self.cfg, self.weights, self.device, B, S, time_dev=tt, state_dev=self.state, tgroup=tgroup,
+                         rows_per_t=rows_per_t)
+
+    # ------------------------------------------------------------------ forward inversion
+    @torch.inference_mode()
+    def invert(self, x0, ctx_src, ctx_uncond, glob, cfg_src, numerical_fix=True, first_order=False, noise=None,
+               generator=None, xts=None, mode="sequential", group=8, use_graph=True):
+        """inversion_forward_process on the 3-D latent (inversion_utils.py:52-144).  x0 [1,C,L]; ctx_* [1,S,Dc] (already
+        assembled: text | seconds_start | seconds_end; ctx_src None = empty source prompt); glob [1,Dg].
+        Returns (zs [T,L,C], xts [T+1,L,C], extra [T,L,C]) channels-last on the device; extra[idx] is the reference's
+        extra_info[idx] (the previous step's data prediction; row T-1 has none)."""
+        s = self.sched
+        T = s.num_inference_steps
+        numel = self.C * self.Lz
+        if xts is None:
+            xts = self.sample_xts(x0, noise, generator)
+        P = 0 if ctx_src is None else 1
+        rows_per_t = 1 + P
+        G = 1 if mode == "sequential" else max(1, min(group, T))
+        while T % G:
+            G -= 1
+        S = ctx_uncond.shape[1]
+        key = ("invert", P, T, G, S, bool(numerical_fix), bool(first_order), float(cfg_src))
+        plan = self._get_plan(key)
+        if plan is None:
+            plan = self._plans[key] = dict(
+                xts=torch.empty((T + 1, self.Lz, self.C), device=self.device, dtype=torch.float32),
+                zs=torch.zeros((T, self.Lz, self.C), device=self.device, dtype=torch.float32),
+                extra=torch.zeros((T, self.Lz, self.C), device=self.device, dtype=torch.float32),
+                hist=torch.zeros((self.Lz, self.C), device=self.device, dtype=torch.float32),
+                coef=torch.zeros((T, L.SA_COEF_STRIDE), device=self.device, dtype=torch.float32),
+                tt=torch.zeros(T, device=self.device, dtype=torch.float32))
+            eng = plan["eng"] = self._dit(G * rows_per_t, S, plan["tt"], G, rows_per_t)
+            pre, post = Tape(self.device), Tape(self.device)
+            for g in range(G):
+                for blk in range(rows_per_t):
+                    r = g * rows_per_t + blk
+                    pre.copy2d(plan["xts"], eng.x_in[r:r + 1], rows=1, cols=numel, ld_src=numel, ld_dst=numel,
+                               state=self.state, idx_off=T - g, idx_mul=-G, idx_stride=numel, coef=plan["coef"],
+                               c_mul=G, c_off=g, c_stride=L.SA_COEF_STRIDE, c_col=0, name="x_in<-c_in*xts")
+            for g in range(G):
+                base = g * rows_per_t
+                post.sa_step(0, xts=plan["xts"], zs=plan["zs"], v_u=eng.v[base:base + 1],
+                             v_c=eng.v[base + 1:base + 2] if P else None, coef=plan["coef"], state=self.state,
+                             hist=plan["hist"], extra=plan["extra"], numel=numel, T=T, fix=int(numerical_fix),
+                             cfg=float(cfg_src), s_mul=G, s_off=g, name="sa_invert_step")
+            post.advance(self.state)
+            pre.finalize()
+            post.finalize()
+            plan["pre"], plan["post"] = pre, post
+        eng, pre, post = plan["eng"], plan["pre"], plan["post"]
+        self.to_lc(xts.reshape(T + 1, self.C, self.Lz), out=plan["xts"])
+        table = sa_coefficient_table(s, 0, T, 0, first_order=first_order, invert=True)
+        plan["coef"].copy_(table)
+        plan["tt"].copy_(table[:, 9])
+        plan["hist"].zero_()
+        ctx = torch.cat([c for _ in range(G) for c in ([ctx_uncond] + ([ctx_src] if P else []))], 0)
+        eng.set_conditioning(ctx, glob.reshape(1, -1).expand(G * rows_per_t, -1))
+        self.state.zero_()
+
+        def body():
+            pre.run()
+            eng.tape.run()
+            post.run()
+        self._run_graph(body, T // G, use_graph, plan)
+        plan["zs"][0].zero_()                                      # inversion_utils.py:131-133
+        return plan["zs"], plan["xts"], plan["extra"]
+
+    # ------------------------------------------------------------------ reverse / edit
+    @torch.inference_mode()
+    def edit(self, xts, zs, tstart, ctx_tgt, ctx_neg, glob, cfg_tar, extra=None, first_order=False, use_graph=True,
+             n_steps=None, m1=None):
+        """inversion_reverse_process on the 3-D latent (inversion_utils.py:200-316) from x_{tstart} with the noise maps
+        zs[:tstart]; `extra` (the inversion's third output) or `m1` (= extra[tstart-1], [L, C]) re-seeds the solver
+        history (setup_extra_inputs, models.py:1178-1184).
+        xts / zs / extra channels-last as returned by invert().  Returns the edited latent [L, C]."""
+        s = self.sched
+        T = s.num_inference_steps
+        Z = int(tstart)
+        numel = self.C * self.Lz
+        S = ctx_tgt.shape[1]
+        key = ("edit", T, Z, S, bool(first_order), float(cfg_tar))
+        plan = self._get_plan(key)
+        if plan is None:
+            plan = self._plans[key] = dict(
+                cur=torch.empty((self.Lz, self.C), device=self.device, dtype=torch.float32),
+                zs=torch.zeros((Z, self.Lz, self.C), device=self.device, dtype=torch.float32),
+                hist=torch.zeros((self.Lz, self.C), device=self.device, dtype=torch.float32),
+                coef=torch.zeros((Z, L.SA_COEF_STRIDE), device=self.device, dtype=torch.float32),
+                tt=torch.zeros(Z, device=self.device, dtype=torch.float32))
+            eng = plan["eng"] = self._dit(2, S, plan["tt"], 1, 2)
+            pre, post = Tape(self.device), Tape(self.device)
+            for blk in range(2):
+                pre.copy2d(plan["cur"], eng.x_in[blk:blk + 1], rows=1, cols=numel, ld_src=numel, ld_dst=numel,
+                           state=self.state, idx_off=0, idx_mul=0, idx_stride=0, coef=plan["coef"], c_mul=1, c_off=0,
+                           c_stride=L.SA_COEF_STRIDE, c_col=0, name="x_in<-c_in*x_t")
+            post.sa_step(1, xts=plan["cur"], zs=plan["zs"], v_u=eng.v[0:1], v_c=eng.v[1:2], coef=plan["coef"],
+                         state=self.state, hist=plan["hist"], out=plan["cur"], numel=numel, T=Z, cfg=float(cfg_tar),
+                         name="sa_reverse_step")
+            post.advance(self.state)
+            pre.finalize()
+            post.finalize()
+            plan["pre"], plan["post"] = pre, post
+        eng, pre, post, cur = plan["eng"], plan["pre"], plan["post"], plan["cur"]
+        cur.copy_(xts[Z])
+        plan["zs"].copy_(zs[:Z])
+        lon = min(T - Z, s.config.solver_order)                    # models.py:1183-1184
+        if lon >= 1 and not first_order and s.config.solver_order > 1:
+            if extra is None and m1 is None:
+                raise ValueError("a second-order start (tstart < T) needs the inversion's extra_info (models.py:1182)")
+            plan["hist"].copy_(m1 if m1 is not None else extra[Z - 1])
+        else:
+            plan["hist"].zero_()
+        table = sa_coefficient_table(s, T - Z, Z, lon, first_order=first_order)
+        plan["coef"].copy_(table)
+        plan["tt"].copy_(table[:, 9])
+        eng.set_conditioning(torch.cat([ctx_neg, ctx_tgt], 0), glob.reshape(1, -1).expand(2, -1))
+        self.state.zero_()
+
+        def body():
+            pre.run()
+            eng.tape.run()
+            post.run()
+        self._run_graph(body, Z if n_steps is None else max(0, min(int(n_steps), Z)), use_graph, plan)
+        return cur.clone()

@@ -22,7 +22,7 @@ CU_COUNT = 256          # MI355X; tiling heuristics target this, overridable for
 # A/B switch for the K-chunk width of conv_gemm: 0 auto, 1 force 32, 2 allow 64 on the 128x128 tile too
 FORCE_BK = int(os.environ.get("AED_FORCE_BK", "0"))
 ATTN_VARIANT = int(os.environ.get("AED_ATTN_VARIANT", "0"))      # 0 auto (split-KV when Nk > 64), 1 forces single-pass
-GN_VARIANT = 0                                                   # (round-1 A/B switch; one kernel generation remains)
+GN_VARIANT = int(os.environ.get("AED_GN_VARIANT", "0"))          # 1: never use the register-resident single-launch GroupNorm (A/B)
 GN_FORCE_SMALL = int(os.environ.get("AED_GN_FORCE_SMALL", "0"))    # A/B: always take the single-launch GroupNorm when it fits
 # 1 (default): small contractions go to the latency-regime kernels of lin_gemm.hip; 0: round-1 routing (A/B runs)
 LIN_MODE = int(os.environ.get("AED_LIN_MODE", "1"))
@@ -161,7 +161,7 @@ class Tape:
         """Implicit-GEMM conv (AED_OP_CONV_GEMM).  x: [B,IH,IW,>=Cin] view, w: [N, KH*KW*Cin].
         x2/C1: two-source A -- channels [0,C1) of every tap come from x, [C1,Cin) from x2 (a concat that is never
         materialised).  geglu: w rows are packed [32 value | 32 gate] per 32 features and out[:, f] =
-        value_f * gelu(gate_f) has N/2 columns."""
+        value_f * gelu(gate_f) has N/2 columns (geglu=2: value_f * silu(gate_f), SwiGLU)."""
         M = B * OH * OW
         K = KH * KW * Cin
         lda = x.stride(-2) if lda is None else lda
@@ -199,7 +199,7 @@ class Tape:
             tile = 4
         i = [M, N, K, lda, ldc, ldr or 0, ld_rv, IH, IW, OH, OW, Cin, KH, KW, stride, pad_h, pad_w, dil_h, dil_w, up,
              a_bs, o_mul, o_add, o_len, out_bs, in_act, out_act, accumulate, ksplit, tile, FORCE_BK, ln_mode,
-             C1 if x2 is not None else 0, lda2 or 0, a_bs2 or 0, int(bool(geglu)), sm_group, w_bs, vec_ld, vec_bs]
+             C1 if x2 is not None else 0, lda2 or 0, a_bs2 or 0, int(geglu), sm_group, w_bs, vec_ld, vec_bs]
         n_out = N // 2 if geglu else N
         idx = self._add(L.OP_CONV_GEMM, i, [in_slope, out_p, out_div, ln_eps, sm_scale],
                         [x, w, bias, out, res, rowvec, None, None, x2, kbias], name=name,
@@ -276,13 +276,14 @@ class Tape:
         return out
 
     def copy2d(self, src, dst, *, rows, cols, ld_src=None, ld_dst=None, state=None, idx_off=0, idx_mul=0,
-               idx_stride=0, name="copy"):
+               idx_stride=0, coef=None, c_mul=0, c_off=0, c_stride=0, c_col=0, name="copy"):
         """dst[r, :cols] = src[r, :cols]; with `state`, src is first advanced by
-        (idx_off + idx_mul*state[0]) * idx_stride elements on the device (trajectory walk)."""
+        (idx_off + idx_mul*state[0]) * idx_stride elements on the device (trajectory walk); with `coef`, every element
+        is multiplied by coef[(state[0]*c_mul + c_off)*c_stride + c_col] (a per-step scalar of a device table)."""
         ld_src = src.stride(-2) if ld_src is None else ld_src
         ld_dst = dst.stride(-2) if ld_dst is None else ld_dst
-        self._add(L.OP_COPY2D, [rows, cols, ld_src, ld_dst, idx_off, idx_mul, idx_stride], [], [src, dst, state],
-                  name=name, nbytes=8 * rows * cols)
+        self._add(L.OP_COPY2D, [rows, cols, ld_src, ld_dst, idx_off, idx_mul, idx_stride, c_mul, c_off, c_stride, c_col],
+                  [], [src, dst, state, coef], name=name, nbytes=8 * rows * cols)
         return dst
 
     @staticmethod
@@ -303,11 +304,16 @@ class Tape:
     def graph_replay(g):
         L.check(L.lib().aed_graph_launch(g, L.current_stream_ptr()), "aed_graph_launch")
 
-    def time_embed(self, out, *, B, dim, flip=True, shift=0.0, timesteps=None, state=None, t_imm=0, name="time_embed"):
+    def time_embed(self, out, *, B, dim, flip=True, shift=0.0, timesteps=None, state=None, t_imm=0, freqs=None,
+                   float_table=False, name="time_embed"):
+        """Sinusoidal features of a timestep read from a device table.  Default: diffusers' Timesteps (int64 table,
+        log-spaced frequencies).  freqs + float_table: learned Fourier features of a continuous timestep (Stable Audio's
+        time_proj: the fp32 table holds 2*pi*t, `freqs` the learned weights)."""
         half = dim // 2
-        exponent = -math.log(10000) * torch.arange(half, dtype=torch.float32) / (half - shift)
-        freqs = torch.exp(exponent).to(self.device)
-        self._add(L.OP_TIME_EMBED, [B, dim, int(flip), out.stride(-2), t_imm, 1], [shift, 10000.0],
+        if freqs is None:
+            exponent = -math.log(10000) * torch.arange(half, dtype=torch.float32) / (half - shift)
+            freqs = torch.exp(exponent).to(self.device)
+        self._add(L.OP_TIME_EMBED, [B, dim, int(flip), out.stride(-2), t_imm, 1, int(float_table)], [shift, 10000.0],
                   [out, timesteps, state, freqs, None], name=name)
         return out
 
@@ -337,6 +343,31 @@ class Tape:
         self._add(code, [numel & 0xFFFFFFFF, numel >> 32, P, T, s_imm, v_pred, flag, s_mul, s_off],
                   [cfg_scalar, *c_imm],
                   [xts, zs, eps_u, eps_c, cfg, coef, state, out], name=name, nbytes=4 * numel * 6)
+
+    # ------------------------------------------------------------------ Stable Audio Open ops (csrc/stable_audio.hip)
+    def rotary(self, x, cos, sin, *, M, N, H, D, R, ld=None, nsec=2, sec_stride=None, name="rotary"):
+        """Rotate the first R features of every head of q (and k) inside a fused projection buffer x[M, ld], in place."""
+        ld = x.stride(-2) if ld is None else ld
+        sec_stride = H * D if sec_stride is None else sec_stride
+        self._add(L.OP_ROTARY, [M, N, H, D, R, ld, nsec, sec_stride], [], [x, cos, sin], name=name,
+                  nbytes=8 * M * nsec * H * R)
+        return x
+
+    def snake(self, x, out, a, inv_b, *, rows, C, name="snake"):
+        self._add(L.OP_SNAKE, [rows & 0xFFFFFFFF, rows >> 32, C, x.stride(-2), out.stride(-2)], [], [x, out, a, inv_b],
+                  name=name, nbytes=8 * rows * C)
+        return out
+
+    def sa_step(self, mode, *, xts, zs, v_u, v_c, coef, state, hist, numel, T, out=None, extra=None, fix=1, cfg=1.0,
+                s_imm=0, s_mul=1, s_off=0, name="sa_step"):
+        """mode 0: get_zs_from_xts, mode 1: reverse_step_with_custom_noise of the Stable Audio wrapper (see aed.h)."""
+        self._add(L.OP_SA_STEP, [numel & 0xFFFFFFFF, numel >> 32, mode, T, s_imm, int(fix), s_mul, s_off], [cfg],
+                  [xts, zs, v_u, v_c, coef, state, hist, out, extra], name=name, nbytes=4 * numel * 7)
+
+    def gauss_sample(self, moments, noise, out, *, rows, C, name="gauss_sample"):
+        self._add(L.OP_GAUSS_SAMPLE, [rows & 0xFFFFFFFF, rows >> 32, C, moments.stride(-2)], [], [moments, noise, out],
+                  name=name, nbytes=16 * rows * C)
+        return out
 
     def reflect_pad(self, src, dst, *, B, N, pad, ldd, name="reflect_pad"):
         self._add(L.OP_REFLECT_PAD, [B, N, pad, ldd], [], [src, dst], name=name, nbytes=8 * B * N)

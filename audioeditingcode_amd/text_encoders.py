@@ -66,6 +66,51 @@ class ProjectionModel(torch.nn.Module):
         return h, mask
 
 
+class StableAudioProjection(torch.nn.Module):
+    """diffusers' StableAudioProjectionModel restated (un-vendored): the text states pass through `text_projection`
+    (identity when the widths agree) and the start / end seconds through two number conditioners -- clamp to
+    [min_value, max_value], normalise to [0, 1], learned Fourier features (plus the raw value), one Linear.  Parameter
+    names follow the checkpoint (`{start,end}_number_conditioner.time_positional_embedding.{0.weights,1.weight,1.bias}`)."""
+
+    def __init__(self, text_encoder_dim=768, conditioning_dim=768, min_value=0, max_value=512,
+                 number_embedding_internal_dim=256, **_ignored):
+        super().__init__()
+        self.min_value, self.max_value = float(min_value), float(max_value)
+        self.text_projection = (torch.nn.Identity() if text_encoder_dim == conditioning_dim
+                                else torch.nn.Linear(text_encoder_dim, conditioning_dim))
+        half = number_embedding_internal_dim // 2
+        for n in ("start", "end"):
+            self.register_parameter(f"{n}_weights", torch.nn.Parameter(torch.randn(half)))
+            setattr(self, f"{n}_linear", torch.nn.Linear(number_embedding_internal_dim + 1, conditioning_dim))
+
+    def load_diffusers_state_dict(self, sd):
+        own = {}
+        for n in ("start", "end"):
+            pre = f"{n}_number_conditioner.time_positional_embedding."
+            own[f"{n}_weights"] = sd[pre + "0.weights"]
+            own[f"{n}_linear.weight"] = sd[pre + "1.weight"]
+            own[f"{n}_linear.bias"] = sd[pre + "1.bias"]
+        if "text_projection.weight" in sd:
+            own["text_projection.weight"], own["text_projection.bias"] = sd["text_projection.weight"], sd["text_projection.bias"]
+        self.load_state_dict(own)
+
+    def _number(self, which, seconds):
+        w, lin = getattr(self, f"{which}_weights"), getattr(self, f"{which}_linear")
+        x = torch.as_tensor(seconds, dtype=torch.float32, device=w.device).reshape(-1).clamp(self.min_value, self.max_value)
+        x = (x - self.min_value) / (self.max_value - self.min_value)
+        t = x[..., None]
+        fr = t * w[None] * 2 * torch.pi
+        e = lin(torch.cat([t, fr.sin(), fr.cos()], dim=-1))
+        return e.view(-1, 1, e.shape[-1])
+
+    def forward(self, text_hidden_states=None, start_seconds=None, end_seconds=None):
+        from types import SimpleNamespace
+        return SimpleNamespace(
+            text_hidden_states=None if text_hidden_states is None else self.text_projection(text_hidden_states),
+            seconds_start_hidden_states=None if start_seconds is None else self._number("start", start_seconds),
+            seconds_end_hidden_states=None if end_seconds is None else self._number("end", end_seconds))
+
+
 class TextEncoders:
     """Holds the tokenizers / encoders of one model family and produces the `(hidden_states, class_labels, mask)`
     triple of the reference's `encode_text` for it."""
@@ -73,7 +118,7 @@ class TextEncoders:
     def __init__(self, kind: str, tokenizer=None, text_encoder=None, tokenizer_2=None, text_encoder_2=None,
                  language_model=None, projection_model: Optional[ProjectionModel] = None, max_new_tokens: int = 8,
                  source: str = "caller-provided modules"):
-        assert kind in ("audioldm", "audioldm2", "tango")
+        assert kind in ("audioldm", "audioldm2", "tango", "stable_audio")
         self.kind, self.source = kind, source
         self.tokenizer, self.text_encoder = tokenizer, text_encoder
         self.tokenizer_2, self.text_encoder_2 = tokenizer_2, text_encoder_2
@@ -103,6 +148,22 @@ class TextEncoders:
             from transformers import T5EncoderModel
             return cls(kind, AutoTokenizer.from_pretrained(need("tokenizer")),
                        T5EncoderModel.from_pretrained(need("text_encoder")).to(device), source=root)
+        if kind == "stable_audio":
+            from transformers import T5EncoderModel
+            proj_dir = need("projection_model")
+            with open(os.path.join(proj_dir, "config.json")) as f:
+                pc = json.load(f)
+            proj = StableAudioProjection(**{k: v for k, v in pc.items() if not k.startswith("_")})
+            wfile = os.path.join(proj_dir, "diffusion_pytorch_model.safetensors")
+            if os.path.exists(wfile):
+                from safetensors.torch import load_file
+                proj.load_diffusers_state_dict(load_file(wfile))
+            else:
+                proj.load_diffusers_state_dict(torch.load(os.path.join(proj_dir, "diffusion_pytorch_model.bin"),
+                                                          map_location="cpu", weights_only=True))
+            return cls(kind, AutoTokenizer.from_pretrained(need("tokenizer")),
+                       T5EncoderModel.from_pretrained(need("text_encoder")).to(device),
+                       projection_model=proj.to(device), source=root)
         from transformers import ClapModel, GPT2Model, T5EncoderModel
         proj_dir = need("projection_model")
         with open(os.path.join(proj_dir, "config.json")) as f:
@@ -168,6 +229,33 @@ class TextEncoders:
         d = self._dev(self.text_encoder)
         emb = self.text_encoder(input_ids=ids.to(d), attention_mask=mask.to(d))[0]
         return emb.to(device=device, dtype=torch.float32), None, (mask == 1).to(device)
+
+    @torch.no_grad()
+    def encode_stable_audio(self, prompts: List[str], device, negative: bool = False, **kwargs):
+        """StableAudWrapper.encode_text (models.py:1069-1103) -> (T5 states through the projection model [P, 128, 768],
+        None, mask [P, 128]): max-length padding; for NEGATIVE prompts the padded positions are zeroed before the
+        projection; the mask multiplies the result (twice in the reference -- idempotent for a 0/1 mask); the empty
+        prompt returns zeros and no mask, which `unet_forward` reads as "zero the whole context"."""
+        ti = self.tokenizer(prompts, padding="max_length", max_length=self.tokenizer.model_max_length, truncation=True,
+                            return_tensors="pt")
+        d = self._dev(self.text_encoder)
+        ids, mask = ti.input_ids.to(d), ti.attention_mask.to(d)
+        e = self.text_encoder(ids, attention_mask=mask)[0]
+        if negative:
+            e = torch.where(mask.to(torch.bool).unsqueeze(2), e, 0.0)
+        e = self.projection_model(text_hidden_states=e).text_hidden_states
+        if prompts == [""]:
+            return torch.zeros_like(e).to(device=device, dtype=torch.float32), None, None
+        m = mask.unsqueeze(-1).to(e.dtype)
+        return (e * m * m).to(device=device, dtype=torch.float32), None, mask.to(device)
+
+    @torch.no_grad()
+    def encode_duration(self, audio_start_in_s, audio_end_in_s, device):
+        """StableAudioPipeline.encode_duration without classifier-free duplication (models.py:1161-1162):
+        (seconds_start_hidden_states, seconds_end_hidden_states), each [1, 1, conditioning_dim]."""
+        out = self.projection_model(start_seconds=[float(audio_start_in_s)], end_seconds=[float(audio_end_in_s)])
+        return (out.seconds_start_hidden_states.to(device=device, dtype=torch.float32),
+                out.seconds_end_hidden_states.to(device=device, dtype=torch.float32))
 
     @torch.no_grad()
     def encode_audioldm2(self, prompts: List[str], device, **kwargs):

@@ -60,6 +60,21 @@ def read_wav(path) -> Tuple[np.ndarray, int]:
         return x[:, 0], sr
 
 
+def read_wav_channels(path) -> Tuple[np.ndarray, int]:
+    """[channels, n] float waveform + sample rate (`torchaudio.load`'s layout, utils.py:78)."""
+    try:
+        import torchaudio
+        w, sr = torchaudio.load(path)
+        return w.numpy(), sr
+    except ImportError:
+        with wave.open(path, "rb") as f:
+            sr, nch, sw, n = f.getframerate(), f.getnchannels(), f.getsampwidth(), f.getnframes()
+            raw = f.readframes(n)
+        dt = {2: np.int16, 4: np.int32}[sw]
+        x = np.frombuffer(raw, dtype=dt).reshape(-1, nch).astype(np.float32) / float(np.iinfo(dt).max + 1)
+        return np.ascontiguousarray(x.T), sr
+
+
 def resample(w, sr, new_sr):
     if sr == new_sr:
         return w
@@ -103,10 +118,23 @@ def get_spec(wav: torch.Tensor, fn_STFT) -> torch.Tensor:
 
 def load_audio(audio_path, fn_STFT, left: int = 0, right: int = 0, device: Optional[torch.device] = None,
                return_wav: bool = False, stft: bool = False, model_sr: Optional[int] = None):
-    """code/utils.py:53-76 (the AudioLDM/TANGO spectrogram branch; `audio_path` may also be a
-    (waveform, sample_rate) pair for in-memory clips)."""
+    """code/utils.py:53-95: the AudioLDM/TANGO spectrogram branch (stft=True) and the Stable Audio raw-waveform branch
+    (stft=False -> (waveform [channels, n] normalised to +-0.5 over all channels, model_sr, duration)).  `audio_path` may
+    also be a (waveform, sample_rate) pair for in-memory clips."""
     if not stft:
-        raise NotImplementedError("raw-waveform loading is the Stable Audio branch (SURVEY 8f row 4)")
+        if isinstance(audio_path, str):
+            wav, sr = read_wav_channels(audio_path)
+        else:
+            wav, sr = audio_path
+            wav = np.asarray(wav, dtype=np.float32)
+            wav = wav[None] if wav.ndim == 1 else wav
+        if sr != model_sr:
+            wav = np.stack([resample(c, sr, model_sr) for c in wav])
+        w = torch.from_numpy(np.ascontiguousarray(wav)).float()
+        w = w - torch.mean(w)                                   # utils.py:83-88
+        w = w / (torch.max(torch.abs(w)) + 1e-8)
+        w = w * 0.5
+        return w, model_sr, w.shape[-1] / model_sr
     if isinstance(audio_path, str):
         wav, sr = read_wav(audio_path)
         duration = get_duration(audio_path)

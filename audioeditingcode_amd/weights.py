@@ -204,6 +204,99 @@ def vocoder_param_shapes(cfg):
     return sh
 
 
+def dit_param_shapes(cfg):
+    """diffusers StableAudioDiTModel parameter inventory (names as in its state dict)."""
+    C = cfg["num_attention_heads"] * cfg["attention_head_dim"]
+    KV = cfg["num_key_value_attention_heads"] * cfg["attention_head_dim"]
+    cin, cout, dc = cfg["in_channels"], cfg["out_channels"], cfg["cross_attention_dim"]
+    ff = cfg.get("ff_inner_dim") or 4 * C
+    sh = {"time_proj.weight": (cfg["time_proj_dim"] // 2,),
+          "timestep_proj.0.weight": (C, cfg["time_proj_dim"]), "timestep_proj.0.bias": (C,),
+          "timestep_proj.2.weight": (C, C), "timestep_proj.2.bias": (C,),
+          "global_proj.0.weight": (C, cfg["global_states_input_dim"]), "global_proj.2.weight": (C, C),
+          "cross_attention_proj.0.weight": (dc, cfg["cross_attention_input_dim"]),
+          "cross_attention_proj.2.weight": (dc, dc),
+          "preprocess_conv.weight": (cin, cin, 1), "proj_in.weight": (C, cin)}
+    for i in range(cfg["num_layers"]):
+        p = f"transformer_blocks.{i}."
+        for n in ("norm1", "norm2", "norm3"):
+            sh[p + n + ".weight"] = (C,)
+            sh[p + n + ".bias"] = (C,)
+        for n in ("to_q", "to_k", "to_v", "to_out.0"):
+            sh[p + f"attn1.{n}.weight"] = (C, C)
+        sh[p + "attn2.to_q.weight"] = (C, C)
+        sh[p + "attn2.to_k.weight"] = (KV, dc)
+        sh[p + "attn2.to_v.weight"] = (KV, dc)
+        sh[p + "attn2.to_out.0.weight"] = (C, C)
+        sh[p + "ff.net.0.proj.weight"] = (2 * ff, C)
+        sh[p + "ff.net.0.proj.bias"] = (2 * ff,)
+        sh[p + "ff.net.2.weight"] = (C, ff)
+        sh[p + "ff.net.2.bias"] = (C,)
+    sh["proj_out.weight"] = (cout, C)
+    sh["postprocess_conv.weight"] = (cout, cout, 1)
+    return sh
+
+
+def oobleck_param_shapes(cfg):
+    """diffusers AutoencoderOobleck inventory AFTER weight-norm folding (`fold_weight_norm`): plain conv weights,
+    Snake1d alpha/beta [1,C,1]."""
+    sh = {}
+    hid, ca = cfg["encoder_hidden_size"], cfg["audio_channels"]
+    mult = [1] + list(cfg["channel_multiples"])
+    ratios = list(cfg["downsampling_ratios"])
+
+    def conv(p, o, i, k, bias=True):
+        sh[p + ".weight"] = (o, i, k)
+        if bias:
+            sh[p + ".bias"] = (o,)
+
+    def snake(p, c):
+        sh[p + ".alpha"] = (1, c, 1)
+        sh[p + ".beta"] = (1, c, 1)
+
+    def res(p, c):
+        snake(p + ".snake1", c)
+        conv(p + ".conv1", c, c, 7)
+        snake(p + ".snake2", c)
+        conv(p + ".conv2", c, c, 1)
+
+    conv("encoder.conv1", hid, ca, 7)
+    for i, st in enumerate(ratios):
+        ci, co = hid * mult[i], hid * mult[i + 1]
+        for j in range(3):
+            res(f"encoder.block.{i}.res_unit{j + 1}", ci)
+        snake(f"encoder.block.{i}.snake1", ci)
+        conv(f"encoder.block.{i}.conv1", co, ci, 2 * st)
+    snake("encoder.snake1", hid * mult[-1])
+    conv("encoder.conv2", 2 * cfg["decoder_input_channels"], hid * mult[-1], 3)
+    dch = cfg["decoder_channels"]
+    conv("decoder.conv1", dch * mult[-1], cfg["decoder_input_channels"], 7)
+    for i, st in enumerate(ratios[::-1]):
+        ci, co = dch * mult[len(ratios) - i], dch * mult[len(ratios) - i - 1]
+        snake(f"decoder.block.{i}.snake1", ci)
+        sh[f"decoder.block.{i}.conv_t1.weight"] = (ci, co, 2 * st)          # ConvTranspose1d layout [Cin, Cout, k]
+        sh[f"decoder.block.{i}.conv_t1.bias"] = (co,)
+        for j in range(3):
+            res(f"decoder.block.{i}.res_unit{j + 1}", co)
+    snake("decoder.snake1", dch)
+    conv("decoder.conv2", ca, dch, 7, bias=False)
+    return sh
+
+
+def projection_param_shapes(cfg):
+    """diffusers StableAudioProjectionModel: identity text projection when the dims agree, two number conditioners."""
+    sh = {}
+    d, k = cfg["conditioning_dim"], cfg["number_embedding_internal_dim"]
+    if cfg["text_encoder_dim"] != d:
+        sh["text_projection.weight"] = (d, cfg["text_encoder_dim"])
+        sh["text_projection.bias"] = (d,)
+    for n in ("start_number_conditioner", "end_number_conditioner"):
+        sh[n + ".time_positional_embedding.0.weights"] = (k // 2,)
+        sh[n + ".time_positional_embedding.1.weight"] = (d, k + 1)
+        sh[n + ".time_positional_embedding.1.bias"] = (d,)
+    return sh
+
+
 def random_state_dict(shapes, seed=0, gain=1.0):
     """Fan-in scaled init (keeps activations O(1) so parity tests exercise real dynamic range);
     norm weights 1 + 0.1*randn, biases 0.02*randn.  Deterministic in (shapes order, seed)."""
@@ -214,6 +307,8 @@ def random_state_dict(shapes, seed=0, gain=1.0):
             sd[name] = torch.zeros(shp)
         elif name in ("scale",):
             sd[name] = torch.ones(shp)
+        elif name.endswith("time_proj.weight") or name.endswith(".weights"):     # learned Fourier frequencies
+            sd[name] = torch.randn(shp, generator=g)
         elif len(shp) == 1:
             is_norm_w = name.endswith(".weight")
             t = torch.randn(shp, generator=g)
@@ -222,8 +317,11 @@ def random_state_dict(shapes, seed=0, gain=1.0):
             fan_in = 1
             for s in shp[1:]:
                 fan_in *= s
-            if "upsampler" in name:            # ConvTranspose1d [Cin, Cout, k]: fan-in = Cin*k/stride-ish
+            if "upsampler" in name or "conv_t1" in name:   # ConvTranspose1d [Cin, Cout, k]: fan-in = Cin*k/stride-ish
                 fan_in = shp[0] * max(1, shp[2] // 4)
+            if name.endswith(".alpha") or name.endswith(".beta"):          # Snake1d log-scale parameters
+                sd[name] = 0.3 * torch.randn(shp, generator=g)
+                continue
             sd[name] = torch.randn(shp, generator=g) * (gain / fan_in ** 0.5)
     return sd
 
@@ -247,7 +345,8 @@ def find_checkpoint(model_id):
     home = os.environ.get("HF_HOME", os.path.join(os.path.expanduser("~"), ".cache", "huggingface"))
     cands += sorted(glob.glob(os.path.join(home, "hub", "models--" + model_id.replace("/", "--"), "snapshots", "*")))
     for c in cands:
-        if os.path.exists(os.path.join(c, "unet", "config.json")):
+        if os.path.exists(os.path.join(c, "unet", "config.json")) or \
+                os.path.exists(os.path.join(c, "transformer", "config.json")):       # Stable Audio: DiT, no U-Net
             return c
     return None
 
@@ -295,4 +394,23 @@ def load_checkpoint(root):
     if os.path.exists(sp):
         with open(sp) as f:
             res["scheduler"] = json.load(f)
+    return res
+
+
+def load_stable_audio_checkpoint(root):
+    """Configs + weights of a local StableAudioPipeline directory: transformer/ (DiT), vae/ (Oobleck, weight norm
+    folded), projection_model/, scheduler/."""
+    names = ["diffusion_pytorch_model.safetensors", "diffusion_pytorch_model.bin"]
+    res = {}
+    for sub in ("transformer", "vae", "projection_model"):
+        with open(os.path.join(root, sub, "config.json")) as f:
+            cfg = {k: v for k, v in json.load(f).items() if not k.startswith("_")}
+        sd = _load_component(root, sub, names)
+        if sub == "vae":
+            sd = fold_weight_norm(sd)
+        res[sub] = (cfg, {k: v.float() for k, v in sd.items()})
+    sp = os.path.join(root, "scheduler", "scheduler_config.json")
+    if os.path.exists(sp):
+        with open(sp) as f:
+            res["scheduler"] = {k: v for k, v in json.load(f).items() if not k.startswith("_")}
     return res

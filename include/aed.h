@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define AED_VERSION 2
+#define AED_VERSION 3
 
 /* ----------------------------------------------------------------------------------------
  * op tape
@@ -62,6 +62,11 @@ enum aed_opcode {
     AED_OP_GN_SMALL = 22,     /* single-launch GroupNorm(+SiLU) for small feature maps (K4)       */
     AED_OP_XATTN_FOLD = 23,   /* per-prompt operands of the folded cross-attention: G' = k_h.(gamma o Wq_h), its two
                                  LayerNorm-fold vectors, VO^T = (v_h.Wo_h^T)^T -- once per prompt, not per step      */
+    AED_OP_ROTARY = 24,       /* partial rotary embedding of q and k in place (Stable Audio DiT self-attention)           */
+    AED_OP_SNAKE = 25,        /* Snake1d activation of the Oobleck VAE                                                     */
+    AED_OP_SA_STEP = 26,      /* CFG + StableAudWrapper.get_zs_from_xts / reverse_step_with_custom_noise (SDE-DPM-Solver++
+                                 order 1 / 2, history on the device; models.py:1209-1271, :1282-1329)                      */
+    AED_OP_GAUSS_SAMPLE = 27, /* mean + (softplus(scale) + 1e-4) * noise (Oobleck posterior sample, models.py:1132-1133)    */
     AED_OP_COUNT
 };
 
@@ -133,6 +138,32 @@ int aed_reverse_step_with_custom_noise(const float* xt, const float* eps_u, cons
 int aed_sample_xts_from_x0(const float* x0, const float* noise, const float* sqrt_abar,
                            const float* sqrt_1m_abar, float* xts_out, int n_t, int64_t numel,
                            void* stream);
+
+/* ----------------------------------------------------------------------------------------
+ * Stable Audio Open (StableAudWrapper, models.py:1051-1354)
+ * -------------------------------------------------------------------------------------- */
+
+/* Per-step coefficients of the CosineDPMSolver++ SDE update, computed on the host in fp32 with the expression order of
+ * models.py:1238-1255 / the scheduler's update functions (sigma_s = sigmas[i], sigma_t = sigmas[i+1], h = ln sigma_s - ln sigma_t):
+ *   c[0]=c_in = 1/sqrt(sigma_s^2+sd^2) (scale_model_input)   c[1]=c_skip  c[2]=c_out (v-prediction -> data prediction)
+ *   c[3]=sigma_t/sigma_s*exp(-h)   c[4]=1-exp(-2h)   c[5]=sigma_t*sqrt(1-exp(-2h))   c[6]=1/r0 (r0 = h_prev/h)
+ *   c[7]=solver order of this step (1 or 2)   c[8]=1 when z is defined as 0 (final step, sigma_t = 0)
+ *   c[9]=2*pi*timestep (the DiT's Fourier-feature argument)   c[10..11] reserved                                        */
+#define AED_SA_COEF_STRIDE 12
+
+/* StableAudWrapper.get_zs_from_xts (models.py:1209-1271) fused with the CFG combine of inversion_utils.py:97-102 (one
+ * prompt).  `hist` holds the previous step's data prediction on entry (the scheduler's model_outputs[-2]; ignored when
+ * c[7] == 1) and this step's on exit.  Writes z, overwrites xtm1 when numerical_fix, and copies the previous data
+ * prediction to extra_out (the reference's third return value) when it is not NULL.  v_c may be NULL.                   */
+int aed_sa_get_zs_from_xts(const float* xt, float* xtm1, const float* v_u, const float* v_c, float cfg_scalar,
+                           const float* coef_host, float* hist, int numerical_fix, float* z, float* extra_out,
+                           int64_t numel, void* stream);
+
+/* StableAudWrapper.reverse_step_with_custom_noise (models.py:1282-1329) fused with the CFG combine of
+ * inversion_utils.py:276-281.  z may be NULL (treated as zero noise).                                                   */
+int aed_sa_reverse_step_with_custom_noise(const float* xt, const float* v_u, const float* v_c, float cfg_scalar,
+                                          const float* coef_host, float* hist, const float* z, float* prev_out,
+                                          int64_t numel, void* stream);
 
 #ifdef __cplusplus
 }

@@ -8,7 +8,7 @@ torchvision, torchaudio, librosa, wandb, soundfile, progressbar); name-only stub
 modules are injected exactly as SURVEY.md 8(c)/Appendix B describes.  What each
 fixture pins is listed in tests/golden/README.md.
 
-Usage:  python oracle/make_golden.py [loops|pc|pc_cli|audio|hifigan|unet|vae|all]
+Usage:  python oracle/make_golden.py [loops|pc|pc_cli|audio|hifigan|unet|vae|stable_audio|all]
 """
 import importlib.util
 import os
@@ -560,6 +560,113 @@ def gen_vae():
     print("vae twin", tuple(mean.shape), tuple(recon.shape), float(recon.abs().mean()))
 
 
+# --------------------------------------------------------------------------- Stable Audio wrapper math + loops
+def gen_stable_audio():
+    """Runs the reference's StableAudWrapper methods (models.py:1069-1354) and its loops on a 3-D latent.  diffusers is
+    absent: the scheduler is oracle.stable_audio.OracleCosineDPMSolverScheduler (restated), the tokenizer / text
+    encoder / projection model / transformer are small deterministic stand-ins -- what is pinned is the reference's own
+    code: encode_text (negative / empty-prompt / double-mask rules), unet_forward (context assembly, zeroing),
+    sample_xts_from_x0, setup_extra_inputs (history re-seeding), get_zs_from_xts, reverse_step_with_custom_noise."""
+    install_stubs()
+    sys.path.insert(0, REF)
+    import models as ref_models
+    from ddm_inversion import inversion_utils as ref_inv
+    from oracle import stable_audio as osa
+
+    ref_models.get_1d_rotary_pos_embed = lambda dim, n, use_real=True, repeat_interleave_real=False: osa.rotary_table(dim, n)
+    SI = osa.StandIns
+    C, Lz, D, S = SI.C, SI.Lz, SI.D, SI.S
+    Tok, TextEnc, projection_model, encode_duration, transformer = (SI.Tok, SI.TextEnc, SI.projection_model,
+                                                                    SI.encode_duration, SI.transformer)
+
+    class FakeSA(ref_models.StableAudWrapper):
+        def __init__(self, sched, T):
+            ref_models.PipelineWrapper.__init__(self, model_id="fake/stable-audio", device=torch.device("cpu"))
+            sched.set_timesteps(T)
+            self.model = SimpleNamespace(
+                scheduler=sched, tokenizer=Tok(), text_encoder=TextEnc(), projection_model=projection_model,
+                encode_duration=encode_duration, rotary_embed_dim=4, transformer=transformer,
+                vae=SimpleNamespace(hop_length=16, config=SimpleNamespace(sampling_rate=100, audio_channels=2)))
+            self.model.transformer.config = SimpleNamespace(in_channels=C, sample_size=Lz)
+
+    rec = {}
+
+    def run_case(name, T, tstart, src, tgt, cfg_src, cfg_tar, seed, first_order=False):
+        sched = osa.OracleCosineDPMSolverScheduler()
+        m = FakeSA(sched, T)
+        g = torch.Generator().manual_seed(300 + seed)
+        x0 = torch.randn((1, C, Lz), generator=g) * 0.8
+        torch.manual_seed(seed)
+        with torch.no_grad():
+            _, zs, wts, extra = ref_inv.inversion_forward_process(
+                m, x0, etas=1.0, prompts=[src], cfg_scales=[cfg_src], num_inference_steps=T, numerical_fix=True,
+                duration=3.0, first_order=first_order)
+            w0, _ = ref_inv.inversion_reverse_process(
+                m, xT=wts, tstart=torch.tensor([tstart], dtype=torch.int), etas=1.0, prompts=[tgt], neg_prompts=[""],
+                cfg_scales=[cfg_tar], zs=zs[:tstart], duration=3.0, extra_info=extra, first_order=first_order)
+        torch.manual_seed(seed)
+        sched2 = osa.OracleCosineDPMSolverScheduler()
+        xts_init = FakeSA(sched2, T).sample_xts_from_x0(x0, num_inference_steps=T)
+        ex = torch.stack([e if e is not None else torch.full_like(x0, float("nan")) for e in extra])
+        rec.update({f"{name}.x0": x0.numpy(), f"{name}.xts_init": xts_init.numpy(), f"{name}.zs": zs.numpy(),
+                    f"{name}.xts": wts.numpy(), f"{name}.extra": ex.numpy(), f"{name}.w_edit": w0.numpy(),
+                    f"{name}.meta": np.array([T, tstart, cfg_src, cfg_tar, seed, int(first_order)], dtype=np.float64),
+                    f"{name}.src": np.array(src), f"{name}.tgt": np.array(tgt),
+                    f"{name}.sigmas": sched.sigmas.numpy(), f"{name}.timesteps": sched.timesteps.numpy()})
+        print("sa loop", name, tuple(zs.shape), "recon err", float((w0 - x0).abs().max()),
+              "finite:", bool(torch.isfinite(w0).all()))
+
+    run_case("T20", 20, 12, "a dog barking", "a cat meowing", 1.0, 7.0, seed=0)
+    run_case("T20_emptysrc", 20, 20, "", "rain on a roof", 1.0, 4.0, seed=1)
+    run_case("T12_first", 12, 8, "rain", "jazz", 3.0, 6.0, seed=2, first_order=True)      # also T < 15: lower_order_final
+
+    # encode_text / unet_forward semantics on their own
+    m = FakeSA(osa.OracleCosineDPMSolverScheduler(), 8)
+    for tag, prompts, neg in (("pos", ["a dog barking"], False), ("neg", ["low quality"], True), ("empty", [""], True)):
+        e, _, mask = m.encode_text(prompts, negative=neg)
+        rec[f"enc.{tag}.embeds"] = e.numpy()
+        rec[f"enc.{tag}.mask"] = (mask.numpy() if mask is not None else np.zeros(0))
+    raw_ids = m.model.tokenizer(["a dog barking"], max_length=S)
+    rec["enc.raw"] = m.model.text_encoder(raw_ids.input_ids)[0].numpy()
+    x = torch.randn((1, C, Lz), generator=torch.Generator().manual_seed(5))
+    m.setup_extra_inputs(x, init_timestep=m.model.scheduler.timesteps[0], audio_end_in_s=2.5)
+    e, _, mask = m.encode_text(["a dog barking"])
+    rec["fwd.x"] = x.numpy()
+    rec["fwd.cond"] = m.unet_forward(x, m.model.scheduler.timesteps[3], e, encoder_attention_mask=mask)[0].sample.numpy()
+    rec["fwd.uncond"] = m.unet_forward(x, m.model.scheduler.timesteps[3], e, encoder_attention_mask=None)[0].sample.numpy()
+    rec["fwd.wave_window"] = np.array([m.waveform_start, m.waveform_end])
+    # --- step math at chosen steps of the T=200 schedule (kernel targets; the coefficient rows travel with the fixture,
+    #     as in step_math_T200.npz, because host table arithmetic differs in the last bit between CPUs)
+    from audioeditingcode_amd.scheduler import CosineDPMSolverMultistepScheduler, sa_step_coefficients
+    T = 200
+    gg = torch.Generator().manual_seed(77)
+    cases = [(0, 1), (1, 2), (57, 2), (150, 2), (198, 2), (199, 1)]
+    rec["step.index_order"] = np.array(cases)
+    for k, (i, order) in enumerate(cases):
+        m = FakeSA(osa.OracleCosineDPMSolverScheduler(), T)
+        sch = m.model.scheduler
+        xt, xtm1, v, m1, zin = (torch.randn((1, C, Lz), generator=gg) * sc for sc in (1.0 + float(sch.sigmas[i]),
+                                                                                    1.0 + float(sch.sigmas[i + 1]), 1.0, 1.0, 1.0))
+        def arm():
+            sch._step_index = i
+            sch.model_outputs = [None, m1.clone() if order == 2 else None]
+            sch.lower_order_nums = 0 if i == 0 else 2
+        arm()
+        z, xfix, ex = m.get_zs_from_xts(xt, xtm1.clone(), v, sch.timesteps[i], numerical_fix=True)
+        d = sch.model_outputs[-1].clone()
+        arm()
+        prev = m.reverse_step_with_custom_noise(v, sch.timesteps[i], xt, variance_noise=zin)
+        ps = CosineDPMSolverMultistepScheduler()
+        ps.set_timesteps(T)
+        assert torch.equal(ps.sigmas, sch.sigmas)
+        coef = sa_step_coefficients(ps, i, order, zero_z=(i == T - 1))
+        for name, val in (("xt", xt), ("xtm1", xtm1), ("v", v), ("m1", m1), ("z_in", zin), ("z", z), ("xfix", xfix),
+                          ("d", d), ("prev", prev), ("coef", coef)):
+            rec[f"step.{name}{k}"] = val.numpy()
+    np.savez_compressed(os.path.join(OUT, "sa_wrapper.npz"), **rec)
+    print("sa_wrapper.npz keys", len(rec))
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     os.makedirs(OUT, exist_ok=True)
@@ -567,7 +674,8 @@ if __name__ == "__main__":
     # each generator runs in a fresh interpreter when "all" (the stubs of one break another)
     if what == "all":
         import subprocess
-        for w in ("loops", "pc", "pc_cli", "audio", "hifigan", "unet", "vae"):
+        for w in ("loops", "pc", "pc_cli", "audio", "hifigan", "unet", "vae", "stable_audio"):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), w])
     else:
-        {"loops": gen_loops, "pc": gen_pc, "pc_cli": gen_pc_cli, "audio": gen_audio, "hifigan": gen_hifigan, "unet": gen_unet, "vae": gen_vae}[what]()
+        {"loops": gen_loops, "pc": gen_pc, "pc_cli": gen_pc_cli, "audio": gen_audio, "hifigan": gen_hifigan, "unet": gen_unet, "vae": gen_vae,
+         "stable_audio": gen_stable_audio}[what]()

@@ -124,7 +124,8 @@ def conv_gemm(op):
     if geglu_on:        # packed columns: per 64 columns [32 value | 32 gate] -> 32 output features value * gelu(gate)
         v3 = val.float().reshape(M, N // 64, 2, 32)
         g = v3[:, :, 1]
-        val = (v3[:, :, 0] * (0.5 * g * (1.0 + torch.erf(g * 0.70710678118654752440)))).reshape(M, N // 2).double()
+        gate = g / (1.0 + torch.exp(-g)) if geglu_on == 2 else 0.5 * g * (1.0 + torch.erf(g * 0.70710678118654752440))
+        val = (v3[:, :, 0] * gate).reshape(M, N // 2).double()
         N = N // 2
     cols = torch.arange(N)[None, :]
     if p[4]:
@@ -237,9 +238,13 @@ def geglu(op):
 def copy2d(op):
     i, p = op.i, op.p
     rows, cols, lds, ldd, idx_off, idx_mul, idx_stride = [int(i[k]) for k in range(7)]
-    shift = (idx_off + idx_mul * _state0(p[2])) * idx_stride if p[2] else 0
-    src = _f32(int(p[0]) + 4 * shift, (rows - 1) * lds + cols).as_strided((rows, cols), (lds, 1))
-    _f32(p[1], (rows - 1) * ldd + cols).as_strided((rows, cols), (ldd, 1)).copy_(src.clone())
+    st = _state0(p[2]) if p[2] else 0
+    shift = (idx_off + idx_mul * st) * idx_stride if p[2] else 0
+    src = _f32(int(p[0]) + 4 * shift, (rows - 1) * lds + cols).as_strided((rows, cols), (lds, 1)).clone()
+    if p[3]:
+        c_mul, c_off, c_stride, c_col = [int(i[k]) for k in range(7, 11)]
+        src = src * _f32(int(p[3]) + 4 * ((st * c_mul + c_off) * c_stride + c_col), 1)[0]
+    _f32(p[1], (rows - 1) * ldd + cols).as_strided((rows, cols), (ldd, 1)).copy_(src)
 
 
 def time_embed(op):
@@ -250,7 +255,10 @@ def time_embed(op):
     s = _state0(p[2]) if p[2] else 0
     if p[1]:
         tidx = _view(p[4], B, ctypes.c_int32, np.int32) if p[4] else torch.zeros(B, dtype=torch.int32)
-        table = _view(p[1], s * tgroup + int(tidx.max()) + 1, ctypes.c_int64, np.int64)
+        if int(i[6]):
+            table = _view(p[1], s * tgroup + int(tidx.max()) + 1)
+        else:
+            table = _view(p[1], s * tgroup + int(tidx.max()) + 1, ctypes.c_int64, np.int64)
         t = table[s * tgroup + tidx.long()].float()
     else:
         t = torch.full((B,), float(t_imm))
@@ -380,10 +388,102 @@ def nop(op):
     return
 
 
+# ------------------------------------------------------------------------------------------------- Stable Audio Open ops
+def rotary(op):
+    i, p = op.i, op.p
+    M, N, H, D, R, ld, nsec, sec_stride = [int(i[k]) for k in range(8)]
+    hr = R // 2
+    x = _f32(p[0], (M - 1) * ld + (nsec - 1) * sec_stride + H * D)
+    ct, st = _f32(p[1], N * hr).reshape(N, hr), _f32(p[2], N * hr).reshape(N, hr)
+    pos = torch.arange(M) % N
+    for sec in range(nsec):
+        v = x.as_strided((M, H, D), (ld, D, 1), sec * sec_stride)
+        re, im = v[:, :, :hr].clone(), v[:, :, hr:R].clone()
+        cs, sn = ct[pos][:, None, :], st[pos][:, None, :]
+        v[:, :, :hr] = re * cs + (-im) * sn
+        v[:, :, hr:R] = im * cs + re * sn
+
+
+def snake(op):
+    i, p = op.i, op.p
+    rows = int(i[0]) & 0xFFFFFFFF | (int(i[1]) << 32)
+    C, ldx, ldy = int(i[2]), int(i[3]), int(i[4])
+    x = _f32(p[0], (rows - 1) * ldx + C).as_strided((rows, C), (ldx, 1))
+    a, ib = _f32(p[2], C), _f32(p[3], C)
+    out = x + ib[None] * torch.sin(a[None] * x).pow(2)
+    _f32(p[1], (rows - 1) * ldy + C).as_strided((rows, C), (ldy, 1)).copy_(out)
+
+
+def _sa_update(x, d, m1, c, zz):
+    k1, k2, k3, inv_r0 = c[3], c[4], c[5], c[6]
+    if c[7] > 1.5:
+        D1 = inv_r0 * (d - m1)
+        return ((k1 * x + k2 * d) + (0.5 * k2) * D1) + k3 * zz
+    return (k1 * x + k2 * d) + k3 * zz
+
+
+def _sa_step_math(mode, x, xm1, u, vc, cfg, c, hist, z_in, fix):
+    """Shared by the tape op and the FakeLib entry points: returns (z, new x_{t-1} or None, m1, d)."""
+    v = u + cfg * (vc - u) if vc is not None else u
+    d = c[1] * x + c[2] * v
+    m1 = hist.clone()
+    k1, k2, k3, inv_r0 = c[3], c[4], c[5], c[6]
+    if mode == 0:
+        if c[8] > 0.5:
+            zz = torch.zeros_like(x)
+        elif c[7] > 1.5:
+            zz = (((xm1 - k1 * x) - k2 * d) - (0.5 * k2) * (inv_r0 * (d - m1))) / k3
+        else:
+            zz = ((xm1 - k1 * x) - k2 * d) / k3
+        return zz, (_sa_update(x, d, m1, c, zz) if fix else None), m1, d
+    zz = z_in if z_in is not None else torch.zeros_like(x)
+    return zz, _sa_update(x, d, m1, c, zz), m1, d
+
+
+def sa_step(op):
+    i, p = op.i, op.p
+    numel = int(i[0]) & 0xFFFFFFFF | (int(i[1]) << 32)
+    mode, T, s_imm, fix, s_mul, s_off = [int(i[k]) for k in range(2, 8)]
+    s = _state0(p[5]) * max(1, s_mul) + s_off if p[5] else s_imm
+    c = _f32(int(p[4]) + 4 * 12 * s, 12)
+    u = _f32(p[2], numel)
+    vc = _f32(p[3], numel) if p[3] else None
+    hist = _f32(p[6], numel)
+    cfg = torch.tensor(float(op.f[0]))
+    if mode == 0:
+        idx = T - s - 1
+        x = _f32(int(p[0]) + 4 * (idx + 1) * numel, numel)
+        xm1 = _f32(int(p[0]) + 4 * idx * numel, numel)
+        zz, nx, m1, d = _sa_step_math(0, x, xm1, u, vc, cfg, c, hist, None, fix)
+        _f32(int(p[1]) + 4 * idx * numel, numel).copy_(zz)
+        if nx is not None:
+            xm1.copy_(nx)
+        if p[8]:
+            _f32(int(p[8]) + 4 * idx * numel, numel).copy_(m1)
+    else:
+        x = _f32(p[0], numel)
+        z_in = None
+        if p[1]:
+            z_in = _f32(int(p[1]) + 4 * (T - s - 1) * numel, numel) if T > 0 else _f32(p[1], numel)
+        _, nx, m1, d = _sa_step_math(1, x.clone(), None, u, vc, cfg, c, hist, z_in, 1)
+        _f32(p[7], numel).copy_(nx)
+    hist.copy_(d)
+
+
+def gauss_sample(op):
+    i, p = op.i, op.p
+    rows = int(i[0]) & 0xFFFFFFFF | (int(i[1]) << 32)
+    C, ldm = int(i[2]), int(i[3])
+    mom = _f32(p[0], (rows - 1) * ldm + 2 * C).as_strided((rows, 2 * C), (ldm, 1))
+    noise = _f32(p[1], rows * C).reshape(rows, C)
+    out = mom[:, :C] + (torch.nn.functional.softplus(mom[:, C:]) + 1e-4) * noise
+    _f32(p[2], rows * C).reshape(rows, C).copy_(out)
+
+
 DISPATCH = {0: nop, 1: conv_gemm, 2: gn_stats, 3: gn_apply, 4: layernorm, 5: attention, 6: geglu, 7: copy2d,
             8: time_embed, 9: softmax_rows, 10: transpose, 11: axpby, 12: invert_step, 13: reverse_step,
             14: reverse_step, 15: advance, 16: reflect_pad, 17: magnitude, 18: transpose, 19: transpose, 20: nop,
-            21: gn_scale_shift, 22: gn_small, 23: xattn_fold}
+            21: gn_scale_shift, 22: gn_small, 23: xattn_fold, 24: rotary, 25: snake, 26: sa_step, 27: gauss_sample}
 
 
 def run_tape(tape, start=0, end=None):
@@ -425,6 +525,32 @@ class FakeLib:
         if z:
             prev = prev + c[4] * _f32(z, numel)
         _f32(prev_out, numel).copy_(prev)
+        return 0
+
+    def aed_sa_get_zs_from_xts(self, xt, xtm1, v_u, v_c, cfg_scalar, coef_host, hist, fix, z, extra_out, numel, stream):
+        c = torch.tensor([float(coef_host[k]) for k in range(12)])
+        p = self._ptr
+        xm1, h = _f32(p(xtm1), numel), _f32(p(hist), numel)
+        zz, nx, m1, d = _sa_step_math(0, _f32(p(xt), numel), xm1, _f32(p(v_u), numel),
+                                      _f32(p(v_c), numel) if p(v_c) else None, torch.tensor(float(cfg_scalar)), c, h,
+                                      None, fix)
+        _f32(p(z), numel).copy_(zz)
+        if nx is not None:
+            xm1.copy_(nx)
+        if p(extra_out):
+            _f32(p(extra_out), numel).copy_(m1)
+        h.copy_(d)
+        return 0
+
+    def aed_sa_reverse_step_with_custom_noise(self, xt, v_u, v_c, cfg_scalar, coef_host, hist, z, prev_out, numel, stream):
+        c = torch.tensor([float(coef_host[k]) for k in range(12)])
+        p = self._ptr
+        h = _f32(p(hist), numel)
+        _, nx, m1, d = _sa_step_math(1, _f32(p(xt), numel).clone(), None, _f32(p(v_u), numel),
+                                     _f32(p(v_c), numel) if p(v_c) else None, torch.tensor(float(cfg_scalar)), c, h,
+                                     _f32(p(z), numel) if p(z) else None, 1)
+        _f32(p(prev_out), numel).copy_(nx)
+        h.copy_(d)
         return 0
 
     def aed_last_error(self):

@@ -49,6 +49,19 @@ def install_cpu_stack(monkeypatch):
     monkeypatch.setattr(EditEngine, "_run_graph", run_graph)
     monkeypatch.setattr(EditEngine, "sample_xts", sample_xts)
 
+    from audioeditingcode_amd.stable_audio import StableAudioEditEngine
+
+    def sa_sample_xts(self, x0, noise=None, generator=None):
+        s = self.sched
+        T = s.num_inference_steps
+        x0 = x0.float()
+        if noise is None:
+            noise = torch.stack([torch.randn(x0.shape, generator=generator, dtype=torch.float32) for _ in range(T)])
+        sig = torch.stack([s.sigmas[T - (r + 1)] for r in range(T)]).reshape(T, *[1] * x0.dim())
+        return torch.cat([x0[None], x0[None] + noise * sig])
+    monkeypatch.setattr(StableAudioEditEngine, "_run_graph", run_graph)
+    monkeypatch.setattr(StableAudioEditEngine, "sample_xts", sa_sample_xts)
+
 
 @pytest.fixture
 def cpu_stack(monkeypatch):

@@ -1,0 +1,283 @@
+"""GPU parity of the Stable Audio Open path (SURVEY 8(f) row 4 / BASELINE config 5): new kernels against plain torch,
+the solver step against vectors produced by the reference's own methods (bit-exact), the DiT / Oobleck tapes and the
+device-resident loops against the oracle (oracle/stable_audio.py), tiny and full width."""
+import ctypes
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from audioeditingcode_amd import _lib as L          # noqa: E402
+from audioeditingcode_amd import configs, weights   # noqa: E402
+from audioeditingcode_amd.scheduler import CosineDPMSolverMultistepScheduler   # noqa: E402
+from audioeditingcode_amd.tape import Tape          # noqa: E402
+from oracle import stable_audio as osa              # noqa: E402
+
+DEV = "cuda:0"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def run(tp):
+    tp.run()
+    torch.cuda.synchronize()
+
+
+def rel(a, b):
+    return float((a - b).abs().max() / b.abs().max())
+
+
+# ------------------------------------------------------------------------------------------------ kernels
+def test_solver_step_bit_exact_vs_reference_vectors(golden_dir):
+    g = np.load(os.path.join(golden_dir, "sa_wrapper.npz"))
+    lib = L.lib()
+    for k, (i, order) in enumerate(g["step.index_order"]):
+        cf = (ctypes.c_float * L.SA_COEF_STRIDE)(*g[f"step.coef{k}"].tolist())
+        xt, xtm1, v, m1, zin = (torch.from_numpy(g[f"step.{n}{k}"]).to(DEV) for n in ("xt", "xtm1", "v", "m1", "z_in"))
+        hist, z, extra = m1.clone(), torch.empty_like(xt), torch.empty_like(xt)
+        L.check(lib.aed_sa_get_zs_from_xts(xt.data_ptr(), xtm1.data_ptr(), v.data_ptr(), None, 0.0, cf, hist.data_ptr(),
+                                           1, z.data_ptr(), extra.data_ptr(), xt.numel(), L.current_stream_ptr()))
+        hist2, prev = m1.clone(), torch.empty_like(xt)
+        L.check(lib.aed_sa_reverse_step_with_custom_noise(xt.data_ptr(), v.data_ptr(), None, 0.0, cf, hist2.data_ptr(),
+                                                          zin.data_ptr(), prev.data_ptr(), xt.numel(),
+                                                          L.current_stream_ptr()))
+        torch.cuda.synchronize()
+        for got, name in ((z, "z"), (xtm1, "xfix"), (hist, "d"), (hist2, "d"), (prev, "prev"), (extra, "m1")):
+            np.testing.assert_array_equal(got.cpu().numpy(), g[f"step.{name}{k}"], err_msg=f"step {i} {name}")
+
+
+def test_cfg_inside_the_solver_step():
+    """v = v_u + cfg * (v_c - v_u) fused in front of the step equals the step on the pre-combined prediction."""
+    s = CosineDPMSolverMultistepScheduler()
+    s.set_timesteps(50)
+    from audioeditingcode_amd.scheduler import sa_step_coefficients
+    cf = (ctypes.c_float * L.SA_COEF_STRIDE)(*sa_step_coefficients(s, 20, 2).tolist())
+    xt, xtm1, vu, vc, m1 = (rnd(1, 64, 128, seed=k).to(DEV) for k in range(5))
+    outs = []
+    for fused in (True, False):
+        hist, z, xm = m1.clone(), torch.empty_like(xt), xtm1.clone()
+        a = vu if fused else (vu + 3.5 * (vc - vu))
+        L.check(L.lib().aed_sa_get_zs_from_xts(xt.data_ptr(), xm.data_ptr(), a.data_ptr(), vc.data_ptr() if fused else None,
+                                               3.5, cf, hist.data_ptr(), 1, z.data_ptr(), None, xt.numel(),
+                                               L.current_stream_ptr()))
+        torch.cuda.synchronize()
+        outs.append((z.cpu(), xm.cpu(), hist.cpu()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
+def test_rotary_snake_gauss_sample_and_scaled_copy():
+    # rotary on the q and k sections of a fused qkv buffer, first R of D features of every head
+    B, N, H, D, R = 2, 37, 3, 32, 16
+    C = H * D
+    qkv = rnd(B * N, 3 * C, seed=1)
+    cos, sin = osa.rotary_table(R, N)
+    ref = qkv.clone().view(B, N, 3, H, D)
+    for sec in (0, 1):
+        ref[:, :, sec] = osa.apply_rotary(ref[:, :, sec].permute(0, 2, 1, 3), cos, sin).permute(0, 2, 1, 3)
+    tp = Tape(DEV)
+    x = qkv.to(DEV)
+    tp.rotary(x, cos[:, : R // 2].contiguous().to(DEV), sin[:, : R // 2].contiguous().to(DEV), M=B * N, N=N, H=H, D=D,
+              R=R, nsec=2, sec_stride=C)
+    # Snake1d
+    rows, Cs = 1000, 48
+    xs, al, be = rnd(rows, Cs, seed=2) * 2, rnd(Cs, seed=3) * 0.3, rnd(Cs, seed=4) * 0.3
+    ys = tp.alloc(rows, Cs)
+    tp.snake(xs.to(DEV), ys, torch.exp(al).to(DEV), (torch.exp(be) + 1e-9).reciprocal().to(DEV), rows=rows, C=Cs)
+    sref = osa.snake(xs.t()[None], al.view(1, -1, 1), be.view(1, -1, 1))[0].t()
+    # posterior sample
+    mom, noise = rnd(50, 16, seed=5) * 3, rnd(50, 8, seed=6)
+    mom[0, 8] = 25.0                                         # softplus threshold branch
+    smp = tp.alloc(50, 8)
+    tp.gauss_sample(mom.to(DEV), noise.to(DEV), smp, rows=50, C=8)
+    gref = mom[:, :8] + (F.softplus(mom[:, 8:]) + 1e-4) * noise
+    # copy with a per-step scale read from a device table
+    coef = rnd(5, 12, seed=7).to(DEV)
+    state = torch.tensor([3, 0, 0, 0], dtype=torch.int32, device=DEV)
+    src, dst = rnd(4, 2, 100, seed=8).to(DEV), tp.alloc(1, 200)
+    tp.copy2d(src, dst, rows=1, cols=200, ld_src=200, ld_dst=200, state=state, idx_off=4, idx_mul=-1, idx_stride=200,
+              coef=coef, c_mul=1, c_off=1, c_stride=12, c_col=0)
+    # learned Fourier time features from a float table
+    tt = (2 * math.pi * torch.tensor([0.1, 0.5, 0.9, 0.7])).to(DEV)
+    w = rnd(16, seed=9).to(DEV)
+    tf = tp.alloc(2, 32)
+    tp.time_embed(tf, B=2, dim=32, flip=True, timesteps=tt, state=state, freqs=w, float_table=True)
+    run(tp)
+    assert rel(x.cpu().view(B, N, 3, H, D), ref) < 1e-6
+    assert (ys.cpu() - sref).abs().max() < 2e-6 * float(sref.abs().max())
+    assert (smp.cpu() - gref).abs().max() < 1e-5
+    assert torch.equal(dst.cpu().view(-1), (src[1].reshape(-1) * coef[4, 0]).cpu())
+    arg = tt[3].cpu() * w.cpu()
+    assert (tf.cpu() - torch.cat([arg.cos(), arg.sin()])[None].expand(2, -1)).abs().max() < 2e-6
+
+
+@pytest.mark.parametrize("tile", [13, 14, 15, 17, 1, 3])
+def test_fused_swiglu(tile):
+    """FF1 of the DiT: LayerNorm folded in, SiLU gate in the epilogue (packed value/gate rows)."""
+    from audioeditingcode_amd.unet import geglu_pack_index
+    M, C = (300, 128) if tile not in (1, 3) else (1100, 128)
+    dff = 4 * C
+    x = rnd(M, C, seed=1) * 1.5 + 0.2
+    w, b = rnd(2 * dff, C, seed=2, scale=0.08), rnd(2 * dff, seed=3, scale=0.1)
+    ga, be = 1 + 0.1 * rnd(C, seed=4), 0.1 * rnd(C, seed=5)
+    perm = geglu_pack_index(dff)
+    wf = (w[perm].double() * ga.double()[None]).float()
+    t = (w[perm].double() @ be.double() + b[perm].double()).float()
+    tp = Tape(DEV)
+    out = tp.alloc(M, dff)
+    tp.linear(x.to(DEV), wf.to(DEV), t.to(DEV), out, M=M, K=C, N=2 * dff, ln_rowsum=wf.double().sum(1).float().to(DEV),
+              geglu=2, tile=tile)
+    run(tp)
+    a, gate = F.linear(F.layer_norm(x, (C,), ga, be), w, b).chunk(2, dim=-1)
+    assert (out.cpu() - a * F.silu(gate)).abs().max() < 5e-5
+
+
+# ------------------------------------------------------------------------------------------------ DiT
+def _dit_case(cfg, S, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(2, cfg["in_channels"], cfg["sample_size"], generator=g)
+    x[1] = x[0]
+    ctx = torch.randn(2, S, cfg["cross_attention_input_dim"], generator=g)
+    ctx[0] = 0
+    glob = torch.randn(1, cfg["global_states_input_dim"], generator=g).expand(2, -1).contiguous()
+    return x, ctx, glob
+
+
+@pytest.mark.parametrize("size", ["tiny", "full"])
+def test_dit_forward_matches_oracle(size):
+    from audioeditingcode_amd.stable_audio import DiTEngine
+    if size == "tiny":
+        cfg, S, tol = configs.get_family("tiny/stable-audio-open-1.0")["dit"], 8, 3e-5
+    else:                                   # Stable Audio Open 1.0 width (1536, 24 heads, 12 kv heads, 130-token context,
+        cfg = dict(configs.FAMILIES["stable_audio"]["dit"])     # 1025-token sequence) at 4 of its 24 layers
+        cfg["num_layers"] = 4
+        S, tol = 130, 2e-4
+    sd = weights.random_state_dict(weights.dit_param_shapes(cfg), seed=3)
+    x, ctx, glob = _dit_case(cfg, S, 5)
+    s = CosineDPMSolverMultistepScheduler()
+    s.set_timesteps(200)
+    t = s.timesteps[90]
+    eng = DiTEngine(cfg, sd, DEV, 2, S)
+    eng.set_conditioning(ctx, glob)
+    eng.set_timestep(t)
+    eng.x_in.copy_(x.transpose(1, 2))
+    v = eng.forward().transpose(1, 2).cpu()
+    torch.cuda.synchronize()
+    ref = osa.dit_forward(sd, cfg, x, t.reshape(1), ctx, glob[:, None, :],
+                          osa.rotary_table(cfg["attention_head_dim"] // 2, cfg["sample_size"] + 1))
+    assert torch.isfinite(v).all() and rel(v, ref) < tol, rel(v, ref)
+    assert float((v[0] - v[1]).abs().max()) > 1e-3          # the conditioned row differs from the zero-context row
+
+
+# ------------------------------------------------------------------------------------------------ Oobleck
+@pytest.mark.parametrize("size", ["tiny", "full"])
+def test_oobleck_encode_decode_match_oracle(size):
+    from audioeditingcode_amd.stable_audio import OobleckDecoder, OobleckEncoder
+    if size == "tiny":
+        cfg, Lz = configs.get_family("tiny/stable-audio-open-1.0")["oobleck"], 16
+    else:                                   # full channel widths (128 .. 2048), hop 2048, a 0.74 s window
+        cfg, Lz = configs.FAMILIES["stable_audio"]["oobleck"], 16
+    sd = weights.random_state_dict(weights.oobleck_param_shapes(cfg), seed=6)
+    hop = math.prod(cfg["downsampling_ratios"])
+    g = torch.Generator().manual_seed(2)
+    audio = torch.randn(1, cfg["audio_channels"], Lz * hop, generator=g) * 0.5
+    noise = torch.randn(1, cfg["decoder_input_channels"], Lz, generator=g)
+    enc = OobleckEncoder(cfg, sd, DEV, 1, Lz * hop)
+    z = enc(audio.transpose(1, 2), noise.transpose(1, 2)).transpose(1, 2).cpu()
+    mean, std = osa.oobleck_encode(sd, cfg, audio)
+    ref = mean + std * noise
+    assert rel(z, ref) < 1e-4, rel(z, ref)
+    dec = OobleckDecoder(cfg, sd, DEV, 1, Lz)
+    wav = dec(ref.transpose(1, 2)).transpose(1, 2).cpu()
+    rw = osa.oobleck_decode(sd, cfg, ref)
+    assert wav.shape == rw.shape == (1, cfg["audio_channels"], Lz * hop) and rel(wav, rw) < 2e-4, rel(wav, rw)
+
+
+# ------------------------------------------------------------------------------------------------ loops
+@pytest.mark.parametrize("mode,first", [("sequential", False), ("batched", False), ("sequential", True)])
+def test_device_loops_match_oracle(mode, first):
+    from audioeditingcode_amd.stable_audio import StableAudioEditEngine
+    cfg = configs.get_family("tiny/stable-audio-open-1.0")["dit"]
+    sd = weights.random_state_dict(weights.dit_param_shapes(cfg), seed=4)
+    T, tstart, S = 12, 8, 6
+    sched = CosineDPMSolverMultistepScheduler()
+    sched.set_timesteps(T)
+    g = torch.Generator().manual_seed(11)
+    x0 = torch.randn(1, cfg["in_channels"], cfg["sample_size"], generator=g)
+    ctx_src = torch.randn(1, S, cfg["cross_attention_input_dim"], generator=g)
+    ctx_tgt = torch.randn(1, S, cfg["cross_attention_input_dim"], generator=g)
+    ctx_unc = torch.zeros_like(ctx_src)
+    glob = torch.randn(1, cfg["global_states_input_dim"], generator=g)
+    noise = torch.stack([torch.randn(x0.shape, generator=g) for _ in range(T)])
+    eng = StableAudioEditEngine(cfg, sd, sched, DEV)
+    zs, xts, extra = eng.invert(x0, ctx_src, ctx_unc, glob, 3.0, first_order=first, noise=noise, mode=mode, group=4)
+    zs, xts, extra = zs.clone(), xts.clone(), extra.clone()
+    w = eng.edit(xts, zs, tstart, ctx_tgt, ctx_unc, glob, 5.0, extra=extra, first_order=first)
+    # trajectory replay (SURVEY section 4 invariant): same prompt / guidance both ways walks the stored trajectory back
+    back = eng.edit(xts, zs, tstart, ctx_src, ctx_unc, glob, 3.0, extra=extra, first_order=first)
+    torch.cuda.synchronize()
+    osched = osa.OracleCosineDPMSolverScheduler()
+    osched.set_timesteps(T)
+    rot = osa.rotary_table(cfg["attention_head_dim"] // 2, cfg["sample_size"] + 1)
+
+    def dit(x_inp, t, ctx):
+        return osa.dit_forward(sd, cfg, x_inp, t.reshape(1), ctx, glob[:, None, :], rot)
+    ow = osa.OracleStableAudio(osched, dit, in_channels=cfg["in_channels"], sample_size=cfg["sample_size"])
+    sig = torch.stack([osched.sigmas[T - (r + 1)] for r in range(T)])[:, None, None]
+    oxts0 = torch.cat([x0, x0 + noise[:, 0] * sig])
+    _, ozs, oxts, oextra = osa.invert(ow, x0, ctx_src, ctx_unc, 3.0, T, first_order=first, xts=oxts0.clone())
+    ow2 = osa.edit(ow, oxts, tstart, ctx_tgt, ctx_unc, 5.0, ozs[:tstart], extra_info=oextra, first_order=first)
+    cl = lambda t: t.transpose(-1, -2).cpu()                        # noqa: E731
+    tol = 2e-4 if mode == "sequential" else 3e-3
+    assert rel(cl(xts), oxts) < tol and rel(cl(zs), ozs) < 10 * tol, (rel(cl(xts), oxts), rel(cl(zs), ozs))
+    assert rel(cl(w), ow2[0]) < 20 * tol, rel(cl(w), ow2[0])
+    assert rel(back, xts[0]) < 20 * tol, rel(back, xts[0])
+
+
+def test_wrapper_edit_clip_on_the_gpu():
+    """load_model -> load_audio (raw waveform) -> Oobleck encode -> inversion -> edit -> Oobleck decode through the
+    reference's API names; batched and sequential schedules agree; finite audio of the requested duration."""
+    from audioeditingcode_amd.main_run import edit_clip
+    from audioeditingcode_amd.models import load_model
+    from audioeditingcode_amd.utils import load_audio
+    T, tstart = 8, 5
+    m = load_model("tiny/stable-audio-open-1.0", DEV, T)
+    n = m.model.transformer.config.sample_size * m.model.vae.hop_length
+    sr = m.get_sr()
+    wav = (rnd(2, n - 16, seed=3) * 0.1).numpy()
+    x0, _, duration = load_audio((wav, sr), None, stft=False, model_sr=sr)
+    outs = []
+    for schedule in ("sequential", "batched"):
+        torch.manual_seed(9)
+        audio, orig, w_edit = edit_clip(m, x0, ["a dog barking"], ["a cat meowing"], [""], [2.0], [6.0], T, tstart,
+                                        duration=duration, schedule=schedule, timestep_group=4)
+        assert audio.shape == (2, int(duration * sr)) and torch.isfinite(audio).all()
+        outs.append(w_edit.cpu())
+    assert rel(outs[1], outs[0]) < 2e-2
+    # same clip through the oracle
+    torch.manual_seed(9)
+    ocfg, osd = m.family["oobleck"], m.state_dicts["vae"]
+    a = torch.zeros(1, 2, n)
+    a[:, :, : n - 16] = x0[None]
+    mean, std = osa.oobleck_encode(osd, ocfg, a)
+    w0 = mean + std * torch.randn(mean.shape)
+    cfg, sd = m.family["dit"], m.state_dicts["transformer"]
+    osched = osa.OracleCosineDPMSolverScheduler()
+    osched.set_timesteps(T)
+    rot = osa.rotary_table(cfg["attention_head_dim"] // 2, cfg["sample_size"] + 1)
+    glob = m.audio_duration_embeds.cpu()
+    ow = osa.OracleStableAudio(osched, lambda x, t, c: osa.dit_forward(sd, cfg, x, t.reshape(1), c, glob, rot),
+                               in_channels=cfg["in_channels"], sample_size=cfg["sample_size"])
+    xts0 = ow.sample_xts_from_x0(w0, T)
+    ctxs = [m.assemble_context(*[m.encode_text([p], negative=neg)[k] for k in (0, 2)]).cpu()
+            for p, neg in (("a dog barking", False), ("a cat meowing", False), ("", True))]
+    _, zs, xts, extra = osa.invert(ow, w0, ctxs[0], ctxs[2], 2.0, T, xts=xts0)
+    w_o = osa.edit(ow, xts, tstart, ctxs[1], ctxs[2], 6.0, zs[:tstart], extra_info=extra)
+    assert rel(outs[0], w_o) < 5e-3, rel(outs[0], w_o)

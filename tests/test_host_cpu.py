@@ -32,7 +32,7 @@ def test_library_exports_every_header_symbol():
     for sym in declared:
         assert hasattr(lib, sym), f"{sym} declared in include/aed.h but not exported by libaed.so"
     assert sorted(L.EXPORTS) == declared
-    assert L.lib().aed_version() == 2
+    assert L.lib().aed_version() == 3
     assert ctypes.sizeof(L.aed_op) == 4 + 4 + 40 * 4 + 8 * 4 + 10 * 8
 
 

@@ -1,0 +1,273 @@
+"""Stable Audio Open path, host logic on CPU: the tapes the product lays out (DiT, Oobleck, loops) are executed by the
+tape interpreter (oracle/tape_interp.py, test instrumentation) and compared with the plain-torch restatement
+(oracle/stable_audio.py).  Catches graph / packing / indexing mistakes before the GPU run; the kernels themselves are
+checked by tests/test_gpu_stable_audio.py."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from audioeditingcode_amd import configs, weights
+from audioeditingcode_amd.scheduler import CosineDPMSolverMultistepScheduler
+from oracle import stable_audio as osa
+
+
+def _family():
+    return configs.get_family("tiny/stable-audio-open-1.0")
+
+
+def _dit_inputs(cfg, S, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(2, cfg["in_channels"], cfg["sample_size"], generator=g)
+    x[1] = x[0]
+    ctx = torch.randn(2, S, cfg["cross_attention_input_dim"], generator=g)
+    ctx[0] = 0                                                      # unconditional row: zeroed context
+    glob = torch.randn(1, cfg["global_states_input_dim"], generator=g).expand(2, -1).contiguous()
+    return x, ctx, glob
+
+
+def test_parameter_inventories_match_the_published_sizes():
+    fam = configs.FAMILIES["stable_audio"]
+    assert abs(weights.count_params(weights.dit_param_shapes(fam["dit"])) / 1e6 - 1057) < 2          # "1.06 B" DiT
+    assert abs(weights.count_params(weights.oobleck_param_shapes(fam["oobleck"])) / 1e6 - 156) < 1   # 156 M autoencoder
+    assert math.prod(fam["oobleck"]["downsampling_ratios"]) == 2048
+
+
+def test_dit_tape_matches_oracle(cpu_stack):
+    from audioeditingcode_amd.stable_audio import DiTEngine
+    cfg = _family()["dit"]
+    sd = weights.random_state_dict(weights.dit_param_shapes(cfg), seed=3)
+    S = 8
+    x, ctx, glob = _dit_inputs(cfg, S, 5)
+    sched = CosineDPMSolverMultistepScheduler()
+    sched.set_timesteps(10)
+    t = sched.timesteps[4]
+    eng = DiTEngine(cfg, sd, "cpu", 2, S)
+    eng.set_conditioning(ctx, glob)
+    eng.set_timestep(t)
+    eng.x_in.copy_(x.transpose(1, 2))
+    v = eng.forward().transpose(1, 2)
+    ref = osa.dit_forward(sd, cfg, x, t.reshape(1), ctx, glob[:, None, :],
+                          osa.rotary_table(cfg["attention_head_dim"] // 2, cfg["sample_size"] + 1))
+    err = float((v - ref).abs().max() / ref.abs().max())
+    assert err < 2e-5, err
+    names = [m["name"] for m in eng.tape.meta]
+    L = cfg["num_layers"]
+    assert sum(n.endswith("rotary") for n in names) == L and sum("sdpa" in n for n in names) == 2 * L
+    assert sum(n.endswith("+swiglu") for n in names) == L and len(eng.ctx_tape.ops) == 4 + L
+    # FLOP inventory of the full-size model: ~2.1 TFLOP per sample forward
+    full = configs.FAMILIES["stable_audio"]["dit"]
+    Cf = full["num_attention_heads"] * full["attention_head_dim"]
+    per_tok = full["num_layers"] * (4 * Cf * Cf + 2 * Cf * Cf + 3 * Cf * 4 * Cf)
+    assert abs(2 * per_tok * 1025 / 1e12 - 2.1) < 0.1
+
+
+@pytest.mark.parametrize("mode,first", [("sequential", False), ("batched", False), ("sequential", True)])
+def test_loops_match_oracle(cpu_stack, mode, first):
+    from audioeditingcode_amd.stable_audio import StableAudioEditEngine
+    cfg = _family()["dit"]
+    sd = weights.random_state_dict(weights.dit_param_shapes(cfg), seed=4)
+    T, tstart, S = 8, 5, 6
+    sched = CosineDPMSolverMultistepScheduler()
+    sched.set_timesteps(T)
+    g = torch.Generator().manual_seed(11)
+    x0 = torch.randn(1, cfg["in_channels"], cfg["sample_size"], generator=g)
+    ctx_src = torch.randn(1, S, cfg["cross_attention_input_dim"], generator=g)
+    ctx_tgt = torch.randn(1, S, cfg["cross_attention_input_dim"], generator=g)
+    ctx_unc = torch.zeros_like(ctx_src)
+    glob = torch.randn(1, cfg["global_states_input_dim"], generator=g)
+    noise = torch.stack([torch.randn(x0.shape, generator=g) for _ in range(T)])
+
+    eng = StableAudioEditEngine(cfg, sd, sched, "cpu")
+    zs, xts, extra = eng.invert(x0, ctx_src, ctx_unc, glob, 3.0, first_order=first, noise=noise, mode=mode, group=4)
+    zs, xts, extra = zs.clone(), xts.clone(), extra.clone()
+    w = eng.edit(xts, zs, tstart, ctx_tgt, ctx_unc, glob, 5.0, extra=extra, first_order=first)
+
+    osched = osa.OracleCosineDPMSolverScheduler()
+    osched.set_timesteps(T)
+    rot = osa.rotary_table(cfg["attention_head_dim"] // 2, cfg["sample_size"] + 1)
+
+    def dit(x_inp, t, ctx):
+        return osa.dit_forward(sd, cfg, x_inp, t.reshape(1), ctx, glob[:, None, :], rot)
+    ow = osa.OracleStableAudio(osched, dit, in_channels=cfg["in_channels"], sample_size=cfg["sample_size"])
+    oxts0 = torch.cat([x0, x0 + noise[:, 0] * torch.stack([osched.sigmas[T - (r + 1)] for r in range(T)])[:, None, None]])
+    _, ozs, oxts, oextra = osa.invert(ow, x0, ctx_src, ctx_unc, 3.0, T, first_order=first, xts=oxts0.clone())
+    ow2 = osa.edit(ow, oxts, tstart, ctx_tgt, ctx_unc, 5.0, ozs[:tstart], extra_info=oextra, first_order=first)
+
+    tol = 3e-5 if mode == "sequential" else 2e-3       # batched: x_t enters the DiT before its ~1-ulp numerical fix
+    cl = lambda t: t.transpose(-1, -2)                  # noqa: E731
+    np.testing.assert_allclose(cl(xts).numpy(), oxts.numpy(), atol=tol * float(oxts.abs().max()))
+    np.testing.assert_allclose(cl(zs).numpy(), ozs.numpy(), atol=tol * max(1.0, float(ozs.abs().max())))
+    for i in range(T - 1):
+        np.testing.assert_allclose(cl(extra[i]).numpy(), oextra[i][0].numpy(), atol=tol * 10)
+    assert oextra[T - 1] is None
+    np.testing.assert_allclose(cl(w).numpy(), ow2[0].numpy(), atol=10 * tol * float(ow2.abs().max()))
+
+
+def test_oobleck_tapes_match_oracle(cpu_stack):
+    from audioeditingcode_amd.stable_audio import OobleckDecoder, OobleckEncoder
+    cfg = _family()["oobleck"]
+    sd = weights.random_state_dict(weights.oobleck_param_shapes(cfg), seed=6)
+    hop = math.prod(cfg["downsampling_ratios"])
+    g = torch.Generator().manual_seed(2)
+    audio = torch.randn(1, cfg["audio_channels"], 16 * hop, generator=g) * 0.5
+    enc = OobleckEncoder(cfg, sd, "cpu", 1, 16 * hop)
+    noise = torch.randn(1, cfg["decoder_input_channels"], 16, generator=g)
+    z = enc(audio.transpose(1, 2), noise.transpose(1, 2)).transpose(1, 2)
+    mean, std = osa.oobleck_encode(sd, cfg, audio)
+    ref = mean + std * noise
+    assert float((z - ref).abs().max() / ref.abs().max()) < 2e-5
+    dec = OobleckDecoder(cfg, sd, "cpu", 1, 16)
+    wav = dec(ref.transpose(1, 2)).transpose(1, 2)
+    rw = osa.oobleck_decode(sd, cfg, ref)
+    assert wav.shape == rw.shape == (1, cfg["audio_channels"], 16 * hop)
+    assert float((wav - rw).abs().max() / rw.abs().max()) < 2e-5
+
+
+# ------------------------------------------------------------------------------------------------ wrapper level
+def _cpu_wrapper(T):
+    from audioeditingcode_amd import models
+
+    class _CpuSA(models.StableAudWrapper):
+        def _require_device(self):           # test instrumentation only: the product class refuses a CPU device
+            pass
+    m = _CpuSA(model_id="tiny/stable-audio-open-1.0", device="cpu", seed=0)
+    m.load_scheduler()
+    m.model.scheduler.set_timesteps(T, device=None)
+    return m
+
+
+def _oracle_of(m, T):
+    cfg, sd = m.family["dit"], m.state_dicts["transformer"]
+    osched = osa.OracleCosineDPMSolverScheduler()
+    osched.set_timesteps(T)
+    rot = osa.rotary_table(cfg["attention_head_dim"] // 2, cfg["sample_size"] + 1)
+
+    def dit(x_inp, t, ctx):
+        return osa.dit_forward(sd, cfg, x_inp, t.reshape(1), ctx, m.audio_duration_embeds, rot)
+    return osa.OracleStableAudio(osched, dit, in_channels=cfg["in_channels"], sample_size=cfg["sample_size"])
+
+
+def test_product_wrapper_refuses_cpu_and_load_model_dispatches():
+    from audioeditingcode_amd import _lib as L
+    from audioeditingcode_amd import models
+    assert configs.family_of("stabilityai/stable-audio-open-1.0") == "stable_audio"
+    with pytest.raises(L.AedError):
+        models.load_model("tiny/stable-audio-open-1.0", "cpu", 10)
+
+
+def test_edit_clip_through_the_wrapper_api(cpu_stack):
+    """raw waveform -> Oobleck encode (posterior sample) -> inversion -> edit -> Oobleck decode, vs the oracle."""
+    from audioeditingcode_amd.main_run import edit_clip
+    from audioeditingcode_amd.utils import load_audio
+    T, tstart = 6, 4
+    m = _cpu_wrapper(T)
+    hop = m.model.vae.hop_length
+    n = m.model.transformer.config.sample_size * hop
+    sr = m.get_sr()
+    g = torch.Generator().manual_seed(3)
+    wav = (torch.randn(2, n - 40, generator=g) * 0.1).numpy()
+    x0, sr2, duration = load_audio((wav, sr), None, stft=False, model_sr=sr)
+    assert sr2 == sr and x0.shape == (2, n - 40) and abs(float(x0.abs().max()) - 0.5) < 1e-6
+    assert abs(duration - (n - 40) / sr) < 1e-9
+    torch.manual_seed(9)
+    audio, orig, w_edit = edit_clip(m, x0, ["a dog barking"], ["a cat meowing"], [""], [2.0], [6.0], T, tstart,
+                                    duration=duration)
+    assert audio.shape == (2, int(duration * sr)) and torch.isfinite(audio).all() and orig.shape == x0.shape
+
+    # the same clip through the oracle (same CPU generator stream: posterior noise first, then the T x_t draws)
+    torch.manual_seed(9)
+    ocfg, osd = m.family["oobleck"], m.state_dicts["vae"]
+    a = torch.zeros(1, 2, n)
+    a[:, :, : n - 40] = x0[None]
+    mean, std = osa.oobleck_encode(osd, ocfg, a)
+    w0 = mean + std * torch.randn(mean.shape)
+    ow = _oracle_of(m, T)
+    xts0 = ow.sample_xts_from_x0(w0, T)
+    src = m.assemble_context(*[m.encode_text(["a dog barking"])[k] for k in (0, 2)])
+    tgt = m.assemble_context(*[m.encode_text(["a cat meowing"])[k] for k in (0, 2)])
+    unc = m.assemble_context(*[m.encode_text([""], negative=True)[k] for k in (0, 2)])
+    assert float(unc.abs().max()) == 0.0
+    _, zs, xts, extra = osa.invert(ow, w0, src, unc, 2.0, T, xts=xts0)
+    w_o = osa.edit(ow, xts, tstart, tgt, unc, 6.0, zs[:tstart], extra_info=extra)
+    err = float((w_edit - w_o).abs().max() / w_o.abs().max())
+    assert err < 2e-3, err
+    wav_o = osa.oobleck_decode(osd, ocfg, w_o)[:, :, : int(duration * sr)]
+    assert float((audio - wav_o[0]).abs().max() / wav_o.abs().max()) < 5e-3
+
+
+def test_host_driven_methods_follow_the_reference_call_pattern(cpu_stack):
+    """The reference's own loop (scale_model_input -> unet_forward x2 -> get_zs_from_xts / reverse_step_with_custom_noise,
+    inversion_utils.py:74-129, :221-315) driven through the wrapper's methods equals the device-resident loop."""
+    from audioeditingcode_amd.ddm_inversion.inversion_utils import inversion_forward_process, inversion_reverse_process
+    T, tstart = 5, 3
+    m = _cpu_wrapper(T)
+    c = m.model.transformer.config
+    g = torch.Generator().manual_seed(1)
+    x0 = torch.randn(1, c.in_channels, c.sample_size, generator=g)
+    torch.manual_seed(4)
+    _, zs, xts, extra = inversion_forward_process(m, x0, etas=1.0, prompts=["rain"], cfg_scales=[3.0],
+                                                  num_inference_steps=T, numerical_fix=True, duration=0.2)
+    w, _ = inversion_reverse_process(m, xT=xts, tstart=torch.tensor([tstart]), etas=1.0, prompts=["jazz"],
+                                     neg_prompts=[""], cfg_scales=[5.0], zs=zs[:tstart], duration=0.2, extra_info=extra)
+    # host-driven replay with the wrapper's step methods
+    s = m.model.scheduler
+    torch.manual_seed(4)
+    hs, _, mk = m.encode_text(["rain"])
+    uhs, _, umk = m.encode_text([""], negative=True)
+    xts2 = m.sample_xts_from_x0(x0, num_inference_steps=T)
+    zs2 = torch.zeros(m.get_noise_shape(x0, T))
+    extra2 = [None] * T
+    t_to_idx = {float(v): k for k, v in enumerate(s.timesteps)}
+    m.setup_extra_inputs(x0, init_timestep=s.timesteps[0], audio_end_in_s=0.2)
+    for t in s.timesteps:
+        idx = T - t_to_idx[float(t)] - 1
+        xt = xts2[idx + 1][None]
+        xi = s.scale_model_input(xt, t)
+        u = m.unet_forward(xi, timestep=t, encoder_hidden_states=uhs, encoder_attention_mask=umk)[0].sample
+        cnd = m.unet_forward(xi, timestep=t, encoder_hidden_states=hs, encoder_attention_mask=mk)[0].sample
+        z, xtm1, ex = m.get_zs_from_xts(xt, xts2[idx][None], u + 3.0 * (cnd - u), t, numerical_fix=True)
+        zs2[idx], xts2[idx], extra2[idx] = z, xtm1, ex
+    zs2[0] = 0
+    np.testing.assert_allclose(zs2.numpy(), zs.numpy(), atol=2e-4 * float(zs.abs().max()))
+    np.testing.assert_allclose(xts2.numpy(), xts.numpy(), atol=2e-5 * float(xts.abs().max()))
+    assert extra2[T - 1] is None and extra[T - 1] is None
+    hs, _, mk = m.encode_text(["jazz"])
+    xt = xts2[tstart].unsqueeze(0)
+    m.setup_extra_inputs(xt, extra_info=extra2, init_timestep=s.timesteps[-tstart], audio_end_in_s=0.2)
+    for k, t in enumerate(s.timesteps[-tstart:]):
+        idx = tstart - k - 1
+        xi = s.scale_model_input(xt, t)
+        u = m.unet_forward(xi, timestep=t, encoder_hidden_states=uhs, encoder_attention_mask=umk)[0].sample
+        cnd = m.unet_forward(xi, timestep=t, encoder_hidden_states=hs, encoder_attention_mask=mk)[0].sample
+        xt = m.reverse_step_with_custom_noise(u + 5.0 * (cnd - u), t, xt, variance_noise=zs2[idx].unsqueeze(0))
+    assert float((xt - w).abs().max() / w.abs().max()) < 2e-3
+
+
+def test_step_coefficients_and_interpreter_reproduce_the_reference_step_vectors(golden_dir):
+    """tests/golden/sa_wrapper.npz step.*: produced by the reference's get_zs_from_xts / reverse_step_with_custom_noise at
+    steps 0, 1, 57, 150, 198, 199 of the T=200 schedule.  The coefficient table of THIS machine must agree with the
+    fixture's to rounding, and the expression order the kernel uses (stated in plain torch by the interpreter's entry
+    points) must reproduce the vectors bit for bit."""
+    import ctypes
+    import os
+    from audioeditingcode_amd.scheduler import sa_step_coefficients
+    from oracle import tape_interp
+    g = np.load(os.path.join(golden_dir, "sa_wrapper.npz"))
+    s = CosineDPMSolverMultistepScheduler()
+    s.set_timesteps(200)
+    fl = tape_interp.FakeLib()
+    for k, (i, order) in enumerate(g["step.index_order"]):
+        c = sa_step_coefficients(s, int(i), int(order), zero_z=(i == 199))
+        np.testing.assert_allclose(c.numpy(), g[f"step.coef{k}"], rtol=3e-6, atol=1e-9)
+        cf = (ctypes.c_float * 12)(*g[f"step.coef{k}"].tolist())
+        xt, xtm1, v, m1, zin = (torch.from_numpy(g[f"step.{n}{k}"].copy()) for n in ("xt", "xtm1", "v", "m1", "z_in"))
+        hist, z = m1.clone(), torch.empty_like(xt)
+        fl.aed_sa_get_zs_from_xts(xt.data_ptr(), xtm1.data_ptr(), v.data_ptr(), None, 0.0, cf, hist.data_ptr(), 1,
+                                  z.data_ptr(), None, xt.numel(), None)
+        hist2, prev = m1.clone(), torch.empty_like(xt)
+        fl.aed_sa_reverse_step_with_custom_noise(xt.data_ptr(), v.data_ptr(), None, 0.0, cf, hist2.data_ptr(),
+                                                 zin.data_ptr(), prev.data_ptr(), xt.numel(), None)
+        for got, name in ((z, "z"), (xtm1, "xfix"), (hist, "d"), (prev, "prev")):
+            np.testing.assert_array_equal(got.numpy(), g[f"step.{name}{k}"])

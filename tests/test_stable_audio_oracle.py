@@ -1,0 +1,144 @@
+"""Stable Audio Open path: the oracle restatement against fixtures produced by the reference's OWN
+StableAudWrapper methods and loops (tests/golden/sa_wrapper.npz, oracle/make_golden.py stable_audio), plus properties of
+the restated third-party pieces (scheduler tables, DiT, Oobleck) that nothing in this image can pin."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import stable_audio as osa
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+SI = osa.StandIns
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(G, "sa_wrapper.npz"))
+
+
+def _cond(prompt, negative, start, end):
+    e, _, mask = osa.encode_text_rule(SI.Tok(), SI.TextEnc(), SI.projection_model, [prompt], negative=negative)
+    return osa.assemble_context(e, mask, start, end)
+
+
+def _oracle_model(T, duration):
+    sched = osa.OracleCosineDPMSolverScheduler()
+    sched.set_timesteps(T)
+    start, end = SI.encode_duration(0.0, duration)
+    glob = torch.cat([start, end], dim=2)
+    rot = osa.rotary_table(4, SI.Lz + glob.shape[1])
+
+    def dit(x_inp, t, ctx):
+        return SI.transformer(x_inp, t.reshape(1), encoder_hidden_states=ctx, global_hidden_states=glob,
+                              rotary_embedding=rot).sample
+    return osa.OracleStableAudio(sched, dit, in_channels=SI.C, sample_size=SI.Lz), start, end
+
+
+@pytest.mark.parametrize("name", ["T20", "T20_emptysrc", "T12_first"])
+def test_loops_match_the_reference_wrapper(gold, name):
+    T, tstart, cfg_src, cfg_tar, seed, first = (float(v) for v in gold[f"{name}.meta"])
+    T, tstart, seed, first = int(T), int(tstart), int(seed), bool(first)
+    src, tgt = str(gold[f"{name}.src"]), str(gold[f"{name}.tgt"])
+    w, start, end = _oracle_model(T, 3.0)
+    np.testing.assert_array_equal(w.model.scheduler.sigmas.numpy(), gold[f"{name}.sigmas"])
+    x0 = torch.from_numpy(gold[f"{name}.x0"])
+    torch.manual_seed(seed)
+    xts0 = w.sample_xts_from_x0(x0, T)
+    np.testing.assert_array_equal(xts0.numpy(), gold[f"{name}.xts_init"])          # RNG draw order + x0 + n*sigma
+    unc = _cond("", True, start, end)
+    _, zs, xts, extra = osa.invert(w, x0, _cond(src, False, start, end), unc, cfg_src, T, src_is_empty=(src == ""),
+                                   first_order=first, xts=xts0.clone())
+    np.testing.assert_allclose(zs.numpy(), gold[f"{name}.zs"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(xts.numpy(), gold[f"{name}.xts"], rtol=0, atol=2e-5 * float(np.abs(gold[f"{name}.xts"]).max()))
+    ex = gold[f"{name}.extra"]
+    for i, e in enumerate(extra):
+        if e is None:
+            assert np.isnan(ex[i]).all()
+        else:
+            np.testing.assert_allclose(e.numpy(), ex[i], atol=2e-5)
+    out = osa.edit(w, xts, tstart, _cond(tgt, False, start, end), unc, cfg_tar, zs[:tstart], extra_info=extra,
+                   first_order=first)
+    np.testing.assert_allclose(out.numpy(), gold[f"{name}.w_edit"], atol=5e-5)
+
+
+def test_encode_text_and_context_rules(gold):
+    for tag, prompts, neg in (("pos", ["a dog barking"], False), ("neg", ["low quality"], True), ("empty", [""], True)):
+        e, _, mask = osa.encode_text_rule(SI.Tok(), SI.TextEnc(), SI.projection_model, prompts, negative=neg)
+        np.testing.assert_array_equal(e.numpy(), gold[f"enc.{tag}.embeds"])
+        assert (mask is None) == (gold[f"enc.{tag}.mask"].size == 0)
+    assert np.abs(gold["enc.raw"][0, -1]).max() > 0 and np.abs(gold["enc.pos.embeds"][0, -1]).max() == 0   # padded row masked
+    w, _, _ = _oracle_model(8, 2.5)
+    start, end = SI.encode_duration(0.0, 2.5)
+    glob = torch.cat([start, end], dim=2)
+    rot = osa.rotary_table(4, SI.Lz + 1)
+    x = torch.from_numpy(gold["fwd.x"])
+    t = w.model.scheduler.timesteps[3]
+    e, _, mask = osa.encode_text_rule(SI.Tok(), SI.TextEnc(), SI.projection_model, ["a dog barking"])
+    for key, m in (("fwd.cond", mask), ("fwd.uncond", None)):
+        ctx = osa.assemble_context(e, m, start, end)
+        out = SI.transformer(x, t.reshape(1), encoder_hidden_states=ctx, global_hidden_states=glob, rotary_embedding=rot)
+        np.testing.assert_array_equal(out.sample.numpy(), gold[key])
+    assert gold["fwd.wave_window"].tolist() == [0, 250]
+
+
+def test_reconstruction_property_any_size():
+    """Same prompt and guidance both ways: the edit replays the trajectory, so the latent at index 0 comes back."""
+    T, tstart = 24, 15
+    w, start, end = _oracle_model(T, 3.0)
+    x0 = torch.randn((1, SI.C, SI.Lz), generator=torch.Generator().manual_seed(7))
+    c, u = _cond("wind chimes", False, start, end), _cond("", True, start, end)
+    _, zs, xts, extra = osa.invert(w, x0, c, u, 2.0, T, generator=torch.Generator().manual_seed(8))
+    out = osa.edit(w, xts, tstart, c, u, 2.0, zs[:tstart], extra_info=extra)
+    assert float((out - xts[0]).abs().max()) < 2e-4
+    assert torch.equal(zs[0], torch.zeros_like(zs[0]))
+
+
+def test_scheduler_tables_properties():
+    s = osa.OracleCosineDPMSolverScheduler()
+    s.set_timesteps(200)
+    assert s.sigmas.shape == (201,) and s.timesteps.shape == (200,)
+    assert abs(float(s.sigmas[0]) - 500.0) < 1e-3 and abs(float(s.sigmas[199]) - 0.3) < 1e-6 and float(s.sigmas[200]) == 0
+    r = (s.sigmas[1:200] / s.sigmas[:199]).log()
+    assert float((r - r[0]).abs().max()) < 1e-4                     # exponential schedule: constant log ratio
+    np.testing.assert_allclose(s.timesteps.numpy(), np.arctan(s.sigmas[:200].numpy()) * 2 / math.pi, rtol=1e-6)
+    x, v = torch.randn(3, 5), torch.randn(3, 5)
+    sig = s.sigmas[50]
+    s._step_index = 50
+    d = s.convert_model_output(v, sample=x)                         # v-prediction, sigma_data = 1
+    np.testing.assert_allclose(d.numpy(), (x / (sig ** 2 + 1) - v * sig / (sig ** 2 + 1) ** 0.5).numpy(), rtol=1e-6)
+    # the first-order update with zero noise and the exact data prediction lands on the same-ratio interpolation
+    nxt = s.dpm_solver_first_order_update(d, sample=x, noise=torch.zeros_like(x))
+    h = float(torch.log(s.sigmas[50]) - torch.log(s.sigmas[51]))
+    ref = (float(s.sigmas[51] / s.sigmas[50]) * math.exp(-h)) * x + (1 - math.exp(-2 * h)) * d
+    np.testing.assert_allclose(nxt.numpy(), ref.numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_rotary_and_gqa_building_blocks():
+    cos, sin = osa.rotary_table(8, 5)
+    assert cos.shape == (5, 8) and torch.equal(cos[:, :4], cos[:, 4:])
+    x = torch.randn(1, 2, 5, 16)
+    y = osa.apply_rotary(x, cos, sin)
+    assert torch.equal(y[..., 8:], x[..., 8:])                               # features past the rotary dim untouched
+    np.testing.assert_allclose(y[..., :8].norm(dim=-1).numpy(), x[..., :8].norm(dim=-1).numpy(), rtol=1e-5)   # a rotation
+    assert torch.allclose(y[:, :, 0], x[:, :, 0])                            # position 0: identity
+
+
+def _rand_sd(shapes, seed):
+    g = torch.Generator().manual_seed(seed)
+    return {k: torch.randn(v, generator=g) * (0.5 / max(1, math.prod(v[1:])) ** 0.5 if len(v) > 1 else 0.1)
+            for k, v in shapes.items()}
+
+
+def test_oobleck_shapes_and_hop():
+    from audioeditingcode_amd import weights
+    cfg = dict(encoder_hidden_size=8, downsampling_ratios=[2, 4], channel_multiples=[1, 2], decoder_channels=8,
+               decoder_input_channels=4, audio_channels=2)
+    sd = _rand_sd(weights.oobleck_param_shapes(cfg), 3)
+    a = torch.randn(1, 2, 64, generator=torch.Generator().manual_seed(4))
+    mean, std = osa.oobleck_encode(sd, cfg, a)
+    assert mean.shape == (1, 4, 8) and std.shape == mean.shape and float(std.min()) >= 1e-4
+    wav = osa.oobleck_decode(sd, cfg, mean)
+    assert wav.shape == (1, 2, 64) and torch.isfinite(wav).all()

@@ -193,11 +193,21 @@ def test_oobleck_encode_decode_match_oracle(size):
     z = enc(audio.transpose(1, 2), noise.transpose(1, 2)).transpose(1, 2).cpu()
     mean, std = osa.oobleck_encode(sd, cfg, audio)
     ref = mean + std * noise
-    assert rel(z, ref) < 1e-4, rel(z, ref)
+    # fp32 noise floor of THIS network: sin(a*x) at |x| ~ 100 (random weights) turns summation-order differences of the
+    # K = 14 336 convolutions into ~1e-4 relative ones; measured against a float64 evaluation, the device must not be
+    # further from it than a small multiple of what the float32 CPU evaluation is
+    sd64 = {k: v.double() for k, v in sd.items()}
+    m64, s64 = osa.oobleck_encode(sd64, cfg, audio.double())
+    ref64 = m64 + s64 * noise.double()
+    floor = rel(ref.double(), ref64)
+    assert rel(z.double(), ref64) < max(1e-4, 4 * floor), (rel(z.double(), ref64), floor)
     dec = OobleckDecoder(cfg, sd, DEV, 1, Lz)
     wav = dec(ref.transpose(1, 2)).transpose(1, 2).cpu()
     rw = osa.oobleck_decode(sd, cfg, ref)
-    assert wav.shape == rw.shape == (1, cfg["audio_channels"], Lz * hop) and rel(wav, rw) < 2e-4, rel(wav, rw)
+    rw64 = osa.oobleck_decode(sd64, cfg, ref.double())
+    floor = rel(rw.double(), rw64)
+    assert wav.shape == rw.shape == (1, cfg["audio_channels"], Lz * hop)
+    assert rel(wav.double(), rw64) < max(2e-4, 4 * floor), (rel(wav.double(), rw64), floor)
 
 
 # ------------------------------------------------------------------------------------------------ loops

@@ -1,0 +1,94 @@
+"""BASELINE config 5 on one MI355X: Stable Audio Open 1.0 (DiT 1.06 B + Oobleck 156 M, seeded-random weights of the real
+architecture), one 47.55 s / 44.1 kHz stereo clip, 200-step edit-friendly inversion + edit from tstart=100, fp32 (the
+reference's own precision; the fp8 path BASELINE.json names is not built).  Not the headline bench (that is bench.py =
+config 2): this prints one JSON line of the same shape for the record, with the clip's phases and the DiT forward rate.
+
+    PYTHONPATH=. python tools/bench_stable_audio.py [--steps 1] [--warmup 1] [--group 20] [--T 200] [--tstart 100]"""
+import argparse
+import json
+import sys
+import time
+
+import torch
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--steps", type=int, default=1)
+ap.add_argument("--warmup", type=int, default=1)
+ap.add_argument("--T", type=int, default=200)
+ap.add_argument("--tstart", type=int, default=100)
+ap.add_argument("--group", type=int, default=20)
+ap.add_argument("--schedule", default="batched", choices=["batched", "sequential"])
+ap.add_argument("--model_id", default="stabilityai/stable-audio-open-1.0")
+args = ap.parse_args()
+
+from audioeditingcode_amd import models                     # noqa: E402
+from audioeditingcode_amd.main_run import edit_clip          # noqa: E402
+from audioeditingcode_amd.utils import load_audio            # noqa: E402
+
+dev = torch.device("cuda:0")
+t0 = time.time()
+m = models.load_model(args.model_id, dev, args.T, allow_synthetic=True)
+print(f"weights ({m.weights_source}) ready in {time.time() - t0:.1f} s", file=sys.stderr, flush=True)
+sr = m.get_sr()
+n = m.model.transformer.config.sample_size * m.model.vae.hop_length
+g = torch.Generator().manual_seed(1234)
+tt = torch.arange(n, dtype=torch.float64) / sr
+wave = torch.stack([0.5 * torch.sin(2 * torch.pi * (110.0 + 3.0 * c) * tt * (1 + 0.02 * tt)).float()
+                    + 0.05 * torch.randn(n, generator=g) for c in range(2)]).numpy()
+x0, _, duration = load_audio((wave, sr), None, stft=False, model_sr=sr)
+src, tgt, neg = ["a recording of a piano melody"], ["a recording of an electric guitar melody"], [""]
+phases = {}
+
+
+def clip(seed):
+    torch.manual_seed(seed)
+    return edit_clip(m, x0, src, tgt, neg, [1.0], [7.0], args.T, args.tstart, schedule=args.schedule,
+                     timestep_group=args.group, duration=duration)
+
+
+for i in range(args.warmup):
+    clip(100 + i)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for i in range(args.steps):
+    audio, _, w = clip(200 + i)
+    assert torch.isfinite(w).all() and torch.isfinite(audio).all() and float(w.abs().max()) > 0
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+
+# phases of one more clip (device sync after each), and the DiT forward rate from the loops' own HIP events
+ed = m.editor()
+torch.manual_seed(300)
+t = time.perf_counter(); w0 = m.vae_encode(x0); torch.cuda.synchronize(); phases["oobleck_encode"] = time.perf_counter() - t
+from audioeditingcode_amd.ddm_inversion.inversion_utils import inversion_forward_process, inversion_reverse_process  # noqa: E402
+t = time.perf_counter()
+_, zs, wts, extra = inversion_forward_process(m, w0, etas=1.0, prompts=src, cfg_scales=[1.0], num_inference_steps=args.T,
+                                              numerical_fix=True, schedule=args.schedule, timestep_group=args.group,
+                                              duration=duration)
+torch.cuda.synchronize(); phases["inversion"] = time.perf_counter() - t
+inv_loop_ms = ed.last_loop_ms()
+t = time.perf_counter()
+w_edit, _ = inversion_reverse_process(m, xT=wts, tstart=torch.tensor([args.tstart]), etas=1.0, prompts=tgt, neg_prompts=neg,
+                                      cfg_scales=[7.0], zs=zs[:args.tstart], duration=duration, extra_info=extra)
+torch.cuda.synchronize(); phases["edit"] = time.perf_counter() - t
+edit_loop_ms = ed.last_loop_ms()
+t = time.perf_counter(); aud = m.vae_decode(w_edit); torch.cuda.synchronize(); phases["oobleck_decode"] = time.perf_counter() - t
+fwd_flops = None
+for plan in ed._plans.values():
+    fwd_flops = plan["eng"].tape.flops / plan["eng"].B            # per sample forward
+edit_tf = 2 * fwd_flops * args.tstart / (edit_loop_ms * 1e-3) / 1e12
+inv_tf = 2 * fwd_flops * args.T / (inv_loop_ms * 1e-3) / 1e12
+clip_tflop = fwd_flops * 2 * (args.T + args.tstart) / 1e12
+print(json.dumps(dict(
+    metric="edited-clips/sec (config 5: Stable Audio Open 1.0, 200-step inv+edit, 47.55 s@44.1 kHz stereo)",
+    value=args.steps / dt, unit="clips/s", n_gpus=1, steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * dt / args.steps,
+    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="fp32", data="synthetic",
+    config=dict(workload="BASELINE configs[4]: Stable Audio Open 1.0 DiT (24 layers, 1536 wide, 1025 tokens, 130-token "
+                         "context) + Oobleck VAE, one clip, fp32 (fp8 path not built)", T=args.T, tstart=args.tstart,
+                schedule=args.schedule, timesteps_per_dit_call=args.group),
+    phases_s_one_clip={k: round(v, 4) for k, v in phases.items()},
+    roofline=dict(bound="mfma", unit="TFLOP/s", peak=157.3, kernel="whole DiT forward (tape-counted algorithmic FLOPs)",
+                  edit_loop_ms_per_step=edit_loop_ms / args.tstart, edit_loop_tflops=edit_tf, edit_loop_frac=edit_tf / 157.3,
+                  inversion_loop_ms=inv_loop_ms, inversion_tflops=inv_tf, inversion_frac=inv_tf / 157.3,
+                  clip_dit_tflop=clip_tflop, path_tflops=clip_tflop / (dt / args.steps),
+                  path_frac=clip_tflop / (dt / args.steps) / 157.3))))

@@ -57,16 +57,17 @@ class Conditioning:
 
 
 def _pad_ctx(parts, L, attr_e, attr_m):
-    """Stack per-group context tensors of different lengths into [R, L, d] + additive bias [R, L]."""
+    """Stack per-group context tensors of different lengths into [R, L, d] + additive bias [R, L], on the device the
+    conditioning already lives on (no host round trip)."""
     es, bs = [], []
     for c in parts:
-        e = getattr(c, attr_e)
+        e = getattr(c, attr_e).float()
         m = getattr(c, attr_m)
         r, l, d = e.shape
-        ep = torch.zeros(r, L, d, dtype=torch.float32)
-        ep[:, :l] = e.float().cpu()
-        b = torch.full((r, L), PAD_BIAS, dtype=torch.float32)
-        b[:, :l] = 0.0 if m is None else (1 - m.float().cpu()) * MASK_BIAS
+        ep = torch.zeros(r, L, d, dtype=torch.float32, device=e.device)
+        ep[:, :l] = e
+        b = torch.full((r, L), PAD_BIAS, dtype=torch.float32, device=e.device)
+        b[:, :l] = 0.0 if m is None else (1 - m.float().to(e.device)) * MASK_BIAS
         es.append(ep)
         bs.append(b)
     return torch.cat(es, 0), torch.cat(bs, 0)
@@ -121,9 +122,9 @@ class EditEngine:
     def _set_cond(self, eng, groups):
         """groups: list of Conditioning, concatenated along the batch in order."""
         if self.kind == "audioldm":
-            eng.set_conditioning(class_labels=torch.cat([g.class_labels.float().cpu() for g in groups], 0))
+            eng.set_conditioning(class_labels=torch.cat([g.class_labels.float() for g in groups], 0))
         elif self.kind == "audioldm2":
-            e0 = torch.cat([g.ehs0.float().cpu() for g in groups], 0)
+            e0 = torch.cat([g.ehs0.float() for g in groups], 0)
             e1, b1 = _pad_ctx(groups, eng.L1, "ehs1", "mask1")
             eng.set_conditioning(ehs0=e0, ehs1=e1, bias1=b1)
         else:

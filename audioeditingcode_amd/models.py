@@ -10,6 +10,7 @@ Tensors cross this boundary exactly as in the reference: NCHW fp32 torch tensors
 import ctypes
 import os
 import sys
+import weakref
 import zlib
 from types import SimpleNamespace
 from typing import Dict, List, Optional, Tuple, Union
@@ -28,6 +29,37 @@ from .unet import PackedUNetWeights, UNetEngine
 
 class UNet2DConditionOutput(SimpleNamespace):
     """Stand-in for diffusers' output dataclass: callers only read `.sample`."""
+
+
+class _LazySkips(dict):
+    """`{up_block_index: [skip tensors, NCHW]}` of unet_forward's third return value (models.py:854-866).  The engine keeps
+    skips channels-last; the NCHW copies are made the first time a block's list is read, so calls that never look at the
+    skip connections (every step of the plain loops) do not pay for 12 transposes."""
+
+    def __init__(self, groups):
+        super().__init__({i: None for i in groups})
+        self._groups = groups
+
+    def __getitem__(self, i):
+        v = super().__getitem__(i)
+        if v is None:
+            v = [b.permute(0, 3, 1, 2).contiguous() for b in self._groups[i]]
+            super().__setitem__(i, v)
+        return v
+
+    def get(self, i, default=None):
+        return self[i] if i in self._groups else default
+
+    def values(self):
+        return [self[i] for i in self._groups]
+
+    def materialize(self):
+        """Copy every block's skips now (called before the engine's buffers are overwritten by its next forward)."""
+        for i in self._groups:
+            self[i]
+
+    def items(self):
+        return [(i, self[i]) for i in self._groups]
 
 
 class _FnSTFT:
@@ -311,11 +343,13 @@ class PipelineWrapper(torch.nn.Module):
         eng = self._cached(("unet", B, H, W, L0, L1),
                            lambda: UNetEngine(self.family["unet"], self.unet_weights, self.device, B, H, W,
                                               ctx_len0=L0, ctx_len1=L1, use_ehs=self.kind != "audioldm"))
+        pending = getattr(eng, "_pending_skips", None)
+        pending = pending() if pending is not None else None
+        if pending is not None:            # a previous call's result is still held by the caller: its views go stale now
+            pending.materialize()
         eng.set_conditioning(**{k: v for k, v in cond.items() if v is not None})
         eng.x_in.copy_(sample.to(self.device, torch.float32).permute(0, 2, 3, 1))
         eng.set_timestep(int(timestep))
-        hooks = (replace_h_space is not None or mid_block_additional_residual is not None
-                 or replace_skip_conns is not None or zero_out_resconns is not None)
         eng.forward(first_half_only=True)
         if replace_h_space is None:
             h_space = eng.h_space.permute(0, 3, 1, 2).contiguous()
@@ -325,7 +359,7 @@ class PipelineWrapper(torch.nn.Module):
         if mid_block_additional_residual is not None:
             eng.h_space.add_(mid_block_additional_residual.to(self.device).permute(0, 2, 3, 1))
         nres = self.family["unet"].get("layers_per_block", 2) + 1
-        extracted, sk = {}, list(eng.skips)
+        groups, sk = {}, list(eng.skips)
         for i in range(len(self.family["unet"]["up_block_types"])):
             grp, sk = sk[-nres:], sk[:-nres]
             if replace_skip_conns is not None and replace_skip_conns.get(i):
@@ -336,7 +370,9 @@ class PipelineWrapper(torch.nn.Module):
                         (type(zero_out_resconns) is list and i in zero_out_resconns):
                     for buf in grp:
                         buf.zero_()
-            extracted[i] = [b.permute(0, 3, 1, 2).contiguous() for b in grp]
+            groups[i] = grp
+        extracted = _LazySkips(groups)
+        eng._pending_skips = weakref.ref(extracted)
         eng.forward(second_half_only=True)
         out = eng.eps.permute(0, 3, 1, 2).contiguous()
         if not return_dict:

@@ -60,8 +60,9 @@ def _pad_ctx(parts, L, attr_e, attr_m):
     """Stack per-group context tensors of different lengths into [R, L, d] + additive bias [R, L], on the device the
     conditioning already lives on (no host round trip)."""
     es, bs = [], []
+    dev0 = getattr(parts[0], attr_e).device
     for c in parts:
-        e = getattr(c, attr_e).float()
+        e = getattr(c, attr_e).float().to(dev0)
         m = getattr(c, attr_m)
         r, l, d = e.shape
         ep = torch.zeros(r, L, d, dtype=torch.float32, device=e.device)
@@ -122,9 +123,11 @@ class EditEngine:
     def _set_cond(self, eng, groups):
         """groups: list of Conditioning, concatenated along the batch in order."""
         if self.kind == "audioldm":
-            eng.set_conditioning(class_labels=torch.cat([g.class_labels.float() for g in groups], 0))
+            d0 = groups[0].class_labels.device
+            eng.set_conditioning(class_labels=torch.cat([g.class_labels.float().to(d0) for g in groups], 0))
         elif self.kind == "audioldm2":
-            e0 = torch.cat([g.ehs0.float() for g in groups], 0)
+            d0 = groups[0].ehs0.device
+            e0 = torch.cat([g.ehs0.float().to(d0) for g in groups], 0)
             e1, b1 = _pad_ctx(groups, eng.L1, "ehs1", "mask1")
             eng.set_conditioning(ehs0=e0, ehs1=e1, bias1=b1)
         else:

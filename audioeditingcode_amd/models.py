@@ -522,6 +522,7 @@ class StableAudWrapper(PipelineWrapper):
             self.family["dit"], dit_sd = comp["transformer"]
             self.family["oobleck"], vae_sd = comp["vae"]
             self.family["projection"], proj_sd = comp["projection_model"]
+            self.family["ctx"]["t5_dim"] = self.family["projection"].get("text_encoder_dim", self.family["ctx"]["t5_dim"])
             if "scheduler" in comp:
                 self.family["scheduler"] = comp["scheduler"]
             self.weights_source = ckpt

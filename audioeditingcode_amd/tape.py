@@ -34,6 +34,11 @@ try:
 except ImportError:                                              # pragma: no cover
     TILE_TABLE = {}
 TILE_TABLE = dict(TILE_TABLE)
+try:                                   # the Stable Audio DiT's shapes, swept separately (tools/tile_sweep.py ... dit)
+    from .tile_table_dit import TILE_TABLE as _DIT_TABLE
+    TILE_TABLE.update(_DIT_TABLE)
+except ImportError:
+    pass
 for _ent in filter(None, os.environ.get("AED_TILE_OVERRIDE", "").split(";")):
     _k, _v = _ent.split(":", 1)
     _v = [int(t) for t in _v.split(":")]

@@ -6,6 +6,8 @@ written), WEIGHTS COLD (every launch reads its weight matrix from a different sl
 served from the 256 MB Infinity Cache -- a forward streams 1.39 GB of weights, i.e. they are always cold in the loop).
 
     PYTHONPATH=. python tools/tile_sweep.py <B> [R]      -> gpurun_out/tile_sweep_B<B>.json + a table on stdout
+    PYTHONPATH=. python tools/tile_sweep.py <B> [R] dit  -> the contractions of the Stable Audio DiT forward instead
+                                                            (gpurun_out/tile_sweep_dit_B<B>.json)
 
 The winners are pasted into audioeditingcode_amd/tile_table.py (tools/tile_table_from_sweep.py does it)."""
 import collections
@@ -25,17 +27,29 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 R = int(sys.argv[2]) if len(sys.argv) > 2 else (120 if B <= 4 else 16)
 POOL_BYTES = 768 << 20
 dev = "cuda:0"
-fam = configs.FAMILIES["audioldm2"]
-sd = weights.random_state_dict(weights.unet_param_shapes(fam["unet"]), seed=0)
-eng = UNetEngine(fam["unet"], sd, dev, B, 256, 16, ctx_len0=8, ctx_len1=16)
-g = torch.Generator().manual_seed(1)
-eng.set_conditioning(ehs0=torch.randn(B, 8, 768, generator=g), ehs1=torch.randn(B, 16, 1024, generator=g),
-                     bias1=torch.zeros(B, 16))
-eng.x_in.copy_(torch.randn(B, 256, 16, 8, generator=g))
-eng.set_timestep(500)
+DIT = len(sys.argv) > 3 and sys.argv[3] == "dit"
+if DIT:
+    from audioeditingcode_amd.stable_audio import DiTEngine
+    dcfg = dict(configs.FAMILIES["stable_audio"]["dit"], num_layers=1)      # every layer has the same contractions
+    sd = weights.random_state_dict(weights.dit_param_shapes(dcfg), seed=0)
+    eng = DiTEngine(dcfg, sd, dev, B, 130)
+    g = torch.Generator().manual_seed(1)
+    eng.set_conditioning(torch.randn(B, 130, dcfg["cross_attention_input_dim"], generator=g),
+                         torch.randn(B, dcfg["global_states_input_dim"], generator=g))
+    eng.set_timestep(0.4)
+    eng.x_in.copy_(torch.randn(B, dcfg["sample_size"], dcfg["in_channels"], generator=g))
+else:
+    fam = configs.FAMILIES["audioldm2"]
+    sd = weights.random_state_dict(weights.unet_param_shapes(fam["unet"]), seed=0)
+    eng = UNetEngine(fam["unet"], sd, dev, B, 256, 16, ctx_len0=8, ctx_len1=16)
+    g = torch.Generator().manual_seed(1)
+    eng.set_conditioning(ehs0=torch.randn(B, 8, 768, generator=g), ehs1=torch.randn(B, 16, 1024, generator=g),
+                         bias1=torch.zeros(B, 16))
+    eng.x_in.copy_(torch.randn(B, 256, 16, 8, generator=g))
+    eng.set_timestep(500)
 st = torch.cuda.Stream()
 pool = torch.empty(POOL_BYTES // 4, device=dev, dtype=torch.float32).normal_(0, 0.02)
-ws = torch.empty(64 << 20, device=dev, dtype=torch.float32)          # split-K workspace for legacy configs
+ws = torch.empty((512 if DIT else 64) << 20, device=dev, dtype=torch.float32)          # split-K workspace for legacy configs
 
 with torch.cuda.stream(st):
     eng.forward()           # every activation buffer holds realistic values
@@ -138,4 +152,4 @@ for key, (op, count, name, flops) in reps.items():
           + " ".join(f"{k}={v:.1f}" for k, v in sorted(res.items(), key=lambda kv: kv[1])[:6]), flush=True)
 print(f"B={B}: conv_gemm per forward with the current rule {tot_auto / 1e3:.3f} ms, with per-shape best {tot_best / 1e3:.3f} ms")
 os.makedirs("gpurun_out", exist_ok=True)
-json.dump(rows, open(f"gpurun_out/tile_sweep_B{B}.json", "w"), indent=1)
+json.dump(rows, open(f"gpurun_out/tile_sweep_{'dit_' if DIT else ''}B{B}.json", "w"), indent=1)

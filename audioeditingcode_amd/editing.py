@@ -74,21 +74,11 @@ def _pad_ctx(parts, L, attr_e, attr_m):
     return torch.cat(es, 0), torch.cat(bs, 0)
 
 
-class EditEngine:
-    def __init__(self, unet_cfg, weights, scheduler, device, H, W, kind):
-        self.cfg, self.sched, self.device = unet_cfg, scheduler, torch.device(device)
-        self.H, self.W, self.C = H, W, unet_cfg["in_channels"]
-        self.kind = kind
-        self.weights = weights if isinstance(weights, PackedUNetWeights) else PackedUNetWeights(weights, device)
-        self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
-        self._unets = {}
-        self.state = torch.zeros(4, dtype=torch.int32, device=self.device)
-        self.ts_dev = torch.zeros(scheduler.config.num_train_timesteps, dtype=torch.int64, device=self.device)
-        self._plans = {}        # loop plans: persistent buffers + tapes + captured graph, keyed by loop shape
-        self.max_plans = 8      # least-recently-used plans beyond this are dropped (cfg / tstart sweeps would otherwise
-        #                         grow HBM without bound: every plan owns trajectory buffers and an instantiated hipGraph)
+class LoopPlumbing:
+    """What the device-resident loop engines share (this module's EditEngine, stable_audio.StableAudioEditEngine): an LRU
+    of loop plans (persistent buffers + tapes + one instantiated hipGraph per loop shape) and the graph runner.
+    Subclasses provide `self.device`, `self.stream`, `self._plans`, `self.max_plans`."""
 
-    # ------------------------------------------------------------------ helpers
     def _drop_plan(self, key):
         old = self._plans.pop(key)
         g = old.get("graph")
@@ -112,6 +102,57 @@ class EditEngine:
         for key in list(self._plans):
             self._drop_plan(key)
 
+    def _run_graph(self, body, steps, use_graph=True, plan=None):
+        """Run `body()` `steps` times on the engine stream.  The step sequence is captured into a hipGraph
+        once per plan (same buffers => same graph for every later clip) and replayed."""
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev1 = torch.cuda.Event(enable_timing=True)
+            if use_graph and steps > 1:
+                g = plan.get("graph") if plan is not None else None
+                if g is None:
+                    g = Tape.graph_capture(body)
+                    if plan is not None:
+                        plan["graph"] = g
+                ev0.record(self.stream)
+                for _ in range(steps):
+                    Tape.graph_replay(g)
+                ev1.record(self.stream)
+                self._last_events = (ev0, ev1)
+                if plan is None:
+                    self.stream.synchronize()
+                    L.check(L.lib().aed_graph_destroy(g), "aed_graph_destroy")
+            else:
+                ev0.record(self.stream)
+                for _ in range(steps):
+                    body()
+                ev1.record(self.stream)
+                self._last_events = (ev0, ev1)
+        cur.wait_stream(self.stream)
+
+    def last_loop_ms(self):
+        ev0, ev1 = self._last_events
+        ev1.synchronize()
+        return ev0.elapsed_time(ev1)
+
+
+class EditEngine(LoopPlumbing):
+    def __init__(self, unet_cfg, weights, scheduler, device, H, W, kind):
+        self.cfg, self.sched, self.device = unet_cfg, scheduler, torch.device(device)
+        self.H, self.W, self.C = H, W, unet_cfg["in_channels"]
+        self.kind = kind
+        self.weights = weights if isinstance(weights, PackedUNetWeights) else PackedUNetWeights(weights, device)
+        self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        self._unets = {}
+        self.state = torch.zeros(4, dtype=torch.int32, device=self.device)
+        self.ts_dev = torch.zeros(scheduler.config.num_train_timesteps, dtype=torch.int64, device=self.device)
+        self._plans = {}        # loop plans: persistent buffers + tapes + captured graph, keyed by loop shape
+        self.max_plans = 8      # least-recently-used plans beyond this are dropped (cfg / tstart sweeps would otherwise
+        #                         grow HBM without bound: every plan owns trajectory buffers and an instantiated hipGraph)
+
+    # ------------------------------------------------------------------ helpers
     def unet(self, B, L0=0, L1=0):
         key = (B, L0, L1)
         if key not in self._unets:
@@ -172,41 +213,6 @@ class EditEngine:
         tp.transpose(src, dst, Bt=max(1, math.prod(lead)), R=H * W, C=C)
         tp.run()
         return dst
-
-    def _run_graph(self, body, steps, use_graph=True, plan=None):
-        """Run `body()` `steps` times on the engine stream.  The step sequence is captured into a hipGraph
-        once per plan (same buffers => same graph for every later clip) and replayed."""
-        cur = torch.cuda.current_stream(self.device)
-        self.stream.wait_stream(cur)
-        with torch.cuda.stream(self.stream):
-            ev0 = torch.cuda.Event(enable_timing=True)
-            ev1 = torch.cuda.Event(enable_timing=True)
-            if use_graph and steps > 1:
-                g = plan.get("graph") if plan is not None else None
-                if g is None:
-                    g = Tape.graph_capture(body)
-                    if plan is not None:
-                        plan["graph"] = g
-                ev0.record(self.stream)
-                for _ in range(steps):
-                    Tape.graph_replay(g)
-                ev1.record(self.stream)
-                self._last_events = (ev0, ev1)
-                if plan is None:
-                    self.stream.synchronize()
-                    L.check(L.lib().aed_graph_destroy(g), "aed_graph_destroy")
-            else:
-                ev0.record(self.stream)
-                for _ in range(steps):
-                    body()
-                ev1.record(self.stream)
-                self._last_events = (ev0, ev1)
-        cur.wait_stream(self.stream)
-
-    def last_loop_ms(self):
-        ev0, ev1 = self._last_events
-        ev1.synchronize()
-        return ev0.elapsed_time(ev1)
 
     # ------------------------------------------------------------------ A6: sample_xts_from_x0
     @torch.inference_mode()

@@ -88,22 +88,7 @@ class PipelineWrapper(torch.nn.Module):
                  token: Optional[str] = None, seed: int = 0, state_dicts: Optional[Dict] = None,
                  allow_synthetic: Optional[bool] = None, *args, **kwargs) -> None:
         super().__init__()
-        # Seeded-random weights and stand-in text embeddings exist for benchmarks and parity tests (no checkpoint can be
-        # downloaded here).  They must never be used silently: a run that edits audio with them exits 0 and writes
-        # noise.  They need an explicit opt-in: allow_synthetic=True, AED_ALLOW_SYNTHETIC=1, or a "tiny/" test model.
-        if allow_synthetic is None:
-            allow_synthetic = os.environ.get("AED_ALLOW_SYNTHETIC") == "1" or model_id.startswith("tiny/")
-        self.synthetic_ok = bool(allow_synthetic)
-        self.text_encoders = None
-        self.conditioning_source = "unset"
-        if double_precision:
-            raise NotImplementedError("double_precision=True: the native path is fp32 (the reference's default)")
-        self.model_id = model_id
-        self.device = torch.device(device)
-        self.double_precision = double_precision
-        self.token = token
-        self._require_device()
-        L.lib()                                                       # fail loudly if libaed.so is missing
+        self._init_common(model_id, device, double_precision, token, allow_synthetic)
         self.family = configs.get_family(model_id)
         self.kind = self.family["ctx"]["kind"]
         ckpt = weights.find_checkpoint(model_id) if state_dicts is None else None
@@ -150,6 +135,25 @@ class PipelineWrapper(torch.nn.Module):
             vae_scale_factor=2 ** (len(vcfg["block_out_channels"]) - 1))
         self._engines = {}
         self._editors = {}
+
+    def _init_common(self, model_id, device, double_precision, token, allow_synthetic) -> None:
+        """Preamble shared by every wrapper: the synthetic opt-in, the fp32-only rule, the HIP-only rule, libaed.so."""
+        # Seeded-random weights and stand-in text embeddings exist for benchmarks and parity tests (no checkpoint can be
+        # downloaded here).  They must never be used silently: a run that edits audio with them exits 0 and writes
+        # noise.  They need an explicit opt-in: allow_synthetic=True, AED_ALLOW_SYNTHETIC=1, or a "tiny/" test model.
+        if allow_synthetic is None:
+            allow_synthetic = os.environ.get("AED_ALLOW_SYNTHETIC") == "1" or model_id.startswith("tiny/")
+        self.synthetic_ok = bool(allow_synthetic)
+        self.text_encoders = None
+        self.conditioning_source = "unset"
+        if double_precision:
+            raise NotImplementedError("double_precision=True: the native path is fp32 (the reference's default)")
+        self.model_id = model_id
+        self.device = torch.device(device)
+        self.double_precision = double_precision
+        self.token = token
+        self._require_device()
+        L.lib()                                                       # fail loudly if libaed.so is missing
 
     def _require_device(self) -> None:
         """The product runs on HIP only.  (The CPU test suite subclasses the wrapper and overrides this hook to execute
@@ -501,16 +505,7 @@ class StableAudWrapper(PipelineWrapper):
                  token: Optional[str] = None, seed: int = 0, state_dicts: Optional[Dict] = None,
                  allow_synthetic: Optional[bool] = None, *args, **kwargs) -> None:
         torch.nn.Module.__init__(self)
-        if allow_synthetic is None:
-            allow_synthetic = os.environ.get("AED_ALLOW_SYNTHETIC") == "1" or model_id.startswith("tiny/")
-        self.synthetic_ok = bool(allow_synthetic)
-        self.text_encoders = None
-        self.conditioning_source = "unset"
-        if double_precision:
-            raise NotImplementedError("double_precision=True: the native path is fp32 (the reference's default)")
-        self.model_id, self.device, self.double_precision, self.token = model_id, torch.device(device), False, token
-        self._require_device()
-        L.lib()
+        self._init_common(model_id, device, double_precision, token, allow_synthetic)
         self.family = configs.get_family(model_id)
         self.kind = "stable_audio"
         ckpt = weights.find_checkpoint(model_id) if state_dicts is None else None

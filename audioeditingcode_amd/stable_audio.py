@@ -23,6 +23,7 @@ import math
 import torch
 
 from . import _lib as L
+from .editing import LoopPlumbing
 from .scheduler import sa_coefficient_table
 from .tape import Tape
 from .unet import geglu_pack_index
@@ -370,7 +371,7 @@ class OobleckDecoder(_OobleckBase):
 
 
 # =============================================================================================== loops
-class StableAudioEditEngine:
+class StableAudioEditEngine(LoopPlumbing):
     """Device-resident inversion / edit loops of the Stable Audio wrapper for ONE clip and ONE prompt per pass (the
     reference's DiT call cannot take more: its global token is batch 1, models.py:1345-1349).
 
@@ -388,59 +389,7 @@ class StableAudioEditEngine:
         self._plans = {}
         self.max_plans = 4
 
-    # ------------------------------------------------------------------ plumbing shared with editing.EditEngine
-    def _drop_plan(self, key):
-        old = self._plans.pop(key)
-        g = old.get("graph")
-        if g is not None:
-            if self.stream is not None:
-                self.stream.synchronize()
-            L.check(L.lib().aed_graph_destroy(g), "aed_graph_destroy")
-
-    def _get_plan(self, key):
-        plan = self._plans.pop(key, None)
-        if plan is not None:
-            self._plans[key] = plan
-            return plan
-        while self._plans and len(self._plans) >= self.max_plans:
-            self._drop_plan(next(iter(self._plans)))
-        return None
-
-    def clear_plans(self):
-        for key in list(self._plans):
-            self._drop_plan(key)
-
-    def _run_graph(self, body, steps, use_graph=True, plan=None):
-        cur = torch.cuda.current_stream(self.device)
-        self.stream.wait_stream(cur)
-        with torch.cuda.stream(self.stream):
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            if use_graph and steps > 1:
-                g = plan.get("graph") if plan is not None else None
-                if g is None:
-                    g = Tape.graph_capture(body)
-                    if plan is not None:
-                        plan["graph"] = g
-                ev0.record(self.stream)
-                for _ in range(steps):
-                    Tape.graph_replay(g)
-                ev1.record(self.stream)
-                if plan is None:
-                    self.stream.synchronize()
-                    L.check(L.lib().aed_graph_destroy(g), "aed_graph_destroy")
-            else:
-                ev0.record(self.stream)
-                for _ in range(steps):
-                    body()
-                ev1.record(self.stream)
-            self._last_events = (ev0, ev1)
-        cur.wait_stream(self.stream)
-
-    def last_loop_ms(self):
-        ev0, ev1 = self._last_events
-        ev1.synchronize()
-        return ev0.elapsed_time(ev1)
-
+    # ------------------------------------------------------------------ layout at the wrapper boundary
     @torch.inference_mode()
     def to_lc(self, x, out=None):
         """[..., C, L] -> contiguous [..., L, C] on the device."""

@@ -131,6 +131,7 @@ def test_default_line_has_the_contract_keys():
     assert r["launches_per_clip"] == 100 * 1 + 10 * 1                       # tstart edit forwards + T/G inversion forwards
     assert r["traffic"] is None or r["traffic"] > 0
     assert "value_reference_order" in out
+    assert out["schedule_deviation_rel_l2"] == 0.0          # the mocked edit returns the same latent for both schedules
 
 
 def test_sequential_schedule_and_multi_clip_mode():

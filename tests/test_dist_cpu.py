@@ -32,12 +32,20 @@ def _worker(rank, world, port, q):
     # the no-host-bounce form (views of the received arenas) must carry the same weights
     got_dev = adist.broadcast_state_dict(sd, shapes, "cpu", src=0, max_bucket=200_000, on_device=True)
     assert adist.state_checksum(got_dev) == ck and all(got_dev[k].shape == got[k].shape for k in got)
+    # the Stable Audio components travel the same way (three state dicts: DiT, Oobleck, projection model)
+    sa = configs.get_family("tiny/stable-audio-open-1.0")
+    sa_shapes = dict(transformer=weights.dit_param_shapes(sa["dit"]), vae=weights.oobleck_param_shapes(sa["oobleck"]),
+                     projection_model=weights.projection_param_shapes(sa["projection"]))
+    sa_sd = {k: weights.random_state_dict(v, seed=7 + i) for i, (k, v) in enumerate(sa_shapes.items())} if r == 0 else None
+    sa_got = {k: adist.broadcast_state_dict(None if sa_sd is None else sa_sd[k], sa_shapes[k], "cpu", max_bucket=300_000,
+                                            on_device=True) for k in sa_shapes}
+    sa_ck = sum(adist.state_checksum(v) for v in sa_got.values())
     mine = adist.shard_clips(7, r, w)
     local = torch.full((len(adist.shard_clips(8, r, w)), 8, 4, 4), float(r))
     gathered = adist.gather_to_rank0(local)
     mx = adist.max_over_ranks(1.0 + r, "cpu")
     adist.barrier()
-    q.put((r, ck, mine, None if gathered is None else [float(g.mean()) for g in gathered], mx, list(got)[:3]))
+    q.put((r, ck, mine, None if gathered is None else [float(g.mean()) for g in gathered], mx, list(got)[:3], sa_ck))
 
 
 def test_broadcast_shard_gather_world2():
@@ -51,8 +59,8 @@ def test_broadcast_shard_gather_world2():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, ck0, m0, g0, mx0, k0), (r1, ck1, m1, g1, mx1, k1) = res
-    assert ck0 == ck1 and k0 == k1                         # identical weights on both ranks after the broadcast
+    (r0, ck0, m0, g0, mx0, k0, sa0), (r1, ck1, m1, g1, mx1, k1, sa1) = res
+    assert ck0 == ck1 and k0 == k1 and sa0 == sa1          # identical weights on both ranks after the broadcast
     assert m0 == [0, 2, 4, 6] and m1 == [1, 3, 5]           # clip i -> rank i mod W; every clip exactly once
     assert g0 == [0.0, 1.0] and g1 is None                  # latents gathered on rank 0 in rank order
     assert mx0 == mx1 == 2.0

@@ -239,7 +239,8 @@ def dit_param_shapes(cfg):
 
 def oobleck_param_shapes(cfg):
     """diffusers AutoencoderOobleck inventory AFTER weight-norm folding (`fold_weight_norm`): plain conv weights,
-    Snake1d alpha/beta [1,C,1]."""
+    Snake1d alpha/beta [1,C,1].  The encoder's last convolution emits the posterior's (mean | scale) pair, i.e.
+    2 * decoder_input_channels channels -- which is `encoder_hidden_size` (128 = 2 * 64) in the released config."""
     sh = {}
     hid, ca = cfg["encoder_hidden_size"], cfg["audio_channels"]
     mult = [1] + list(cfg["channel_multiples"])

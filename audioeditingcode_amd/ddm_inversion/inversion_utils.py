@@ -84,9 +84,9 @@ def inversion_forward_process(model, x0: torch.Tensor, etas: Optional[float] = N
     sched = model.model.scheduler
     if type(etas) in [int, float]:
         etas = [etas] * sched.num_inference_steps
-    eta = float(etas[0]) if etas is not None else 0.0
-    if etas is not None and any(float(e) != eta for e in etas):
-        raise NotImplementedError("per-step eta schedules: the native loop takes one eta")
+    # one eta, or the reference's per-step list (`eta=etas[idx]`, inversion_utils.py:124): the device loop reads a
+    # coefficient row per step either way
+    eta = 0.0 if etas is None else (float(etas[0]) if all(float(e) == float(etas[0]) for e in etas) else list(etas))
     cond_src, cfg_tensor = None, None
     P = len(prompts)
     if has_src:
@@ -177,15 +177,21 @@ def inversion_reverse_process(model, xT: torch.Tensor, tstart: torch.Tensor, fix
     if type(etas) in [int, float]:
         etas = [etas] * sched.num_inference_steps
     assert len(etas) == sched.num_inference_steps
-    # the device-resident loop starts at xT[len(zs)] with one eta; anything else (a start index that differs from the
-    # number of noise maps, per-step eta lists) takes the step-by-step path, which follows the reference literally
-    general = int(tstart.max()) != (zs.shape[0] if zs is not None else int(tstart.max())) or \
-        any(float(e) != float(etas[0]) for e in etas)
+    # the device-resident loop starts at xT[len(zs)]; a start index that differs from the number of noise maps takes the
+    # step-by-step path, which follows the reference literally.  Per-step eta lists run on the device loop (a coefficient
+    # row per step); the list is indexed like the reference's `etas[idx]`, idx = number of the noise map
+    general = int(tstart.max()) != (zs.shape[0] if zs is not None else int(tstart.max()))
+    if zs is not None:
+        used = [float(e) for e in etas[:zs.shape[0]]]
+        # a list that switches the noise term off at SOME steps: the reference skips `+ eta*sigma*z` there (models.py:152),
+        # the fused kernel would multiply a possibly non-finite z by zero -- take the literal path
+        general = general or (any(e == 0 for e in used) and any(e > 0 for e in used))
     if hooks or uneven or general:
         return _reverse_with_hooks(model, xT, tstart, fix_alpha, etas, prompts, neg_prompts, cfg_scales, zs,
                                    cutoff_points, hspace_add, hspace_replace, skipconns_replace, zero_out_resconns,
                                    extract_h_space, extract_skipconns)
-    eta = float(etas[0])
+    Zn = zs.shape[0]
+    eta = float(etas[0]) if all(float(e) == float(etas[0]) for e in etas) else [float(e) for e in etas[:Zn]]
     cond_tgt = conditioning_from_text(model, model.encode_text(prompts))
     cond_neg = conditioning_from_text(model, model.encode_text(neg_prompts, negative=True))
     cfg_tensor = None

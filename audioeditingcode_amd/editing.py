@@ -239,6 +239,18 @@ class EditEngine(LoopPlumbing):
                 "aed_sample_xts_from_x0")
         return xts
 
+    @staticmethod
+    def _etas_in_loop_order(eta, n_rows):
+        """The reference indexes its per-step list as `etas[idx]` with idx DEscending along the loop (idx = T - k - 1 in
+        the inversion, Z - k - 1 in the edit; inversion_utils.py:75,124 and :221-224,302): row k of the coefficient table
+        gets etas[n_rows - 1 - k].  A scalar stays a scalar."""
+        if isinstance(eta, (int, float)):
+            return float(eta)
+        etas = [float(e) for e in eta]
+        if len(etas) < n_rows:
+            raise ValueError(f"{len(etas)} eta values for {n_rows} steps")
+        return [etas[n_rows - 1 - k] for k in range(n_rows)]
+
     # ------------------------------------------------------------------ A7: forward inversion
     @torch.inference_mode()
     def invert(self, x0, cond_src, cond_uncond, cfg_src, eta=1.0, numerical_fix=True, noise=None, generator=None,
@@ -293,7 +305,7 @@ class EditEngine(LoopPlumbing):
         eng, pre, post = plan["eng"], plan["pre"], plan["post"]
         xts = self.to_nhwc(xts, out=plan["xts"])                  # [T+1, n, H, W, C]
         zs = plan["zs"]
-        plan["coef"].copy_(coefficient_table(s, s.timesteps.cpu(), eta=eta, kind="ddpm"))
+        plan["coef"].copy_(coefficient_table(s, s.timesteps.cpu(), eta=self._etas_in_loop_order(eta, T), kind="ddpm"))
         self.ts_dev[:T] = s.timesteps.to(self.device)
         if cfg_tensor is not None:
             self.to_nhwc(cfg_tensor.reshape(P, n, self.C, self.H, self.W), out=plan["cfgt"])
@@ -343,7 +355,9 @@ class EditEngine(LoopPlumbing):
         v_pred = int(s.config.prediction_type == "v_prediction")
         scalar = float(cfg_tar[0]) if cfg_tensor is None else 1.0
         L0, L1 = self._ctx_lens(groups)
-        has_noise = int(eta > 0 and zs is not None)
+        eta_rows = self._etas_in_loop_order(eta, Z)
+        any_noise = (eta_rows > 0) if isinstance(eta_rows, float) else any(e > 0 for e in eta_rows)
+        has_noise = int(any_noise and zs is not None)
         key = ("edit", n, P, T, Z, L0, L1, v_pred, cfg_tensor is not None, scalar, has_noise, table_kind)
         plan = self._get_plan(key)
         if plan is None:
@@ -369,7 +383,7 @@ class EditEngine(LoopPlumbing):
         cur.copy_(xts[Z])                                          # inversion_utils.py:203
         if has_noise:
             plan["zs"].copy_(zs[:Z])
-        plan["coef"].copy_(coefficient_table(s, ts, eta=eta, kind=table_kind))
+        plan["coef"].copy_(coefficient_table(s, ts, eta=eta_rows, kind=table_kind))
         self.ts_dev[:T] = s.timesteps.to(self.device)
         if cfg_tensor is not None:
             self.to_nhwc(cfg_tensor.reshape(P, n, self.C, self.H, self.W), out=plan["cfgt"])

@@ -163,8 +163,15 @@ def ddim_prev_coefficients(sched, t):
 
 
 def coefficient_table(sched, timesteps, eta=1.0, kind="ddpm"):
-    fn = {"ddpm": lambda t: step_coefficients(sched, t, eta), "ddim_next": lambda t: ddim_next_coefficients(sched, t),
-          "ddim_prev": lambda t: ddim_prev_coefficients(sched, t)}[kind]
+    """One coefficient row per loop step.  `eta`: a scalar, or one value PER ROW (the caller has already put the
+    reference's `etas[idx]` list into loop order, see editing.EditEngine._etas_in_loop_order)."""
+    n = len(timesteps)
+    etas = [float(e) for e in eta] if isinstance(eta, (list, tuple)) or torch.is_tensor(eta) else [float(eta)] * n
+    if len(etas) != n:
+        raise ValueError(f"{len(etas)} eta values for {n} steps")
+    if kind == "ddpm":
+        return torch.stack([step_coefficients(sched, int(t), e) for t, e in zip(timesteps, etas)]).contiguous()
+    fn = {"ddim_next": lambda t: ddim_next_coefficients(sched, t), "ddim_prev": lambda t: ddim_prev_coefficients(sched, t)}[kind]
     return torch.stack([fn(int(t)) for t in timesteps]).contiguous()
 
 

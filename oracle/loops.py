@@ -172,7 +172,8 @@ def invert(w, x0, cond_src, cond_uncond, cfg_scales, num_inference_steps, eta=1.
             eps = cfg_combine(eps_u, eps_c, cfg)
         else:
             eps = eps_u
-        z, xtm1 = w.get_zs_from_xts(xt, xts[idx][None], eps, t, eta=eta, numerical_fix=numerical_fix)
+        eta_i = eta[idx] if isinstance(eta, (list, tuple)) else eta          # `eta=etas[idx]`, inversion_utils.py:124
+        z, xtm1 = w.get_zs_from_xts(xt, xts[idx][None], eps, t, eta=eta_i, numerical_fix=numerical_fix)
         zs[idx] = z
         xts[idx] = xtm1
     zs[0] = torch.zeros_like(zs[0])
@@ -194,7 +195,8 @@ def edit(w, xT, tstart, cond_tgt, cond_neg, cfg_scales, zs, eta=1.0, n_prompts=1
         eps_u = w.unet(xt, t, cond_neg)
         eps_c = w.unet(xt.expand(n_prompts, -1, -1, -1), t, cond_tgt)
         eps = cfg_combine(eps_u, eps_c, cfg)
-        xt = w.reverse_step_with_custom_noise(eps, t, xt, variance_noise=zs[idx].unsqueeze(0), eta=eta)
+        eta_i = eta[idx] if isinstance(eta, (list, tuple)) else eta          # inversion_utils.py:302
+        xt = w.reverse_step_with_custom_noise(eps, t, xt, variance_noise=zs[idx].unsqueeze(0), eta=eta_i)
         apply_fix = (tstart.max() - tstart) > it
         if apply_fix.any():
             af = (apply_fix * fix_alpha)[:, None, None, None]

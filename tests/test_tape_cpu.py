@@ -152,6 +152,31 @@ def test_device_resident_loops_match_oracle_on_cpu(cpu_loops, kind):
     assert rel(w_n, w_o) < 1e-3, rel(w_n, w_o)
 
 
+def test_per_step_eta_lists_on_the_device_loops_on_cpu(cpu_loops):
+    """`etas` as a per-step list (the reference indexes it as etas[idx], inversion_utils.py:124 / :302): one coefficient row
+    per step on the device loops, in both schedules, against the oracle loops with the same list."""
+    T, tstart = 8, 5
+    etas = [1.0, 0.8, 0.6, 1.0, 0.9, 0.7, 1.0, 0.5]
+    eng, ow, conds, to_c, x0 = _loop_setup("audioldm2", T)
+    xts0 = ow.sample_xts_from_x0(x0, T, generator=torch.Generator().manual_seed(3))
+    _, zs_o, xts_o = oloops.invert(ow, x0, conds["src"], conds["unc"], [3.0], T, eta=etas, xts=xts0.clone())
+    w_o = oloops.edit(ow, xts_o, torch.tensor([tstart]), conds["tgt"], conds["unc"], [12.0], zs_o[:tstart], eta=etas)
+    for mode in ("sequential", "batched"):
+        zs, xts = eng.invert(x0, to_c(conds["src"]), to_c(conds["unc"]), [3.0], eta=etas, xts=xts0.unsqueeze(1), mode=mode,
+                             group=4)
+        w = eng.edit(xts, zs, tstart, to_c(conds["tgt"]), to_c(conds["unc"]), [12.0], eta=etas[:tstart])
+        assert rel(eng.to_nchw(xts)[1:, 0], xts_o[1:]) < 1e-5
+        assert rel(eng.to_nchw(zs)[1:, 0], zs_o[1:]) < 2e-3
+        assert rel(eng.to_nchw(w), w_o) < 2e-3
+    # a uniform list equals the scalar; a wrong length is refused
+    za, _ = eng.invert(x0, to_c(conds["src"]), to_c(conds["unc"]), [3.0], eta=[1.0] * T, xts=xts0.unsqueeze(1))
+    za = za.clone()
+    zb, _ = eng.invert(x0, to_c(conds["src"]), to_c(conds["unc"]), [3.0], eta=1.0, xts=xts0.unsqueeze(1))
+    assert torch.equal(za, zb)
+    with pytest.raises(ValueError):
+        eng.invert(x0, to_c(conds["src"]), to_c(conds["unc"]), [3.0], eta=[1.0] * (T - 1), xts=xts0.unsqueeze(1))
+
+
 def test_timestep_batched_inversion_logic_on_cpu(cpu_loops):
     """The headline schedule: G timesteps per U-Net call (row/timestep index tables, per-group step ops, counter
     stride) gives the sequential result up to the 1-ulp numerical-fix coupling."""

@@ -171,6 +171,30 @@ def test_other_families_invert_and_edit_on_cpu(cpu_stack, cls, model_id):
     assert rel(wts[1:], xts_o[1:]) < 1e-5 and rel(w, w_o) < 2e-3, (rel(wts[1:], xts_o[1:]), rel(w, w_o))
 
 
+def test_per_step_eta_lists_through_the_reference_signatures_on_cpu(cpu_stack):
+    """`etas` given as a list to inversion_forward_process / inversion_reverse_process (inversion_utils.py:59-60, :124,
+    :210-214, :302): device loops with a coefficient row per step; a list that turns the noise off at SOME edit steps
+    takes the literal step-by-step path (the reference skips the noise term there)."""
+    from audioeditingcode_amd.ddm_inversion import inversion_forward_process, inversion_reverse_process
+    T, tstart = 4, 3
+    m = _model_of(_CpuTango, "tiny/tango", T)
+    ow = _oracle_wrapper_for(m, T)
+    w0 = torch.randn(1, 8, 16, 16, generator=torch.Generator().manual_seed(2)) * 0.7
+    etas = [1.0, 0.7, 0.9, 0.6]
+    torch.manual_seed(6)
+    _, zs, wts, _ = inversion_forward_process(m, w0, etas=list(etas), prompts=["rain"], cfg_scales=[3.0],
+                                              num_inference_steps=T, numerical_fix=True)
+    xts0 = ow.sample_xts_from_x0(w0, T, generator=torch.Generator().manual_seed(6))
+    _, zs_o, xts_o = oloops.invert(ow, w0, m.encode_text(["rain"]), m.encode_text([""]), [3.0], T, eta=etas, xts=xts0)
+    assert rel(wts[1:], xts_o[1:]) < 1e-5 and rel(zs[1:], zs_o[1:]) < 2e-3
+    for ed_etas in (etas, [1.0, 0.0, 0.9, 0.6]):                    # second list: no noise at idx 1 -> literal path
+        w, _ = inversion_reverse_process(m, xT=wts, tstart=torch.tensor([tstart]), etas=list(ed_etas), prompts=["jazz"],
+                                         neg_prompts=[""], cfg_scales=[9.0], zs=zs[:tstart])
+        w_o = oloops.edit(ow, xts_o, torch.tensor([tstart]), m.encode_text(["jazz"]), m.encode_text([""]), [9.0],
+                          zs_o[:tstart], eta=ed_etas)
+        assert torch.isfinite(w).all() and rel(w, w_o) < 3e-3, rel(w, w_o)
+
+
 def test_ddim_mode_and_sdedit_on_cpu(cpu_stack):
     from audioeditingcode_amd.sdedit import sdedit
     T = 5

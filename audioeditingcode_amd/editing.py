@@ -244,7 +244,7 @@ class EditEngine(LoopPlumbing):
         """The reference indexes its per-step list as `etas[idx]` with idx DEscending along the loop (idx = T - k - 1 in
         the inversion, Z - k - 1 in the edit; inversion_utils.py:75,124 and :221-224,302): row k of the coefficient table
         gets etas[n_rows - 1 - k].  A scalar stays a scalar."""
-        if isinstance(eta, (int, float)):
+        if not isinstance(eta, (list, tuple)) and not (torch.is_tensor(eta) and eta.dim() > 0):
             return float(eta)
         etas = [float(e) for e in eta]
         if len(etas) < n_rows:

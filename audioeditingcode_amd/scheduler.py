@@ -166,7 +166,8 @@ def coefficient_table(sched, timesteps, eta=1.0, kind="ddpm"):
     """One coefficient row per loop step.  `eta`: a scalar, or one value PER ROW (the caller has already put the
     reference's `etas[idx]` list into loop order, see editing.EditEngine._etas_in_loop_order)."""
     n = len(timesteps)
-    etas = [float(e) for e in eta] if isinstance(eta, (list, tuple)) or torch.is_tensor(eta) else [float(eta)] * n
+    is_seq = isinstance(eta, (list, tuple)) or (torch.is_tensor(eta) and eta.dim() > 0)
+    etas = [float(e) for e in eta] if is_seq else [float(eta)] * n
     if len(etas) != n:
         raise ValueError(f"{len(etas)} eta values for {n} steps")
     if kind == "ddpm":

@@ -6,7 +6,6 @@ Reference call sites (relative to /root/reference/code):
   models.py:495-503, :581-589               vae_encode / vae_decode
   models.py:505-509, :591-597               decode_to_mel -> SpeechT5HifiGan
 """
-import math
 
 import numpy as np
 import torch

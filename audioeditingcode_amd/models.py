@@ -13,7 +13,7 @@ import sys
 import weakref
 import zlib
 from types import SimpleNamespace
-from typing import Dict, List, Optional, Tuple, Union
+from typing import Dict, List, Optional, Tuple
 
 import torch
 
@@ -23,7 +23,6 @@ from .codec import STFTEngine, VAEDecoder, VAEEncoder, VocoderEngine
 from .editing import Conditioning, EditEngine
 from .scheduler import (CosineDPMSolverMultistepScheduler, DDIMScheduler, sa_step_coefficients, sa_step_orders,
                         step_coefficients)
-from .tape import Tape
 from .unet import PackedUNetWeights, UNetEngine
 
 

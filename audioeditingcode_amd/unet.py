@@ -14,7 +14,6 @@ Hooks of the reference forward (h-space tap/replace/add models.py:840-847, skip 
 Everything here is host-side graph construction; arithmetic happens in libaed.so.
 Activations are channels-last; the NCHW<->NHWC change happens only at the wrapper boundary.
 """
-import math
 import os
 
 import torch

@@ -2,7 +2,6 @@
 set_reproducability :98-116, get_text_embeddings :217-231) and audioldm/audio/tools.py
 (normalize_wav :46-49, pad_wav :34-44, read_wav_file :52-64, _pad_spec :18-31, wav_to_fbank :67-85)."""
 import math
-import os
 import random
 import wave
 from typing import List, NamedTuple, Optional, Tuple

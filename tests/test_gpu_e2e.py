@@ -2,7 +2,6 @@
 edit -> mel -> waveform, HIP path vs the CPU oracle with identical seeded weights and CPU-drawn noise."""
 import os
 
-import numpy as np
 import pytest
 import torch
 

@@ -8,13 +8,11 @@ import torch
 
 from audioeditingcode_amd import _lib as L
 from audioeditingcode_amd import models, pc_drift
-from audioeditingcode_amd.editing import EditEngine
 from audioeditingcode_amd.main_run import edit_clip
 from audioeditingcode_amd.tape import Tape
 from audioeditingcode_amd.utils import get_text_embeddings, load_audio, synthetic_clip
 from oracle import loops as oloops
 from oracle import pc as opc
-from oracle import tape_interp
 from oracle import unet as ounet
 from oracle import vae as ovae
 from oracle.scheduler import OracleDDIMScheduler

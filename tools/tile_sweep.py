@@ -11,7 +11,6 @@ served from the 256 MB Infinity Cache -- a forward streams 1.39 GB of weights, i
 
 The winners are pasted into audioeditingcode_amd/tile_table.py (tools/tile_table_from_sweep.py does it)."""
 import collections
-import copy
 import ctypes
 import json
 import os

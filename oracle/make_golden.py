@@ -663,6 +663,32 @@ def gen_stable_audio():
         for name, val in (("xt", xt), ("xtm1", xtm1), ("v", v), ("m1", m1), ("z_in", zin), ("z", z), ("xfix", xfix),
                           ("d", d), ("prev", prev), ("coef", coef)):
             rec[f"step.{name}{k}"] = val.numpy()
+    # --- the raw-waveform branch of the reference's own utils.load_audio (utils.py:77-95): torchaudio's two calls are the
+    #     only stand-ins (load -> an in-memory [channels, n] tensor; resample -> scipy's polyphase resampler, the product's
+    #     fallback, so the resampled case pins the call and everything after it, not the resampler)
+    _stub("matplotlib")
+    _stub("matplotlib.pyplot")
+    ta = sys.modules["torchaudio"]
+    store = {}
+    ta.load = lambda path: store[path]
+
+    def _resample(w, orig_freq, new_freq):
+        from scipy.signal import resample_poly
+        import math as _m
+        g_ = _m.gcd(int(orig_freq), int(new_freq))
+        return torch.from_numpy(np.stack([resample_poly(c, int(new_freq) // g_, int(orig_freq) // g_).astype(np.float32)
+                                          for c in w.numpy()]))
+    ta.functional = SimpleNamespace(resample=_resample)
+    ref_utils = _load_by_path("ref_utils_for_sa", os.path.join(REF, "utils.py"))
+    gw = torch.Generator().manual_seed(21)
+    for tag, ch, n_in, sr_in, sr_model in (("stereo_same_sr", 2, 5000, 44100, 44100), ("mono_resampled", 1, 4000, 16000, 44100)):
+        w_in = torch.randn(ch, n_in, generator=gw) * 0.2 + 0.05
+        store[tag] = (w_in.clone(), sr_in)
+        w_out, sr_out, dur = ref_utils.load_audio(tag, None, stft=False, model_sr=sr_model)
+        rec[f"load.{tag}.in"] = w_in.numpy()
+        rec[f"load.{tag}.out"] = w_out.numpy()
+        rec[f"load.{tag}.meta"] = np.array([sr_in, sr_model, sr_out, dur], dtype=np.float64)
+        print("load_audio", tag, tuple(w_out.shape), sr_out, dur)
     np.savez_compressed(os.path.join(OUT, "sa_wrapper.npz"), **rec)
     print("sa_wrapper.npz keys", len(rec))
 

@@ -142,3 +142,16 @@ def test_oobleck_shapes_and_hop():
     assert mean.shape == (1, 4, 8) and std.shape == mean.shape and float(std.min()) >= 1e-4
     wav = osa.oobleck_decode(sd, cfg, mean)
     assert wav.shape == (1, 2, 64) and torch.isfinite(wav).all()
+
+
+def test_raw_waveform_load_audio_matches_the_reference_branch(gold):
+    """utils.load_audio(stft=False) (the Stable Audio branch, reference utils.py:77-95 run here): mean removal and peak
+    normalisation over ALL channels, x0.5, duration from the resampled length.  (The resampler itself is a stand-in on both
+    sides -- torchaudio is absent -- so the second case pins the call order, not the filter.)"""
+    from audioeditingcode_amd.utils import load_audio
+    for tag in ("stereo_same_sr", "mono_resampled"):
+        w_in = gold[f"load.{tag}.in"]
+        sr_in, sr_model, sr_out, dur = gold[f"load.{tag}.meta"]
+        w, sr, d = load_audio((w_in, int(sr_in)), None, stft=False, model_sr=int(sr_model))
+        assert sr == int(sr_out) and abs(d - dur) < 1e-12 and tuple(w.shape) == gold[f"load.{tag}.out"].shape
+        np.testing.assert_allclose(w.numpy(), gold[f"load.{tag}.out"], atol=1e-6)

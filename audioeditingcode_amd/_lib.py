@@ -54,6 +54,9 @@ def lib():
         L.aed_graph_end.argtypes = [vp, ctypes.POINTER(vp)]
         L.aed_graph_launch.argtypes = [vp, vp]
         L.aed_graph_destroy.argtypes = [vp]
+        L.aed_stream_create_cu_mask.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_uint32), ci, ci]
+        L.aed_stream_destroy.argtypes = [vp]
+        L.aed_cu_census.argtypes = [vp, ci, ci, vp]
         L.aed_event_create.argtypes = [ctypes.POINTER(vp)]
         L.aed_event_record.argtypes = [vp, vp]
         L.aed_event_elapsed_ms.argtypes = [vp, vp, ctypes.POINTER(cf)]
@@ -65,19 +68,20 @@ def lib():
         L.aed_sa_get_zs_from_xts.argtypes = [vp, vp, vp, vp, cf, fp, vp, ci, vp, vp, ctypes.c_int64, vp]
         L.aed_sa_reverse_step_with_custom_noise.argtypes = [vp, vp, vp, cf, fp, vp, vp, vp, ctypes.c_int64, vp]
         for name in ("aed_launch", "aed_tape_run", "aed_tape_profile", "aed_graph_begin", "aed_graph_end",
-                     "aed_graph_launch", "aed_graph_destroy", "aed_event_create", "aed_event_record",
-                     "aed_event_elapsed_ms", "aed_event_destroy", "aed_get_zs_from_xts",
+                     "aed_graph_launch", "aed_graph_destroy", "aed_stream_create_cu_mask", "aed_stream_destroy",
+                     "aed_cu_census", "aed_event_create", "aed_event_record", "aed_event_elapsed_ms", "aed_event_destroy", "aed_get_zs_from_xts",
                      "aed_reverse_step_with_custom_noise", "aed_sample_xts_from_x0", "aed_device_info",
                      "aed_sa_get_zs_from_xts", "aed_sa_reverse_step_with_custom_noise"):
             getattr(L, name).restype = ci
-        if L.aed_version() != 3:
+        if L.aed_version() != 4:
             raise AedError("libaed.so ABI version mismatch")
         _lib = L
     return _lib
 
 
 EXPORTS = ["aed_version", "aed_last_error", "aed_device_info", "aed_launch", "aed_tape_run", "aed_tape_profile",
-           "aed_graph_begin", "aed_graph_end", "aed_graph_launch", "aed_graph_destroy", "aed_event_create",
+           "aed_graph_begin", "aed_graph_end", "aed_graph_launch", "aed_graph_destroy", "aed_stream_create_cu_mask",
+           "aed_stream_destroy", "aed_cu_census", "aed_event_create",
            "aed_event_record", "aed_event_elapsed_ms", "aed_event_destroy", "aed_get_zs_from_xts",
            "aed_reverse_step_with_custom_noise", "aed_sample_xts_from_x0", "aed_sa_get_zs_from_xts",
            "aed_sa_reverse_step_with_custom_noise"]

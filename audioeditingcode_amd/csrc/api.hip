@@ -24,6 +24,17 @@ int aed_num_cus() {
     return g_cus;
 }
 
+// Where did a stream's workgroups run?  Each block idles ~spin clocks (so the grid spreads over every CU the stream may
+// use instead of recycling the first free one) and records its HW_ID and XCC_ID registers.
+__global__ void cu_census_kernel(uint32_t* out, int spin) {
+    long long t0 = __builtin_readcyclecounter();
+    while (__builtin_readcyclecounter() - t0 < spin) __builtin_amdgcn_s_sleep(8);
+    if (threadIdx.x == 0) {
+        out[2 * blockIdx.x] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));       // HW_REG_HW_ID
+        out[2 * blockIdx.x + 1] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));  // HW_REG_XCC_ID
+    }
+}
+
 typedef int (*launcher_t)(const aed_op*, hipStream_t);
 static int launch_nop(const aed_op*, hipStream_t) { return 0; }
 static launcher_t g_table[AED_OP_COUNT] = {
@@ -120,6 +131,33 @@ int aed_graph_launch(void* graph_exec, void* stream) {
 }
 int aed_graph_destroy(void* graph_exec) {
     if (graph_exec) AED_CHECK_HIP(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+    return 0;
+}
+
+int aed_stream_create_cu_mask(void** stream_out, const uint32_t* mask_words, int n_words, int priority) {
+    AED_REQUIRE(stream_out != nullptr, "aed_stream_create_cu_mask: null output");
+    hipStream_t st = nullptr;
+    if (n_words > 0) {
+        AED_REQUIRE(mask_words != nullptr, "aed_stream_create_cu_mask: null mask");
+        uint32_t any = 0;
+        for (int k = 0; k < n_words; ++k) any |= mask_words[k];
+        AED_REQUIRE(any != 0, "aed_stream_create_cu_mask: empty CU mask");
+        AED_CHECK_HIP(hipExtStreamCreateWithCUMask(&st, (uint32_t)n_words, mask_words));
+    } else {
+        AED_CHECK_HIP(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, priority));
+    }
+    *stream_out = (void*)st;
+    return 0;
+}
+int aed_stream_destroy(void* stream) {
+    if (stream) AED_CHECK_HIP(hipStreamDestroy((hipStream_t)stream));
+    return 0;
+}
+
+int aed_cu_census(uint32_t* out_dev, int n_blocks, int spin_clocks, void* stream) {
+    AED_REQUIRE(out_dev != nullptr && n_blocks > 0, "aed_cu_census: bad arguments");
+    hipLaunchKernelGGL(cu_census_kernel, dim3(n_blocks), dim3(64), 0, (hipStream_t)stream, out_dev, spin_clocks);
+    AED_CHECK_HIP(hipGetLastError());
     return 0;
 }
 

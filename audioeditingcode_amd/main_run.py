@@ -105,8 +105,10 @@ def main(argv=None):
     print(f"edited {duration:.1f} s clip in {time.time() - t0:.2f} s (weights: {ldm_stable.weights_source}; "
           f"text conditioning: {ldm_stable.conditioning_source})")
     os.makedirs(args.results_path, exist_ok=True)
-    write_wav(os.path.join(args.results_path, "edited.wav"), audio[0].numpy(), sr=sr)
-    write_wav(os.path.join(args.results_path, "orig.wav"), orig[0].numpy(), sr=sr)
+    # main_run.py:223-224 saves the whole [channels, n] tensor: mono for the mel families, stereo for Stable Audio
+    audio, orig = (a if a.dim() == 2 else a.reshape(-1, a.shape[-1]) for a in (audio, orig))
+    write_wav(os.path.join(args.results_path, "edited.wav"), audio.numpy(), sr=sr)
+    write_wav(os.path.join(args.results_path, "orig.wav"), orig.numpy(), sr=sr)
 
 
 if __name__ == "__main__":

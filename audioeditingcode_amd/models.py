@@ -262,7 +262,8 @@ class PipelineWrapper(torch.nn.Module):
 
         Same generator algorithm, same seed, same draw order as the in-line path (`torch.manual_seed(seed)` followed by
         one `randn` per timestep, models.py:76-81): a fresh CPU `torch.Generator` seeded with `seed` yields the identical
-        stream, and one `randn` of T stacked shapes equals T sequential draws (both pinned by tests).  The ~40 ms of
+        stream, and the worker makes the same T sequential `randn(shape)` calls (one stacked `randn` of T shapes equals them
+        only when the per-step element count is a multiple of 16 -- not relied on).  The ~40 ms of
         single-threaded CPU RNG per 10 s clip then overlap the previous clip's edit loop.  The buffer is consumed by
         the next `sample_xts_from_x0` call with the same shape / T and ONLY if the global CPU generator is in the state
         `torch.manual_seed(seed)` leaves it in (so a caller that seeded differently gets the in-line draws)."""
@@ -272,7 +273,9 @@ class PipelineWrapper(torch.nn.Module):
 
         def work():
             g = torch.Generator().manual_seed(int(seed))
-            n = torch.randn((int(num_inference_steps), *shape), generator=g, dtype=torch.float32)
+            n = torch.empty((int(num_inference_steps), *shape), dtype=torch.float32)
+            for k in range(int(num_inference_steps)):
+                n[k] = torch.randn(shape, generator=g, dtype=torch.float32)
             box["state_after"] = g.get_state()
             box["noise"] = n.pin_memory() if torch.cuda.is_available() else n
         box["thread"] = threading.Thread(target=work, daemon=True)

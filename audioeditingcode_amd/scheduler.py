@@ -245,6 +245,8 @@ class CosineDPMSolverMultistepScheduler:
     def index_for_timestep(self, timestep, schedule_timesteps=None):
         ts = self.timesteps if schedule_timesteps is None else schedule_timesteps
         idx = (ts.cpu() == torch.as_tensor(timestep).cpu()).nonzero()
+        if len(idx) == 0:                # diffusers' fallback: a timestep outside the current schedule maps to the last index
+            return len(ts) - 1
         return idx[1 if len(idx) > 1 else 0].item()
 
     def _init_step_index(self, timestep):

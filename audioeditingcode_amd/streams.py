@@ -1,0 +1,77 @@
+"""HIP streams restricted to a subset of the MI355X's compute units (include/aed.h: aed_stream_create_cu_mask).
+
+Why: one edited clip is two regimes.  The forward inversion (inversion_utils.py:75-133) runs two
+U-Net calls at batch 200 that fill every CU at ~0.63 of the fp32 MFMA peak; the 100-step edit loop (:221-315) is a chain
+of ~600 dependent launches per step at U-Net batch 2 that is latency-bound and leaves most CUs idle.  Two clips in flight
+-- clip i in its edit loop, clip i+1 in its inversion -- use the idle CUs, but only if the two kernel classes do not
+queue behind each other's workgroups: a 128x128-tile inversion workgroup holds its CU for 0.2-1 ms, a batch-2 kernel
+lasts ~10 us.  So each class gets its own hardware queue with a DISJOINT CU mask.
+
+Bit k of the mask is CU k in the driver's enumeration; consecutive bits rotate over the 8 XCDs, so a contiguous range of
+8*m bits is m CUs on every XCD (each XCD keeps serving both partitions from its own L2).
+"""
+import ctypes
+
+import torch
+
+from . import _lib as L
+
+
+def cu_mask_words(bits, total):
+    """32-bit mask words with the given CU bits set, sized for `total` CUs."""
+    bits = sorted(set(int(b) for b in bits))
+    if not bits or bits[0] < 0 or bits[-1] >= total:
+        raise ValueError(f"CU bits {bits[:1]}..{bits[-1:]} outside [0, {total})")
+    words = [0] * ((total + 31) // 32)
+    for k in bits:
+        words[k // 32] |= 1 << (k % 32)
+    return words
+
+
+class PartitionStream:
+    """A hipStream_t owned by libaed.so (masked to the CU bits `cus`, or unmasked with a priority when `cus` is None),
+    exposed as a torch stream so torch allocations, events and `wait_stream` work on it."""
+
+    def __init__(self, device, cus=None, total=None, priority=0):
+        self.device = torch.device(device)
+        lib = L.lib()
+        if total is None:
+            n_cu = ctypes.c_int()
+            with torch.cuda.device(self.device):
+                L.check(lib.aed_device_info(ctypes.byref(n_cu), None, None, 0), "aed_device_info")
+            total = n_cu.value
+        self.total = total
+        self.cus = None if cus is None else sorted(set(int(b) for b in cus))
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            if cus is None:
+                L.check(lib.aed_stream_create_cu_mask(ctypes.byref(handle), None, 0, int(priority)),
+                        "aed_stream_create_cu_mask")
+            else:
+                words = cu_mask_words(self.cus, total)
+                arr = (ctypes.c_uint32 * len(words))(*words)
+                L.check(lib.aed_stream_create_cu_mask(ctypes.byref(handle), arr, len(words), 0),
+                        "aed_stream_create_cu_mask")
+        self.handle = handle
+        self.stream = torch.cuda.ExternalStream(handle.value, device=self.device)
+
+    def census(self, n_blocks=2048, spin_clocks=200000):
+        """Physical CUs this stream's workgroups land on: sorted list of (xcc, se, sh, cu)."""
+        out = torch.zeros(2 * n_blocks, dtype=torch.int32, device=self.device)
+        L.check(L.lib().aed_cu_census(out.data_ptr(), n_blocks, spin_clocks, ctypes.c_void_p(self.stream.cuda_stream)),
+                "aed_cu_census")
+        self.stream.synchronize()
+        v = out.cpu().view(n_blocks, 2).tolist()
+        return sorted({(x & 0xF, (h >> 13) & 0x7, (h >> 12) & 1, (h >> 8) & 0xF) for h, x in v})
+
+    def close(self):
+        if self.handle is not None:
+            self.stream.synchronize()
+            L.check(L.lib().aed_stream_destroy(self.handle), "aed_stream_destroy")
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

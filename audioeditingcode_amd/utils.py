@@ -69,9 +69,17 @@ def read_wav_channels(path) -> Tuple[np.ndarray, int]:
         with wave.open(path, "rb") as f:
             sr, nch, sw, n = f.getframerate(), f.getnchannels(), f.getsampwidth(), f.getnframes()
             raw = f.readframes(n)
-        dt = {2: np.int16, 4: np.int32}[sw]
-        x = np.frombuffer(raw, dtype=dt).reshape(-1, nch).astype(np.float32) / float(np.iinfo(dt).max + 1)
-        return np.ascontiguousarray(x.T), sr
+        if sw == 1:                                     # 8-bit PCM is unsigned, centred on 128
+            x = (np.frombuffer(raw, dtype=np.uint8).astype(np.float32) - 128.0) / 128.0
+        elif sw == 3:                                   # 24-bit little-endian: widen to int32 (sign in the top byte)
+            b = np.frombuffer(raw, dtype=np.uint8).reshape(-1, 3).astype(np.int32)
+            x = ((b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)) << 8 >> 8).astype(np.float32) / float(1 << 23)
+        elif sw in (2, 4):
+            dt = {2: np.int16, 4: np.int32}[sw]
+            x = np.frombuffer(raw, dtype=dt).astype(np.float32) / float(np.iinfo(dt).max + 1)
+        else:
+            raise ValueError(f"{path}: unsupported PCM sample width {sw} bytes (torchaudio is not installed)")
+        return np.ascontiguousarray(x.reshape(-1, nch).T), sr
 
 
 def resample(w, sr, new_sr):
@@ -174,12 +182,18 @@ def get_text_embeddings(target_prompt: List[str], target_neg_prompt: List[str], 
 
 
 def write_wav(path, wav, sr=16000):
+    """16-bit PCM.  wav: [n] (mono) or [channels, n] (the layout `torchaudio.save` takes in main_run.py:223-224; the
+    Stable Audio path hands over [2, n]) -- channels are interleaved frame by frame, none is dropped."""
     x = np.clip(np.asarray(wav, dtype=np.float32), -1, 1)
+    if x.ndim == 1:
+        x = x[None]
+    if x.ndim != 2:
+        raise ValueError(f"write_wav expects [n] or [channels, n], got shape {x.shape}")
     with wave.open(path, "wb") as f:
-        f.setnchannels(1)
+        f.setnchannels(x.shape[0])
         f.setsampwidth(2)
         f.setframerate(sr)
-        f.writeframes((x * 32767.0).astype(np.int16).tobytes())
+        f.writeframes(np.ascontiguousarray((x * 32767.0).astype(np.int16).T).tobytes())
 
 
 def synthetic_clip(seconds=10.0, sr=16000, seed=1234):

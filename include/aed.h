@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define AED_VERSION 3
+#define AED_VERSION 4
 
 /* ----------------------------------------------------------------------------------------
  * op tape
@@ -100,6 +100,18 @@ int aed_graph_begin(void* stream);
 int aed_graph_end(void* stream, void** graph_exec_out);
 int aed_graph_launch(void* graph_exec, void* stream);
 int aed_graph_destroy(void* graph_exec);
+
+/* Streams restricted to a subset of the chip's compute units (two-clip pipeline: the latency-bound edit loop of clip i
+ * and the throughput-bound inversion of clip i+1 run on DISJOINT CU sets, so neither queues behind the other's
+ * workgroups).  mask_words: n_words x 32 bits, bit k = CU k in the driver's enumeration (consecutive bits rotate over the
+ * 8 XCDs, so a contiguous bit range is spread evenly over them).  priority: 0 normal, <0 higher (HIP convention); used
+ * only when n_words == 0 (an unmasked stream).  The caller destroys the stream with aed_stream_destroy. */
+int aed_stream_create_cu_mask(void** stream_out, const uint32_t* mask_words, int n_words, int priority);
+int aed_stream_destroy(void* stream);
+/* Diagnostic: n_blocks one-wave workgroups, each idling ~spin_clocks shader cycles, write their {HW_ID, XCC_ID} hardware
+ * registers to out_dev[2*n_blocks]: which physical CUs (xcc, se, sh, cu) a stream's work lands on (profiles/ evidence
+ * for the CU partition). */
+int aed_cu_census(uint32_t* out_dev, int n_blocks, int spin_clocks, void* stream);
 
 /* HIP-event helpers so hosts without a HIP binding can time a stream region. */
 int aed_event_create(void** ev_out);

@@ -297,3 +297,10 @@ def test_prefetched_noise_equals_inline_draws(cpu_stack):
     assert m._noise_box["seed"] == 31
     torch.manual_seed(31)
     assert torch.equal(m.sample_xts_from_x0(w0, T), ref)
+    # a latent whose per-step element count is not a multiple of 16 (one stacked randn would differ from T draws there)
+    w_odd = torch.randn(1, 8, 3, 5, generator=torch.Generator().manual_seed(3)) * 0.5
+    torch.manual_seed(77)
+    noise_inline = torch.stack([torch.randn(w_odd.shape) for _ in range(T)])
+    m.prefetch_noise(77, w_odd.shape, T)
+    torch.manual_seed(77)
+    assert torch.equal(m._take_prefetched_noise(w_odd.shape, T), noise_inline)

@@ -8,7 +8,7 @@ torchvision, torchaudio, librosa, wandb, soundfile, progressbar); name-only stub
 modules are injected exactly as SURVEY.md 8(c)/Appendix B describes.  What each
 fixture pins is listed in tests/golden/README.md.
 
-Usage:  python oracle/make_golden.py [loops|pc|pc_cli|audio|hifigan|unet|vae|stable_audio|all]
+Usage:  python oracle/make_golden.py [loops|pc|pc_cli|audio|hifigan|unet|vae|stable_audio|text|all]
 """
 import importlib.util
 import os
@@ -693,6 +693,59 @@ def gen_stable_audio():
     print("sa_wrapper.npz keys", len(rec))
 
 
+# --------------------------------------------------------------------------- A15: the wrappers' encode_text
+def gen_text():
+    """Runs the reference's OWN `AudioLDMWrapper.encode_text` (models.py:511-537), `AudioLDM2Wrapper.encode_text`
+    (:599-677) and `TangoWrapper.encode_text` (:455-472) with the stand-in pipeline members of oracle/text_standins.py
+    (real transformers CLAP / T5 / GPT-2 classes, random-init at reduced width; diffusers' projection model /
+    generate_language_model and tango's encode_text restated -- those packages are absent)."""
+    from oracle import text_standins as ts
+    # transformers' lazy imports must resolve BEFORE the name-only stubs go in (accelerate probes `wandb.__spec__`)
+    clap_t, clap, t5, lm, t5_tango = (ts.clap_text_with_projection(), ts.clap_model_v4_api(), ts.t5_encoder(), ts.gpt2(),
+                                      ts.t5_encoder(seed=16))
+    pw = ts.projection_weights()
+    install_stubs()
+    sys.path.insert(0, REF)
+    import models as ref_models
+
+    def bare(cls, model):
+        w = cls.__new__(cls)                        # the constructors download checkpoints: bypass them
+        ref_models.PipelineWrapper.__init__(w, model_id="fake", device=torch.device("cpu"))
+        w.model = model
+        return w
+
+    rec = {}
+    # ---- AudioLDM-1
+    m1 = bare(ref_models.AudioLDMWrapper, SimpleNamespace(tokenizer=ts.ClapWordTokenizer(), text_encoder=clap_t))
+    # ---- AudioLDM2
+    pipe2 = SimpleNamespace(
+        tokenizer=ts.ClapWordTokenizer(), tokenizer_2=ts.T5WordTokenizer(), text_encoder=clap, text_encoder_2=t5,
+        language_model=lm, projection_model=lambda **kw: ts.audioldm2_projection_forward(pw, **kw),
+        generate_language_model=lambda embeds, attention_mask=None, max_new_tokens=None:
+            ts.generate_language_model(lm, embeds, attention_mask, max_new_tokens))
+    m2 = bare(ref_models.AudioLDM2Wrapper, pipe2)
+    # ---- TANGO
+    tok_tango = ts.T5WordTokenizer()
+    m3 = bare(ref_models.TangoWrapper, SimpleNamespace(encode_text=lambda p: ts.tango_encode_text(tok_tango, t5_tango, p)))
+    rec["checksum"] = np.array([ts.param_checksum(x) for x in (clap_t, clap, t5, lm, t5_tango)])
+    for k, prompts in enumerate(ts.PROMPT_SETS):
+        with torch.no_grad():
+            _, cl, _ = m1.encode_text(list(prompts))
+            gen, t5s, mask = m2.encode_text(list(prompts), negative=(prompts == [""]))
+            th, none, tm = m3.encode_text(list(prompts))
+        assert none is None
+        rec[f"audioldm.{k}.class_labels"] = cl.numpy()
+        rec[f"audioldm2.{k}.generated"] = gen.numpy()
+        rec[f"audioldm2.{k}.t5"] = t5s.numpy()
+        rec[f"audioldm2.{k}.mask"] = mask.numpy()
+        rec[f"tango.{k}.states"] = th.numpy()
+        rec[f"tango.{k}.mask"] = tm.numpy()
+        print("text", k, prompts, "clap", tuple(cl.shape), "gen", tuple(gen.shape), "t5", tuple(t5s.shape),
+              "mask", mask.tolist(), "tango", tuple(th.shape), tm.dtype)
+    np.savez_compressed(os.path.join(OUT, "text_encode.npz"), **rec)
+    print("text_encode.npz keys", len(rec))
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     os.makedirs(OUT, exist_ok=True)
@@ -700,8 +753,8 @@ if __name__ == "__main__":
     # each generator runs in a fresh interpreter when "all" (the stubs of one break another)
     if what == "all":
         import subprocess
-        for w in ("loops", "pc", "pc_cli", "audio", "hifigan", "unet", "vae", "stable_audio"):
+        for w in ("loops", "pc", "pc_cli", "audio", "hifigan", "unet", "vae", "stable_audio", "text"):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), w])
     else:
         {"loops": gen_loops, "pc": gen_pc, "pc_cli": gen_pc_cli, "audio": gen_audio, "hifigan": gen_hifigan, "unet": gen_unet, "vae": gen_vae,
-         "stable_audio": gen_stable_audio}[what]()
+         "stable_audio": gen_stable_audio, "text": gen_text}[what]()

@@ -204,3 +204,11 @@ def test_cli_mains_run_end_to_end(tmp_path, capsys):
     main_run_sdedit.main(["--model_id", "tiny/audioldm2", "--init_aud", wav, "--num_diffusion_steps", "6",
                           "--target_prompt", "jazz", "--tstart", "4", "--results_path", out, "-s", "1"])
     assert glob.glob(os.path.join(out, "**", "s1_skip2_*.wav"), recursive=True)
+
+
+def test_text_encoders_on_the_gpu_match_the_reference_encode_text():
+    """A15 on the GPU box: the transformers modules of the conditioning adapter live on cuda:0 and reproduce the triples
+    the reference's own encode_text methods (models.py:455-472, :511-537, :599-677) returned for the same seeded modules
+    (tests/golden/text_encode.npz, generated by oracle/make_golden.py text)."""
+    from test_text_encoders_cpu import check_against_reference_encode_text
+    check_against_reference_encode_text(DEV, 2e-4)

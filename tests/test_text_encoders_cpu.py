@@ -159,3 +159,52 @@ def test_stable_audio_text_and_duration_conditioning():
     big0, big1 = enc.encode_duration(-3.0, 1000.0, "cpu")                     # clamped to [min_value, max_value]
     assert torch.allclose(big0, enc.encode_duration(0.0, 64.0, "cpu")[0]) and torch.allclose(
         big1, enc.encode_duration(0.0, 64.0, "cpu")[1])
+
+
+def _pinned_encoders(device="cpu"):
+    """The product adapter over the SAME seeded stand-in modules the reference's encode_text methods ran on when
+    tests/golden/text_encode.npz was generated (oracle/make_golden.py text)."""
+    import numpy as np
+
+    from oracle import text_standins as ts
+    import os
+    ref = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "text_encode.npz"))
+    clap_t, clap, t5, lm, t5_tango = (ts.clap_text_with_projection(), ts.clap_model(), ts.t5_encoder(), ts.gpt2(),
+                                      ts.t5_encoder(seed=16))
+    got = np.array([ts.param_checksum(x) for x in (clap_t, clap, t5, lm, t5_tango)])
+    if not np.allclose(got, ref["checksum"], rtol=1e-9):
+        pytest.skip("seeded re-initialisation of the stand-in modules differs from the fixture's (other torch / "
+                    "transformers build): regenerate with oracle/make_golden.py text")
+    proj = ProjectionModel(16, 32, 24)
+    proj.load_state_dict(ts.projection_weights())
+    mods = [m.to(device) for m in (clap_t, clap, t5, lm, t5_tango, proj)]
+    clap_t, clap, t5, lm, t5_tango, proj = mods
+    return ref, dict(
+        audioldm=TextEncoders("audioldm", ts.ClapWordTokenizer(), clap_t),
+        audioldm2=TextEncoders("audioldm2", ts.ClapWordTokenizer(), clap, ts.T5WordTokenizer(), t5, lm, proj,
+                               max_new_tokens=8),
+        tango=TextEncoders("tango", ts.T5WordTokenizer(), t5_tango)), ts.PROMPT_SETS
+
+
+def check_against_reference_encode_text(device, atol):
+    ref, enc, prompt_sets = _pinned_encoders(device)
+    for k, prompts in enumerate(prompt_sets):
+        hs, cl, mk = enc["audioldm"].encode_audioldm(list(prompts), device)
+        assert hs is None and mk is None
+        assert torch.allclose(cl.cpu(), torch.from_numpy(ref[f"audioldm.{k}.class_labels"]), atol=atol), (k, "audioldm")
+        gen, t5s, mask = enc["audioldm2"].encode_audioldm2(list(prompts), device, negative=(prompts == [""]))
+        assert torch.allclose(gen.cpu(), torch.from_numpy(ref[f"audioldm2.{k}.generated"]), atol=atol), (k, "generated")
+        assert torch.allclose(t5s.cpu(), torch.from_numpy(ref[f"audioldm2.{k}.t5"]), atol=atol), (k, "t5")
+        assert torch.equal(mask.cpu(), torch.from_numpy(ref[f"audioldm2.{k}.mask"])), (k, "mask")
+        th, none, tm = enc["tango"].encode_tango(list(prompts), device)
+        assert none is None and tm.dtype == torch.bool
+        assert torch.allclose(th.cpu(), torch.from_numpy(ref[f"tango.{k}.states"]), atol=atol), (k, "tango")
+        assert torch.equal(tm.cpu(), torch.from_numpy(ref[f"tango.{k}.mask"])), (k, "tango mask")
+
+
+def test_adapter_matches_the_reference_encode_text_methods():
+    """A15 pinned: `TextEncoders` reproduces what the reference's own AudioLDMWrapper / AudioLDM2Wrapper / TangoWrapper
+    `encode_text` (models.py:511-537, :599-677, :455-472) returned for the same modules and prompts (two prompts of
+    different length, the empty prompt, one prompt): CLAP max-length padding vs T5 longest padding, the CLAP feature as ONE
+    attended state, slot order (generated GPT-2 states, T5 states, T5 mask), F.normalize, boolean TANGO mask."""
+    check_against_reference_encode_text("cpu", 1e-5)

@@ -46,7 +46,14 @@ else:
                          bias1=torch.zeros(B, 16))
     eng.x_in.copy_(torch.randn(B, 256, 16, 8, generator=g))
     eng.set_timestep(500)
-st = torch.cuda.Stream()
+# AED_SWEEP_CUS=n: run the sweep on a stream masked to n CUs (tile choices for one partition of the clip pipeline)
+SWEEP_CUS = int(os.environ.get("AED_SWEEP_CUS", "0"))
+if SWEEP_CUS:
+    from audioeditingcode_amd.streams import PartitionStream
+    _ps = PartitionStream(dev, cus=range(SWEEP_CUS))
+    st = _ps.stream
+else:
+    st = torch.cuda.Stream()
 pool = torch.empty(POOL_BYTES // 4, device=dev, dtype=torch.float32).normal_(0, 0.02)
 ws = torch.empty((512 if DIT else 64) << 20, device=dev, dtype=torch.float32)          # split-K workspace for legacy configs
 
@@ -151,4 +158,4 @@ for key, (op, count, name, flops) in reps.items():
           + " ".join(f"{k}={v:.1f}" for k, v in sorted(res.items(), key=lambda kv: kv[1])[:6]), flush=True)
 print(f"B={B}: conv_gemm per forward with the current rule {tot_auto / 1e3:.3f} ms, with per-shape best {tot_best / 1e3:.3f} ms")
 os.makedirs("gpurun_out", exist_ok=True)
-json.dump(rows, open(f"gpurun_out/tile_sweep_{'dit_' if DIT else ''}B{B}.json", "w"), indent=1)
+json.dump(rows, open(f"gpurun_out/tile_sweep_{'dit_' if DIT else ''}B{B}{f'_cus{SWEEP_CUS}' if SWEEP_CUS else ''}.json", "w"), indent=1)

@@ -84,7 +84,7 @@ class LoopPlumbing:
         g = old.get("graph")
         if g is not None:
             if self.stream is not None:
-                self.stream.synchronize()
+                torch.cuda.synchronize(self.device)       # the graph may be in flight on a pipeline lane, not only on self.stream
             L.check(L.lib().aed_graph_destroy(g), "aed_graph_destroy")
 
     def _get_plan(self, key):
@@ -102,12 +102,18 @@ class LoopPlumbing:
         for key in list(self._plans):
             self._drop_plan(key)
 
+    def loop_stream(self):
+        """The stream the step graphs are replayed on: the engine's own side stream, or -- while a clip pipeline has
+        put the caller on a CU-partition lane (streams.py; `lane_stream` set by pipeline.ClipPipeline) -- that lane."""
+        return getattr(self, "lane_stream", None) or self.stream
+
     def _run_graph(self, body, steps, use_graph=True, plan=None):
-        """Run `body()` `steps` times on the engine stream.  The step sequence is captured into a hipGraph
+        """Run `body()` `steps` times on the loop stream.  The step sequence is captured into a hipGraph
         once per plan (same buffers => same graph for every later clip) and replayed."""
         cur = torch.cuda.current_stream(self.device)
-        self.stream.wait_stream(cur)
-        with torch.cuda.stream(self.stream):
+        stream = self.loop_stream()
+        stream.wait_stream(cur)
+        with torch.cuda.stream(stream):
             ev0 = torch.cuda.Event(enable_timing=True)
             ev1 = torch.cuda.Event(enable_timing=True)
             if use_graph and steps > 1:
@@ -116,21 +122,21 @@ class LoopPlumbing:
                     g = Tape.graph_capture(body)
                     if plan is not None:
                         plan["graph"] = g
-                ev0.record(self.stream)
+                ev0.record(stream)
                 for _ in range(steps):
                     Tape.graph_replay(g)
-                ev1.record(self.stream)
+                ev1.record(stream)
                 self._last_events = (ev0, ev1)
                 if plan is None:
-                    self.stream.synchronize()
+                    stream.synchronize()
                     L.check(L.lib().aed_graph_destroy(g), "aed_graph_destroy")
             else:
-                ev0.record(self.stream)
+                ev0.record(stream)
                 for _ in range(steps):
                     body()
-                ev1.record(self.stream)
+                ev1.record(stream)
                 self._last_events = (ev0, ev1)
-        cur.wait_stream(self.stream)
+        cur.wait_stream(stream)
 
     def last_loop_ms(self):
         ev0, ev1 = self._last_events
@@ -146,13 +152,25 @@ class EditEngine(LoopPlumbing):
         self.weights = weights if isinstance(weights, PackedUNetWeights) else PackedUNetWeights(weights, device)
         self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
         self._unets = {}
+        # step counter of the loops without a cached plan (DDIM baseline).  Every cached loop plan owns its OWN counter
+        # (plan["state"]): the inversion of one clip and the edit loop of another run concurrently in the clip pipeline.
         self.state = torch.zeros(4, dtype=torch.int32, device=self.device)
         self.ts_dev = torch.zeros(scheduler.config.num_train_timesteps, dtype=torch.int64, device=self.device)
+        self._ts_host = None    # what ts_dev holds (uploaded again only when the schedule changes)
         self._plans = {}        # loop plans: persistent buffers + tapes + captured graph, keyed by loop shape
         self.max_plans = 8      # least-recently-used plans beyond this are dropped (cfg / tstart sweeps would otherwise
         #                         grow HBM without bound: every plan owns trajectory buffers and an instantiated hipGraph)
 
     # ------------------------------------------------------------------ helpers
+    def _upload_timesteps(self, ts, n):
+        """ts_dev[:n] = ts -- skipped when the table already holds these values (same schedule as the previous call: no
+        host-to-device copy, and nothing rewrites a table another lane's loop is reading)."""
+        ts = ts.detach().to("cpu", torch.int64).reshape(-1)[:n].clone()
+        if self._ts_host is not None and self._ts_host.numel() >= n and torch.equal(self._ts_host[:n], ts):
+            return
+        self.ts_dev[:n] = ts.to(self.device)
+        self._ts_host = ts
+
     def unet(self, B, L0=0, L1=0):
         key = (B, L0, L1)
         if key not in self._unets:
@@ -279,6 +297,7 @@ class EditEngine(LoopPlumbing):
         plan = self._get_plan(key)
         if plan is None:
             plan = self._plans[key] = dict(
+                state=torch.zeros(4, dtype=torch.int32, device=self.device),
                 xts=torch.empty((T + 1, n, self.H, self.W, self.C), device=self.device, dtype=torch.float32),
                 zs=torch.zeros((T, n, self.H, self.W, self.C), device=self.device, dtype=torch.float32),
                 coef=torch.zeros((T, L.COEF_STRIDE), device=self.device, dtype=torch.float32),
@@ -289,16 +308,16 @@ class EditEngine(LoopPlumbing):
             for g in range(G):
                 for blk in range(1 + P):
                     dst = eng.x_in[(g * (1 + P) + blk) * n:(g * (1 + P) + blk + 1) * n]
-                    pre.copy2d(plan["xts"], dst, rows=1, cols=numel, ld_src=numel, ld_dst=numel, state=self.state,
+                    pre.copy2d(plan["xts"], dst, rows=1, cols=numel, ld_src=numel, ld_dst=numel, state=plan["state"],
                                idx_off=T - g, idx_mul=-G, idx_stride=numel, name="x_in<-xts")
             for g in range(G):
                 base = g * rows_per_t
                 eps_u = eng.eps[base:base + n]
                 eps_c = eng.eps[base + n:base + rows_per_t] if P else None
                 post.step(L.OP_INVERT_STEP, xts=plan["xts"], zs=plan["zs"], eps_u=eps_u, eps_c=eps_c,
-                          cfg=plan["cfgt"], coef=plan["coef"], state=self.state, out=None, numel=numel, P=max(P, 1),
+                          cfg=plan["cfgt"], coef=plan["coef"], state=plan["state"], out=None, numel=numel, P=max(P, 1),
                           T=T, v_pred=v_pred, flag=int(numerical_fix), cfg_scalar=scalar, s_mul=G, s_off=g)
-            post.advance(self.state)
+            post.advance(plan["state"])
             pre.finalize()
             post.finalize()
             plan["pre"], plan["post"] = pre, post
@@ -306,13 +325,13 @@ class EditEngine(LoopPlumbing):
         xts = self.to_nhwc(xts, out=plan["xts"])                  # [T+1, n, H, W, C]
         zs = plan["zs"]
         plan["coef"].copy_(coefficient_table(s, s.timesteps.cpu(), eta=self._etas_in_loop_order(eta, T), kind="ddpm"))
-        self.ts_dev[:T] = s.timesteps.to(self.device)
+        self._upload_timesteps(s.timesteps, T)
         if cfg_tensor is not None:
             self.to_nhwc(cfg_tensor.reshape(P, n, self.C, self.H, self.W), out=plan["cfgt"])
         # batch rows: for g in G: [uncond x n | prompt_p x n ...]
         self._set_cond(eng, [c for _ in range(G) for c in groups])
-        self._patch_time(eng, self.ts_dev, G, rows_per_t)
-        self.state.zero_()
+        self._patch_time(eng, self.ts_dev, G, rows_per_t, state=plan["state"])
+        plan["state"].zero_()
 
         def body():
             pre.run()
@@ -322,8 +341,9 @@ class EditEngine(LoopPlumbing):
         zs[0].zero_()                                              # inversion_utils.py:131-133
         return zs, xts          # persistent buffers of this plan: valid until the next invert() of the same shape
 
-    def _patch_time(self, eng, ts_dev, G, rows_per_t, offset=0):
-        """Point the U-Net's time-embedding op at (table + offset) with G timesteps per call."""
+    def _patch_time(self, eng, ts_dev, G, rows_per_t, offset=0, state=None):
+        """Point the U-Net's time-embedding op at (table + offset) with G timesteps per call, stepped by `state`."""
+        state = self.state if state is None else state
         op = eng.tape.ops[eng.time_op]
         arr = eng.tape.finalize()
         # cached: captured graphs keep pointing at these index tables
@@ -333,7 +353,7 @@ class EditEngine(LoopPlumbing):
         eng._row_tidx = cache[rows_per_t]
         for o in (op, arr[eng.time_op]):
             o.p[1] = ts_dev.data_ptr() + 8 * offset
-            o.p[2] = self.state.data_ptr()
+            o.p[2] = state.data_ptr()
             o.p[4] = eng._row_tidx.data_ptr()
             o.i[5] = G
 
@@ -362,6 +382,7 @@ class EditEngine(LoopPlumbing):
         plan = self._get_plan(key)
         if plan is None:
             plan = self._plans[key] = dict(
+                state=torch.zeros(4, dtype=torch.int32, device=self.device),
                 cur=torch.empty((n, self.H, self.W, self.C), device=self.device, dtype=torch.float32),
                 zs=torch.zeros((Z, n, self.H, self.W, self.C), device=self.device, dtype=torch.float32),
                 coef=torch.zeros((Z, L.COEF_STRIDE), device=self.device, dtype=torch.float32),
@@ -373,9 +394,9 @@ class EditEngine(LoopPlumbing):
                 pre.copy2d(plan["cur"], eng.x_in[blk * n:(blk + 1) * n], rows=1, cols=numel, ld_src=numel,
                            ld_dst=numel, name="x_in<-x_t")
             post.step(L.OP_REVERSE_STEP, xts=plan["cur"], zs=plan["zs"] if has_noise else None, eps_u=eng.eps[:n],
-                      eps_c=eng.eps[n:], cfg=plan["cfgt"], coef=plan["coef"], state=self.state, out=plan["cur"],
+                      eps_c=eng.eps[n:], cfg=plan["cfgt"], coef=plan["coef"], state=plan["state"], out=plan["cur"],
                       numel=numel, P=P, T=Z if has_noise else 0, v_pred=v_pred, flag=has_noise, cfg_scalar=scalar)
-            post.advance(self.state)
+            post.advance(plan["state"])
             pre.finalize()
             post.finalize()
             plan["pre"], plan["post"] = pre, post
@@ -384,12 +405,12 @@ class EditEngine(LoopPlumbing):
         if has_noise:
             plan["zs"].copy_(zs[:Z])
         plan["coef"].copy_(coefficient_table(s, ts, eta=eta_rows, kind=table_kind))
-        self.ts_dev[:T] = s.timesteps.to(self.device)
+        self._upload_timesteps(s.timesteps, T)
         if cfg_tensor is not None:
             self.to_nhwc(cfg_tensor.reshape(P, n, self.C, self.H, self.W), out=plan["cfgt"])
         self._set_cond(eng, groups)
-        self._patch_time(eng, self.ts_dev, 1, n * (1 + P), offset=T - Z)
-        self.state.zero_()
+        self._patch_time(eng, self.ts_dev, 1, n * (1 + P), offset=T - Z, state=plan["state"])
+        plan["state"].zero_()
 
         def body():
             pre.run()
@@ -410,6 +431,7 @@ class EditEngine(LoopPlumbing):
         ts_asc = torch.flip(s.timesteps.cpu(), dims=[0])[:steps]
         coef = coefficient_table(s, ts_asc, kind="ddim_next").to(self.device)
         self.ts_dev[:steps] = ts_asc.to(self.device)
+        self._ts_host = None                            # the table no longer holds the descending schedule
         groups = [cond_uncond.repeat(n), cond_src]
         L0, L1 = self._ctx_lens(groups)
         eng = self.unet(2 * n, L0, L1)

@@ -187,8 +187,22 @@ class PipelineWrapper(torch.nn.Module):
         if (H, W) not in self._editors:
             self._editors[(H, W)] = EditEngine(self.family["unet"], self.unet_weights, self.model.scheduler,
                                                self.device, H, W, self.kind)
-        self._editors[(H, W)].sched = self.model.scheduler
-        return self._editors[(H, W)]
+        ed = self._editors[(H, W)]
+        ed.sched = self.model.scheduler
+        # inside a clip pipeline (pipeline.ClipPipeline) the loops replay on the caller's CU-partition lane
+        ed.lane_stream = self.__dict__.get("_lane_stream")
+        return ed
+
+    def lane_view(self):
+        """A second handle on this model for a concurrent lane (pipeline.ClipPipeline): shares everything frozen --
+        packed U-Net weights, codec state dicts, scheduler tables, text encoders, configuration -- and owns everything
+        mutable: its own engine caches (activations, loop plans, hipGraphs) and noise-prefetch state."""
+        import copy
+        v = copy.copy(self)
+        v._engines, v._editors = {}, {}
+        v._noise_box = None
+        v.next_noise_seed = None
+        return v
 
     # ------------------------------------------------------------------ reference API
     def get_sigma(self, timestep: int) -> float:
@@ -220,7 +234,7 @@ class PipelineWrapper(torch.nn.Module):
     def decode_to_mel(self, x: torch.Tensor) -> torch.Tensor:
         mel = x[:, 0].detach().float()                                  # [B, T, n_mels]
         voc = self._vocoder(mel.shape[0], mel.shape[1])
-        wav = voc(mel).detach().cpu().float()                           # pipeline returns a CPU tensor
+        wav = voc(mel).detach().to("cpu", torch.float32, copy=True)     # a CPU tensor (never a view of the engine buffer)
         if len(wav.shape) == 1:
             wav = wav.unsqueeze(0)
         return wav

@@ -75,7 +75,7 @@ class Tape:
             return t
         return t.data_ptr()
 
-    def _add(self, code, i=(), f=(), p=(), name="", flops=0, nbytes=0, flags=0):
+    def _add(self, code, i=(), f=(), p=(), name="", flops=0, nbytes=0, flags=0, exec_flops=None):
         op = L.aed_op()
         op.code = code
         op.flags = flags
@@ -89,8 +89,10 @@ class Tape:
                 self.keep.append(v)         # the record holds a raw pointer: keep the storage alive
         self.ops.append(op)
         # `flops` is ALGORITHMIC work (what the reference's formulation of the op costs: SURVEY 8d); ops that execute
-        # fewer (the folded cross-attention) pass it explicitly, the executed count is kept beside it
-        self.meta.append(dict(name=name or L.OP_NAMES[code], code=code, flops=flops, bytes=nbytes))
+        # fewer (the folded cross-attention) pass it explicitly; `exec_flops` is what the kernel executes (MFMA
+        # utilisation is priced against THAT, path-level throughput against the algorithmic count)
+        self.meta.append(dict(name=name or L.OP_NAMES[code], code=code, flops=flops, bytes=nbytes,
+                              exec_flops=flops if exec_flops is None else exec_flops))
         self._arr = None
         return len(self.ops) - 1
 
@@ -208,7 +210,7 @@ class Tape:
         n_out = N // 2 if geglu else N
         idx = self._add(L.OP_CONV_GEMM, i, [in_slope, out_p, out_div, ln_eps, sm_scale],
                         [x, w, bias, out, res, rowvec, None, None, x2, kbias], name=name,
-                        flops=2 * M * N * K if alg_flops is None else alg_flops,
+                        flops=2 * M * N * K if alg_flops is None else alg_flops, exec_flops=2 * M * N * K,
                         nbytes=4 * (B * IH * IW * Cin + N * K + M * n_out), flags=2 if LATE_EPILOGUE else 0)
         if ksplit > 1:
             self._ws_need = max(self._ws_need, ksplit * M * N)
@@ -393,6 +395,10 @@ class Tape:
     @property
     def flops(self):
         return sum(m["flops"] for m in self.meta)
+
+    @property
+    def exec_flops(self):
+        return sum(m["exec_flops"] for m in self.meta)
 
     def run(self, start=0, end=None):
         arr = self.finalize()

@@ -18,7 +18,8 @@ from audioeditingcode_amd import main_run, models               # noqa: E402
 
 class _Tape:
     flops = 3.4e11
-    meta = [dict(code=1, flops=1e9, name="x.conv1"), dict(code=22, flops=0, name="gn")]
+    exec_flops = 3.0e11
+    meta = [dict(code=1, flops=1e9, exec_flops=8e8, name="x.conv1"), dict(code=22, flops=0, exec_flops=0, name="gn")]
     ops = [None, None]
 
     def profile(self):
@@ -54,6 +55,7 @@ class _Ed:
         self._unets = {(b, 8, 16): _Eng() for b in batches}
         self._unets[(batches[0], 8, 9)] = _Eng()            # a second engine of the same batch size (other context length)
         self.state = torch.zeros(4, dtype=torch.int32)
+        self._plans = {"p": dict(state=torch.zeros(4, dtype=torch.int32))}
 
     def edit_latents(self, w0, *a, **k):
         return torch.ones(w0.shape[0], 8, 256, 16)
@@ -65,10 +67,14 @@ class _STFT:
 
 
 class _Model:
-    weights_source, state_dicts, kind = "mock", {}, "audioldm2"
+    weights_source, state_dicts, kind, device = "mock", {}, "audioldm2", "cpu"
 
     def __init__(self, batches):
         self._ed = _Ed(batches)
+        self._editors, self._engines = {}, {}
+
+    def lane_view(self):
+        return _Model([2])
 
     def get_fn_STFT(self):
         return _STFT()
@@ -99,7 +105,39 @@ def _stream_ctx(s):
     yield
 
 
-def _run(argv, batches):
+class _Pipe:
+    """pipeline.ClipPipeline stand-in: L lane views / streams, clips handed back in order."""
+    made = []
+
+    def __init__(self, model, lanes=None):
+        self.n_lanes = lanes
+        self.views = [model.lane_view() for _ in range(lanes)]
+        self.streams = [_Stream() for _ in range(lanes)]
+        self.calls = []
+        _Pipe.made.append(self)
+
+    def warm_up(self, item, *a, **k):
+        self.calls.append(("warm_up", 1))
+
+    def edit_clips(self, items, *a, prepare=None, seeds=None, **k):
+        assert len(seeds) == len(items) and prepare is not None
+        self.calls.append(("edit_clips", len(items)))
+        return [(None, None, torch.ones(1, 8, 256, 16)) for _ in items]
+
+    def lane_report(self):
+        return dict(lanes=self.n_lanes, clips=self.calls[-1][1])
+
+
+def _run(argv, batches, extra_patches=()):
+    from audioeditingcode_amd import pipeline
+    with contextlib.ExitStack() as stack:
+        for pt in extra_patches:
+            stack.enter_context(pt)
+        stack.enter_context(mock.patch.object(pipeline, "ClipPipeline", _Pipe))
+        return _run_inner(argv, batches)
+
+
+def _run_inner(argv, batches):
     with mock.patch.object(sys, "argv", ["bench.py", *argv]), mock.patch("torch.cuda.set_device"), \
             mock.patch("torch.cuda.synchronize"), mock.patch("torch.cuda.Stream", _Stream), \
             mock.patch("torch.cuda.stream", _stream_ctx), mock.patch("torch.cuda.Event", _Event), \
@@ -120,23 +158,55 @@ REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
 
 
 def test_default_line_has_the_contract_keys():
-    out = _run(["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--group", "20"], [2, 40])
+    """Default mode: L lanes in the reference order + the two one-clip-at-a-time legs + roofline measured on all lanes."""
+    _Pipe.made.clear()
+    out = _run(["--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-extras", "--group", "20", "--lanes", "3",
+                "--serial-clips", "2"], [2, 40])
     assert all(k in out for k in REQUIRED)
-    assert out["n_gpus"] == 1 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["n_gpus"] == 1 and out["steps"] == 4 and out["warmup"] == 2 and out["scaling"] == "weak"
     assert out["dtype"] == "f32" and out["vs_baseline"] is None and out["higher_is_better"] is True
     assert "workload" in out["config"] and out["config"]["clips_per_gpu_per_step"] == 1
+    assert out["config"]["clips_in_flight_per_gpu"] == 3 and "reference step order" in out["config"]["workload"]
+    assert _Pipe.made[0].calls == [("warm_up", 1), ("edit_clips", 2), ("edit_clips", 4)]      # lanes built, W warm, K timed
     r = out["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
-    assert set(r["by_batch"]) == {"unet_batch_2", "unet_batch_40"}          # one engine per batch size
-    assert r["launches_per_clip"] == 100 * 1 + 10 * 1                       # tstart edit forwards + T/G inversion forwards
+    assert set(r["by_batch"]) == {"unet_batch_2"} and r["by_batch"]["unet_batch_2"]["lanes_measured"] == 3
+    assert r["launches_per_clip"] == 300 * 1                        # T + tstart forwards at batch 2, one GEMM op each
     assert r["traffic"] is None or r["traffic"] > 0
-    assert "value_reference_order" in out
-    assert out["schedule_deviation_rel_l2"] == 0.0          # the mocked edit returns the same latent for both schedules
+    assert r["path_frac_executed"] < r["path_frac"]
+    assert "value_reference_order" in out and "value_single_clip_batched" in out and out["serial_legs_clips"] == 2
+    assert out["schedule_deviation_rel_l2"] == 0.0          # the mocked edit returns the same latent for every schedule
+    assert out["lanes_vs_serial"] == dict(clips_compared=2, bit_identical=True, max_abs_diff=0.0)
 
 
-def test_sequential_schedule_and_multi_clip_mode():
-    out = _run(["--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--schedule", "sequential", "--group", "20"], [2, 40])
-    assert "value_batched_inversion" in out and "reference order" in out["config"]["workload"]
-    out = _run(["--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--clips-per-gpu", "2", "--group", "20"], [4, 40])
+def test_single_lane_schedules_and_multi_clip_mode():
+    out = _run(["--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--lanes", "1", "--schedule",
+                "sequential", "--group", "20"], [2, 40])
+    assert "value_single_clip_batched" in out and "reference order" in out["config"]["workload"]
+    assert out["roofline"]["launches_per_clip"] == 300
+    out = _run(["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--lanes", "1", "--group", "20"],
+               [2, 40])
+    assert set(out["roofline"]["by_batch"]) == {"unet_batch_2", "unet_batch_40"}
+    assert out["roofline"]["launches_per_clip"] == 100 * 1 + 10 * 1         # tstart edit forwards + T/G inversion forwards
+    out = _run(["--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--clips-per-gpu", "2", "--group",
+                "20", "--no-batched"], [4, 40])
     assert out["config"]["clips_per_gpu_per_step"] == 2 and out["config"]["gathered_latents"] == [[2, 8, 256, 16]]
     assert set(out["roofline"]["by_batch"]) == {"unet_batch_4", "unet_batch_40"}
+
+
+def test_extras_are_reported_and_never_fatal():
+    """parity + sub-benchmarks: a sub-process that prints a JSON line is embedded, one that fails is recorded."""
+    import subprocess
+
+    def fake_run(cmd, **kw):
+        if "bench_config4.py" in " ".join(cmd):
+            return subprocess.CompletedProcess(cmd, 3, stdout="", stderr="boom")
+        return subprocess.CompletedProcess(cmd, 0, stdout='noise\n{"metric": "m", "value": 2.5, "unit": "u", "roofline": '
+                                                          '{"frac": 0.5, "by_batch": {}}}\n', stderr="")
+    out = _run(["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--lanes", "2", "--group", "20"], [2, 40],
+               extra_patches=[mock.patch.object(bench, "parity_leg", lambda *a, **k: dict(latent_rel_l2=1e-4)),
+                              mock.patch.object(bench.subprocess, "run", fake_run)])
+    assert out["parity"] == dict(latent_rel_l2=1e-4)
+    assert out["config3_per_rank"]["value"] == 2.5 and out["config3_per_rank"]["roofline"] == {"frac": 0.5}
+    assert out["config4_pc_extract_apply"]["failed"] == "rc=3"
+    assert out["config5_stable_audio_fp32"]["value"] == 2.5

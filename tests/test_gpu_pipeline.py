@@ -1,0 +1,110 @@
+"""GPU tests of the clip pipeline (pipeline.ClipPipeline: L clips in flight, each in the reference's step order on its own
+HIP stream) and of the CU-masked streams of the C ABI (aed_stream_create_cu_mask / aed_cu_census)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from audioeditingcode_amd import models                                   # noqa: E402
+from audioeditingcode_amd.main_run import edit_clip                        # noqa: E402
+from audioeditingcode_amd.pipeline import ClipPipeline                     # noqa: E402
+from audioeditingcode_amd.streams import PartitionStream                   # noqa: E402
+from audioeditingcode_amd.utils import load_audio, synthetic_clip          # noqa: E402
+
+DEV = "cuda:0"
+ARGS = (["a dog barking"], ["a cat meowing"], [""], [3.0], [12.0])
+
+
+def _serial(m, mels, T, tstart, seeds):
+    out = []
+    for x0, s in zip(mels, seeds):
+        torch.manual_seed(s)
+        out.append(edit_clip(m, x0, *ARGS, T, tstart))
+    torch.cuda.synchronize()
+    return out
+
+
+def test_lanes_are_bit_identical_to_one_clip_at_a_time_tiny():
+    """5 clips through 3 lanes == the same clips one at a time (same per-clip seeds): latents and waveforms bit for bit;
+    a second pass without per-clip seeds consumes the global generator in clip order."""
+    T, tstart = 10, 6
+    m = models.load_model("tiny/audioldm2", DEV, T, seed=0)
+    mels = [load_audio((synthetic_clip(seconds=1.25, seed=7 + i), 16000), m.get_fn_STFT(), device=DEV, stft=True)[0]
+            for i in range(5)]
+    seeds = [40 + i for i in range(5)]
+    ref = _serial(m, mels, T, tstart, seeds)
+    pipe = ClipPipeline(m, lanes=3)
+    pipe.warm_up(mels[0], *ARGS, T, tstart)
+    got = pipe.edit_clips(mels, *ARGS, T, tstart, seeds=seeds)
+    for i, ((a, o, w), (a2, o2, w2)) in enumerate(zip(got, ref)):
+        assert torch.equal(w, w2), (i, float((w - w2).abs().max()))
+        assert torch.equal(a, a2) and torch.equal(o, o2), i
+    rep = pipe.lane_report()
+    assert rep["clips"] == 5 and sum(rep["clips_per_lane"]) == 5
+    torch.manual_seed(99)
+    ref2 = [edit_clip(m, x0, *ARGS, T, tstart) for x0 in mels]
+    torch.manual_seed(99)
+    got2 = pipe.edit_clips(mels, *ARGS, T, tstart)
+    for (a, o, w), (a2, o2, w2) in zip(got2, ref2):
+        assert torch.equal(w, w2) and torch.equal(a, a2)
+
+
+def test_lanes_full_size_audioldm2_bit_identical_and_finite():
+    """BASELINE config 2's model (346.9 M-parameter U-Net, latent 8x256x16) at a short schedule: 4 clips on 4 lanes ==
+    one at a time, bit for bit; every lane was used."""
+    T, tstart = 6, 4
+    m = models.load_model("cvssp/audioldm2", DEV, T, allow_synthetic=True)
+    mels = [load_audio((synthetic_clip(seconds=10.0, seed=3 + i), 16000), m.get_fn_STFT(), device=DEV, stft=True)[0]
+            for i in range(4)]
+    seeds = [7, 8, 9, 10]
+    ref = _serial(m, mels, T, tstart, seeds)
+    pipe = ClipPipeline(m, lanes=4)
+    pipe.warm_up(mels[0], *ARGS, T, tstart)
+    got = pipe.edit_clips(mels, *ARGS, T, tstart, seeds=seeds)
+    for i, ((a, o, w), (a2, o2, w2)) in enumerate(zip(got, ref)):
+        assert torch.isfinite(w).all() and torch.isfinite(a).all()
+        assert torch.equal(w, w2), (i, float((w - w2).abs().max()))
+        assert torch.equal(a, a2), i
+    assert pipe.lane_report()["clips_per_lane"] == [1, 1, 1, 1]
+
+
+def test_cu_masked_streams_census_and_results():
+    """aed_stream_create_cu_mask: a contiguous range of 8k mask bits is k CUs on each of the 8 XCDs (aed_cu_census reads
+    the hardware's XCC / SE / CU ids); a hipGraph replayed on a masked stream gives the same values as on a plain one."""
+    from audioeditingcode_amd import configs, weights
+    from audioeditingcode_amd.unet import UNetEngine
+    full = PartitionStream(DEV)
+    total = full.total
+    assert len(full.census()) == total
+    low = PartitionStream(DEV, cus=range(64))
+    cs = low.census()
+    per_xcc = {}
+    for x, se, sh, cu in cs:
+        per_xcc[x] = per_xcc.get(x, 0) + 1
+    assert len(cs) == 64 and sorted(per_xcc) == list(range(8)) and set(per_xcc.values()) == {8}, per_xcc
+    rest = PartitionStream(DEV, cus=range(64, total))
+    assert len(rest.census()) == total - 64 and not set(rest.census()) & set(cs)
+    fam = configs.tiny_family("audioldm2")
+    sd = weights.random_state_dict(weights.unet_param_shapes(fam["unet"]), seed=0)
+    eng = UNetEngine(fam["unet"], sd, DEV, 2, 32, 16, ctx_len0=8, ctx_len1=8)
+    g = torch.Generator().manual_seed(1)
+    eng.set_conditioning(ehs0=torch.randn(2, 8, 48, generator=g), ehs1=torch.randn(2, 8, 64, generator=g),
+                         bias1=torch.zeros(2, 8))
+    eng.x_in.copy_(torch.randn(2, 32, 16, 8, generator=g))
+    eng.set_timestep(500)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        eng.forward()
+        st.synchronize()
+        ref = eng.eps.clone()
+        eng.tape.capture()
+    for ps in (low, rest):
+        eng.eps.zero_()
+        with torch.cuda.stream(ps.stream):
+            eng.tape.replay()
+        ps.stream.synchronize()
+        assert torch.equal(eng.eps, ref)
+    with pytest.raises(ValueError):
+        PartitionStream(DEV, cus=[total])
+    for ps in (full, low, rest):
+        ps.close()

@@ -304,3 +304,59 @@ def test_prefetched_noise_equals_inline_draws(cpu_stack):
     m.prefetch_noise(77, w_odd.shape, T)
     torch.manual_seed(77)
     assert torch.equal(m._take_prefetched_noise(w_odd.shape, T), noise_inline)
+
+
+def test_clip_pipeline_lanes_equal_serial_edit_clip(cpu_stack, monkeypatch):
+    """pipeline.ClipPipeline (L clips in flight, one lane = stream + lane view + host thread) on the CPU stack: every
+    clip's outputs are bit-identical to main_run.edit_clip run clip by clip -- with per-clip seeds and with one continuous
+    global generator stream (the lanes draw in clip order) --, lane views share the frozen weights and own their engines,
+    an error in one clip surfaces, and the batched inversion is refused with more than one lane."""
+    import contextlib
+
+    from audioeditingcode_amd.pipeline import ClipPipeline
+    monkeypatch.setattr(ClipPipeline, "_new_stream", staticmethod(lambda device: None))
+    monkeypatch.setattr(ClipPipeline, "_stream_ctx", staticmethod(lambda st: contextlib.nullcontext()))
+    threads = torch.get_num_threads()
+    torch.set_num_threads(2)                    # lane threads x intra-op threads would oversubscribe the test box
+    try:
+        T, tstart = 3, 2
+        m = _model(T)
+        mels = [load_audio((synthetic_clip(seconds=0.32, seed=7 + i), 16000), m.get_fn_STFT(), device="cpu", stft=True)[0]
+                for i in range(3)]
+        args = (["a dog barking"], ["a cat meowing"], [""], [3.0], [12.0], T, tstart)
+        serial_seeded = []
+        for i, x0 in enumerate(mels):
+            torch.manual_seed(40 + i)
+            serial_seeded.append(edit_clip(m, x0, *args))
+        torch.manual_seed(99)
+        serial_stream = [edit_clip(m, x0, *args) for x0 in mels[:2]]
+        after = torch.randn(2)
+        pipe = ClipPipeline(m, lanes=2)
+        v0, v1 = pipe.views
+        assert v0.unet_weights is m.unet_weights and v0.state_dicts is m.state_dicts and v0.model is m.model
+        assert v0._engines is not m._engines and v0._editors is not v1._editors
+        pipe.warm_up(mels[0], *args)
+        assert all(pipe._warm) and all(len(v._editors) == 1 for v in pipe.views)
+        got = pipe.edit_clips(mels, *args, seeds=[40, 41, 42])
+        for (a, o, w), (a2, o2, w2) in zip(got, serial_seeded):
+            assert torch.equal(a, a2) and torch.equal(o, o2) and torch.equal(w, w2)
+        rep = pipe.lane_report()
+        assert rep["clips"] == 3 and sum(rep["clips_per_lane"]) == 3 and rep["lanes"] == 2
+        torch.manual_seed(99)
+        got = pipe.edit_clips(mels[:2], *args)              # no per-clip seeds: one global stream, consumed in clip order
+        for (a, o, w), (a2, o2, w2) in zip(got, serial_stream):
+            assert torch.equal(a, a2) and torch.equal(w, w2)
+        assert torch.equal(torch.randn(2), after)           # and the generator ends where the serial loop leaves it
+        assert "sample_xts_from_x0" not in v0.__dict__      # the gated draw hook is removed again
+        with pytest.raises(ValueError):
+            pipe.edit_clips(mels, *args, schedule="batched", timestep_group=2)
+        with pytest.raises(RuntimeError, match="clip 0 failed"):
+            pipe.edit_clips([torch.zeros(1, 1, 3, 5), mels[1]], *args)
+        one = ClipPipeline(m, lanes=1)
+        torch.manual_seed(40)
+        a, o, w = one.edit_clips([mels[0]], *args, schedule="batched", timestep_group=3)[0]
+        torch.manual_seed(40)
+        a2, o2, w2 = edit_clip(m, mels[0], *args, schedule="batched", timestep_group=3)
+        assert torch.equal(w, w2) and torch.equal(a, a2)
+    finally:
+        torch.set_num_threads(threads)

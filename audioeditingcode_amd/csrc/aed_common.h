@@ -33,9 +33,7 @@ int launch_gn_stats(const aed_op* op, hipStream_t s);
 int launch_gn_apply(const aed_op* op, hipStream_t s);
 int launch_gn_scale_shift(const aed_op* op, hipStream_t s);
 int launch_gn_small(const aed_op* op, hipStream_t s);
-int launch_layernorm(const aed_op* op, hipStream_t s);
 int launch_attention(const aed_op* op, hipStream_t s);
-int launch_geglu(const aed_op* op, hipStream_t s);
 int launch_copy2d(const aed_op* op, hipStream_t s);
 int launch_time_embed(const aed_op* op, hipStream_t s);
 int launch_softmax_rows(const aed_op* op, hipStream_t s);

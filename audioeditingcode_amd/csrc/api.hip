@@ -37,10 +37,16 @@ __global__ void cu_census_kernel(uint32_t* out, int spin) {
 
 typedef int (*launcher_t)(const aed_op*, hipStream_t);
 static int launch_nop(const aed_op*, hipStream_t) { return 0; }
+// opcodes whose standalone kernel was retired (ABI v4): LayerNorm lives in the consuming GEMM (fused row statistics),
+// the GEGLU / SwiGLU gate in the FF1 epilogue.  The enum slots stay so that older tapes fail loudly instead of shifting.
+static int launch_retired(const aed_op* op, hipStream_t) {
+    aed_set_error("opcode %d was retired in ABI v4 (fused into conv_gemm: ln_mode / geglu slots)", op->code);
+    return 3;
+}
 static launcher_t g_table[AED_OP_COUNT] = {
     launch_nop,           // NOP
     launch_conv_gemm,     // CONV_GEMM
-    launch_gn_stats, launch_gn_apply, launch_layernorm, launch_attention, launch_geglu, launch_copy2d,
+    launch_gn_stats, launch_gn_apply, launch_retired, launch_attention, launch_retired, launch_copy2d,
     launch_time_embed, launch_softmax_rows, launch_transpose, launch_axpby, launch_invert_step,
     launch_reverse_step, launch_ddim_step, launch_advance, launch_reflect_pad, launch_magnitude,
     launch_layout, launch_layout, launch_splitk_reduce, launch_gn_scale_shift, launch_gn_small, launch_xattn_fold,

@@ -180,252 +180,6 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Split-KV variant for self-attention at small batch (N_k > 64).  With U-Net batch 2 the kernel above puts
-// ONE wavefront on each SIMD of the chip and every wave walks all N_k/64 key tiles serially (QK^T MFMAs ->
-// softmax VALU -> PV MFMAs, nothing to overlap with).  Here a block owns 32 query rows and its 4 waves are
-// (query half) x (key half): each wave visits every second key tile, so the dependent chain per wave is
-// half as long and two waves share each SIMD (MFMA of one overlaps softmax of the other).  The two key
-// halves keep independent online-softmax states (m, l, O) and are merged once at the end through LDS:
-//   m = max(m0, m1);  O = O0*exp(m0-m) + O1*exp(m1-m);  l likewise.
-// (Round 1's first implementation of this scheme staged K/V with D/4 dependent load->wait->ds_write trips per round and
-// reduced with ds_bpermute shuffles; measured on the MI355X in round 2 the rewrite below is 22 % faster at U-Net batch 40
-// (673 -> 526 us per 1024-token call) and 10 % at batch 2, so only the rewrite remains.)
-//
-// Implementation notes (what the ISA of the first version showed):
-//   * staging: every global_load there is followed by s_waitcnt vmcnt(0) + one ds_write (predicated loads in
-//     run-time-bounded loops are not batched by the compiler) -> D/4 dependent memory round trips per round.
-//     Here the trip counts are static, addresses are clamped instead of predicated, the K/V tile of round r+1 is
-//     fetched into registers while round r computes, and written to LDS in one batch;
-//   * softmax reductions: __shfl_xor(.., 16) compiles to ds_bpermute_b32 (32 per round, each a ~100-cycle LDS
-//     round trip with its own wait).  The 16 key columns of a score row are exactly one DPP row, so the
-//     reductions are 4 DPP-modified VALU ops each (quad_perm xor 1, xor 2, row_half_mirror, row_mirror); every
-//     lane of the row ends with the bit-identical result (commutative pairings only);
-//   * XCD-aware block order (all query tiles of a head share one L2).
-template <int CTRL>
-__device__ __forceinline__ float dpp_move(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float row16_max(float v) {
-    v = fmaxf(v, dpp_move<0xB1>(v));      // quad_perm [1,0,3,2]  (lane ^ 1)
-    v = fmaxf(v, dpp_move<0x4E>(v));      // quad_perm [2,3,0,1]  (lane ^ 2)
-    v = fmaxf(v, dpp_move<0x141>(v));     // row_half_mirror: the other quad of the 8-lane half
-    v = fmaxf(v, dpp_move<0x140>(v));     // row_mirror: the other half of the 16-lane row
-    return v;
-}
-__device__ __forceinline__ float row16_sum(float v) {
-    v += dpp_move<0xB1>(v);
-    v += dpp_move<0x4E>(v);
-    v += dpp_move<0x141>(v);
-    v += dpp_move<0x140>(v);
-    return v;
-}
-
-template <int D>
-__global__ __launch_bounds__(256) void attention_split_kernel(AttnParams p) {
-    constexpr int KLD = D + 4;
-    constexpr int VLD = KV_TILE + 4;
-    constexpr int NB = D / 16;
-    constexpr int NLD = D / 8;                      // float4 loads per thread and operand per 128-key round
-    constexpr int C4 = D / 4;                       // float4 per key row
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Ks = smem;                               // [2][64][KLD]
-    float* Vt = Ks + 2 * KV_TILE * KLD;             // [2][D][VLD]
-    float* Ps = Vt + 2 * D * VLD;                   // [4][16][VLD]
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int qg = wave & 1, kh = wave >> 1;
-    const int fi = lane & 15, fh = lane >> 4;
-    // XCD-aware order (the dispatcher puts workgroup id w on XCD w % 8, each XCD has a private L2): the query tiles of
-    // one (batch, head) are consecutive ids, i.e. spread over all 8 L2s, and each re-fetches that head's K/V (PMC on
-    // the first kernel: 5.7x the algorithmic bytes).  Bijective remap: XCD x gets a contiguous range of tile ids.
-    int qt, head, b;
-    {
-        const unsigned nx = gridDim.x, ny = gridDim.y, nwg = nx * ny * gridDim.z;
-        const unsigned orig = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
-        const unsigned xcd = orig & 7u, q = nwg >> 3, r = nwg & 7u;
-        const unsigned id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-        qt = (int)(id % nx);
-        head = (int)((id / nx) % ny);
-        b = (int)(id / (nx * ny));
-    }
-    const int q0 = qt * 32 + qg * 16;
-    const int hoff = head * D;
-
-    const float* Q = p.q + (size_t)b * p.bsq + hoff;
-    const float* K = p.k + (size_t)b * p.bsk + hoff;
-    const float* V = p.v + (size_t)b * p.bsv + hoff;
-    const float* bias = p.bias ? p.bias + (size_t)b * p.ld_bias : nullptr;
-
-    float4 qf[NB];
-    {
-        const int qr = q0 + fi;
-#pragma unroll
-        for (int blk = 0; blk < NB; ++blk) {
-            qf[blk] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (qr < p.Nq) qf[blk] = *reinterpret_cast<const float4*>(Q + (size_t)qr * p.ldq + 16 * blk + 4 * fh);
-        }
-    }
-    f32x4 oacc[NB];
-#pragma unroll
-    for (int c = 0; c < NB; ++c) oacc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float m_run[4], l_run[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { m_run[r] = -INFINITY; l_run[r] = 0.f; }
-
-    float* Pw = Ps + wave * 16 * VLD;
-    const float* Kh = Ks + kh * KV_TILE * KLD;
-    const float* Vh = Vt + kh * D * VLD;
-
-    // loader maps (static trip counts).  K: float4 idx = tid + 256*i -> (key, c4); V: key = tid & 127, channels
-    // 4*(tid>>7) + 8*i .. +3 (written transposed)
-    const int vkey = tid & 127, vdg = (tid >> 7) * 4;
-    float4 kreg[NLD], vreg[NLD];
-    auto prefetch = [&](int k00) {                  // unconditional: keys past the end re-read key Nk-1 (masked later)
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int idx = tid + 256 * i;
-            const int key = idx / C4, c4 = idx - key * C4;
-            const int kk = min(k00 + key, p.Nk - 1);
-            kreg[i] = *reinterpret_cast<const float4*>(K + (size_t)kk * p.ldk + 4 * c4);
-        }
-        const int vk = min(k00 + vkey, p.Nk - 1);
-#pragma unroll
-        for (int i = 0; i < NLD; ++i)
-            vreg[i] = *reinterpret_cast<const float4*>(V + (size_t)vk * p.ldv + vdg + 8 * i);
-    };
-    prefetch(0);
-
-    for (int k00 = 0; k00 < p.Nk; k00 += 2 * KV_TILE) {
-        // ---- registers -> LDS: both halves' K (row-major) and V (transposed) tiles, keys k00 .. k00+127
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int idx = tid + 256 * i;
-            const int key = idx / C4, c4 = idx - key * C4;
-            const float4 v = (k00 + key < p.Nk) ? kreg[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4*>(Ks + key * KLD + 4 * c4) = v;         // half = key / 64, contiguous
-        }
-        {
-            const bool ok = k00 + vkey < p.Nk;
-            float* dst = Vt + (vkey >> 6) * D * VLD + (vkey & 63);
-#pragma unroll
-            for (int i = 0; i < NLD; ++i) {
-                const float4 v = ok ? vreg[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-                const int dd = vdg + 8 * i;
-                dst[(dd + 0) * VLD] = v.x;
-                dst[(dd + 1) * VLD] = v.y;
-                dst[(dd + 2) * VLD] = v.z;
-                dst[(dd + 3) * VLD] = v.w;
-            }
-        }
-        __syncthreads();
-        prefetch(k00 + 2 * KV_TILE);                // next round's tiles fly while this round computes
-        const int k0 = k00 + kh * KV_TILE;
-        if (k0 < p.Nk) {            // wave-uniform: this half has keys in this round
-            f32x4 sacc[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) sacc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int blk = 0; blk < NB; ++blk) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float4 kf = *reinterpret_cast<const float4*>(Kh + (16 * j + fi) * KLD + 16 * blk + 4 * fh);
-                    sacc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[blk].x, kf.x, sacc[j], 0, 0, 0);
-                    sacc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[blk].y, kf.y, sacc[j], 0, 0, 0);
-                    sacc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[blk].z, kf.z, sacc[j], 0, 0, 0);
-                    sacc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[blk].w, kf.w, sacc[j], 0, 0, 0);
-                }
-            }
-            float tmax[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) tmax[r] = -INFINITY;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int key = k0 + 16 * j + fi;
-                const bool ok = key < p.Nk;
-                const float bv = (ok && bias) ? bias[key] : 0.f;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float s = ok ? sacc[j][r] * p.scale + bv : -INFINITY;
-                    sacc[j][r] = s;
-                    tmax[r] = fmaxf(tmax[r], s);
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) tmax[r] = row16_max(tmax[r]);
-            float alpha[4], rsum[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float mn = fmaxf(m_run[r], tmax[r]);
-                alpha[r] = __expf(m_run[r] - mn);
-                m_run[r] = mn;
-                rsum[r] = 0.f;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pv = __expf(sacc[j][r] - m_run[r]);
-                    rsum[r] += pv;
-                    Pw[(4 * fh + r) * VLD + 16 * j + fi] = pv;
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) l_run[r] = l_run[r] * alpha[r] + row16_sum(rsum[r]);
-#pragma unroll
-            for (int c = 0; c < NB; ++c)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) oacc[c][r] *= alpha[r];
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) {
-                const float4 pf = *reinterpret_cast<const float4*>(Pw + fi * VLD + 16 * kb + 4 * fh);
-#pragma unroll
-                for (int c = 0; c < NB; ++c) {
-                    const float4 vf = *reinterpret_cast<const float4*>(Vh + (16 * c + fi) * VLD + 16 * kb + 4 * fh);
-                    oacc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(pf.x, vf.x, oacc[c], 0, 0, 0);
-                    oacc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(pf.y, vf.y, oacc[c], 0, 0, 0);
-                    oacc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(pf.z, vf.z, oacc[c], 0, 0, 0);
-                    oacc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(pf.w, vf.w, oacc[c], 0, 0, 0);
-                }
-            }
-        }
-        __syncthreads();
-    }
-
-    // ---- merge the two key halves (same query rows, same lane layout) through LDS
-    constexpr int MSZ = 8 + 4 * NB;                 // floats per lane: m[4], l[4], O[NB][4]
-    float* mrg = smem + (size_t)qg * 64 * MSZ;      // operand tiles are dead after the last barrier
-    if (kh == 1) {
-        float* dst = mrg + lane * MSZ;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { dst[r] = m_run[r]; dst[4 + r] = l_run[r]; }
-#pragma unroll
-        for (int c = 0; c < NB; ++c)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) dst[8 + 4 * c + r] = oacc[c][r];
-    }
-    __syncthreads();
-    if (kh == 0) {
-        const float* src = mrg + lane * MSZ;
-        float* O = p.o + (size_t)b * p.bso + hoff;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int qr = q0 + 4 * fh + r;
-            const float m1 = src[r], l1 = src[4 + r];
-            const float m = fmaxf(m_run[r], m1);
-            const float a0 = __expf(m_run[r] - m), a1 = (m1 == -INFINITY) ? 0.f : __expf(m1 - m);
-            const float inv = 1.0f / (l_run[r] * a0 + l1 * a1);
-            if (qr >= p.Nq) continue;
-#pragma unroll
-            for (int c = 0; c < NB; ++c)
-                O[(size_t)qr * p.ldo + 16 * c + fi] = (oacc[c][r] * a0 + src[8 + 4 * c + r] * a1) * inv;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
 // Transposed-score flash attention on v_mfma_f32_32x32x2_f32 (round 2) for long key sequences (self-attention at
 // 1024 / 256 tokens: 15 % of the batch-40 inversion forward).  Each wavefront owns 32 queries and works alone:
 //   S^T[key, q] = K Q^T   -- A = a 32-key tile of K (from the wave's own LDS slab), B = Q^T held in registers.
@@ -675,24 +429,9 @@ static int launch_t(const AttnParams& p, int B, hipStream_t s) {
     return 0;
 }
 
-template <int D>
-static int launch_split(const AttnParams& p, int B, hipStream_t s) {
-    constexpr int KLD = D + 4, VLD = KV_TILE + 4;
-    const size_t bytes = sizeof(float) * (2 * KV_TILE * KLD + 2 * D * VLD + 4 * 16 * VLD);
-    static bool attr_set = false;
-    if (!attr_set) {
-        AED_CHECK_HIP(hipFuncSetAttribute((const void*)attention_split_kernel<D>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-        attr_set = true;
-    }
-    dim3 grid(aed_cdiv(p.Nq, 32), p.H, B);
-    hipLaunchKernelGGL(attention_split_kernel<D>, grid, dim3(256), bytes, s, p);
-    return 0;
-}
-
 // slots: p0=q p1=k p2=v p3=bias(or null) p4=out
 //        i0=B i1=H i2=Nq i3=Nk i4=D i5=ldq i6=ldk i7=ldv i8=ldo i9=ld_bias
-//        i10=bsq i11=bsk i12=bsv i13=bso (elements) i14=variant (0 auto: transposed-score kernel when Nk > 64; 1 forces single-pass; 2 forces split-KV) ; f0=scale
+//        i10=bsq i11=bsk i12=bsv i13=bso (elements) i14=variant (0 auto: transposed-score kernel when Nk > 64; 1 forces the single-pass kernel) ; f0=scale
 int launch_attention(const aed_op* op, hipStream_t s) {
     const int32_t* i = op->i;
     AttnParams p;
@@ -706,8 +445,8 @@ int launch_attention(const aed_op* op, hipStream_t s) {
     AED_REQUIRE(p.ldq % 4 == 0 && p.ldk % 4 == 0 && p.ldv % 4 == 0, "attention: row strides must be multiples of 4");
     AED_REQUIRE(p.Nq > 0 && p.Nk > 0, "attention: empty sequence");
     AED_REQUIRE(p.ldo % 4 == 0, "attention: output row stride must be a multiple of 4");
-    if (p.Nk > KV_TILE && i[14] != 1 && i[14] != 2) {
-        // transposed-score kernel (i14 = 2 forces the older split-KV kernel for A/B runs).  Few workgroups (U-Net batch 2):
+    if (p.Nk > KV_TILE && i[14] != 1) {
+        // transposed-score kernel.  Few workgroups (U-Net batch 2):
         // the 4 waves of a workgroup split the keys; many: each wave takes its own query tile.
         const long wg_ksplit1 = (long)aed_cdiv(p.Nq, 128) * p.H * i[0];
         const bool ks4 = wg_ksplit1 < 2L * aed_num_cus();
@@ -718,20 +457,6 @@ int launch_attention(const aed_op* op, hipStream_t s) {
             case 64: rc = ks4 ? launch_t<64, 4>(p, i[0], s) : launch_t<64, 1>(p, i[0], s); break;
             case 80: rc = ks4 ? launch_t<80, 4>(p, i[0], s) : launch_t<80, 1>(p, i[0], s); break;
             case 16: rc = ks4 ? launch_t<16, 4>(p, i[0], s) : launch_t<16, 1>(p, i[0], s); break;
-            default: AED_REQUIRE(false, "attention: unsupported head dim %d (16/32/48/64/80)", i[4]);
-        }
-        if (rc) return rc;
-        AED_CHECK_HIP(hipGetLastError());
-        return 0;
-    }
-    if (p.Nk > KV_TILE && i[14] != 1) {        // split-KV variant (i14 = 1 forces the single-pass kernel)
-        int rc = 0;
-        switch (i[4]) {
-            case 16: rc = launch_split<16>(p, i[0], s); break;
-            case 32: rc = launch_split<32>(p, i[0], s); break;
-            case 48: rc = launch_split<48>(p, i[0], s); break;
-            case 64: rc = launch_split<64>(p, i[0], s); break;
-            case 80: rc = launch_split<80>(p, i[0], s); break;
             default: AED_REQUIRE(false, "attention: unsupported head dim %d (16/32/48/64/80)", i[4]);
         }
         if (rc) return rc;

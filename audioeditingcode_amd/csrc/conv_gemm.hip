@@ -449,134 +449,6 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 1) void conv_gemm
 #undef STAMP
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Wave-split-K variant for the SMALL contractions of the edit loop (U-Net batch 2: M*N of a few hundred
-// 32x32 tiles, K of a few hundred).  There the LDS-staged kernel above is latency-bound (measured: ~10 us
-// floor for 3 us of MFMA work).  Here a block owns ONE 32x32 output tile and its 4 wavefronts split K:
-// every wave streams its own K range of the A and W rows straight into MFMA operand registers (lane
-// (i,h) loads 4 consecutive k of row i -- no LDS, no barrier in the main loop, loads of the next
-// k-blocks in flight behind the MFMAs), the four partial tiles meet once in LDS, are summed in a fixed
-// order (deterministic) and every thread finishes 4 outputs with coalesced stores.  4x more blocks than
-// 64x64 tiles and a 4x shorter dependent MFMA chain per wave.
-// Measured and NOT adopted (round 1, s_memtime timelines, batch-2 U-Net forward 11.2 ms with this version):
-// deeper register prefetch (2-4 sets in flight: 11.5-17.7 ms, the lane=row loads are cache-line-request bound),
-// 8 waves per tile (13.8 ms), per-wave LDS staging with coalesced loads (12.1 ms), 4 accumulator chains (no change).
-template <int UNROLL>
-__global__ __launch_bounds__(256) void conv_gemm_wsk_kernel(CGParams p) {
-    __shared__ float part[4][16][64];
-    __shared__ float ln_part[4][32][2];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int fi = lane & 31, fh = lane >> 5;
-    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
-
-    // this wave's range of 8-wide k-blocks
-    const int nkb = p.K >> 3;
-    const int parts = 4 * p.ksplit;
-    const int part_id = blockIdx.z * 4 + wave;
-    const int base = nkb / parts, rem = nkb % parts;
-    const int kb_begin = part_id * base + min(part_id, rem);
-    const int kb_end = kb_begin + base + (part_id < rem ? 1 : 0);
-
-    // A row of this lane
-    const int m = m0 + fi;
-    const bool mvalid = m < p.M;
-    const int mm = mvalid ? m : 0;
-    const int bidx = mm / p.rpb;
-    const int rr = mm - bidx * p.rpb;
-    const int oy = rr / p.OW, ox = rr - oy * p.OW;
-    const int ay0 = oy * p.stride - p.pad_h, ax0 = ox * p.stride - p.pad_w;
-    const unsigned abase = (unsigned)bidx * (unsigned)p.a_bs + 4 * fh;
-    const int vIH = p.vIH, vIW = p.vIW;
-    const int n = n0 + fi;
-    const bool nvalid = n < p.N;
-    const float* wrow = p.W + (size_t)(nvalid ? n : 0) * p.K + 4 * fh;
-
-    // running tap position
-    int k0 = kb_begin * 8;
-    int tap = k0 / p.Cin;
-    int c0 = k0 - tap * p.Cin;
-    int ty = tap / p.KW, tx = tap - ty * p.KW;
-
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    float ln_s1 = 0.f, ln_s2 = 0.f;
-
-    for (int kb = kb_begin; kb < kb_end; kb += UNROLL) {
-        float4 av[UNROLL], wv[UNROLL];
-        bool aok[UNROLL];
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            const bool live = kb + u < kb_end;
-            const int iy = ay0 + ty * p.dil_h, ix = ax0 + tx * p.dil_w;
-            const bool ok = live & mvalid & ((unsigned)iy < (unsigned)vIH) & ((unsigned)ix < (unsigned)vIW);
-            const int cy = ok ? (iy >> p.up) : 0, cx = ok ? (ix >> p.up) : 0;
-            const unsigned off = abase + (unsigned)(cy * p.IW + cx) * (unsigned)p.lda + c0;
-            av[u] = *reinterpret_cast<const float4*>(p.A + (ok ? off : 4u * fh));
-            wv[u] = *reinterpret_cast<const float4*>(wrow + (live ? k0 : 0));
-            aok[u] = ok;
-            if (!(live && nvalid)) wv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            k0 += 8;
-            c0 += 8;
-            if (c0 >= p.Cin) {
-                c0 = 0;
-                if (++tx == p.KW) { tx = 0; ++ty; }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            float4 a = av[u];
-            if (!aok[u]) a = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p.ln_mode) {
-                ln_s1 += (a.x + a.y) + (a.z + a.w);
-                ln_s2 += (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
-            }
-            if (p.in_act) {
-                a.x = in_transform(a.x, p.in_act, p.in_slope);
-                a.y = in_transform(a.y, p.in_act, p.in_slope);
-                a.z = in_transform(a.z, p.in_act, p.in_slope);
-                a.w = in_transform(a.w, p.in_act, p.in_slope);
-            }
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, wv[u].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, wv[u].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, wv[u].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, wv[u].w, acc, 0, 0, 0);
-        }
-    }
-    // partial tiles -> LDS.  acc[r] = C[row (r&3)+8*(r>>2)+4*fh][col fi]
-#pragma unroll
-    for (int r = 0; r < 16; ++r) part[wave][r][lane] = acc[r];
-    if (p.ln_mode) {
-        ln_s1 += __shfl_xor(ln_s1, 32, 64);
-        ln_s2 += __shfl_xor(ln_s2, 32, 64);
-        if (fh == 0) { ln_part[wave][fi][0] = ln_s1; ln_part[wave][fi][1] = ln_s2; }
-    }
-    __syncthreads();
-    // thread t finishes 4 outputs: (row, col) with col = t & 31 (coalesced), row = (t >> 5) + 8*j
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = (tid >> 5) + 8 * j;
-        const int col = tid & 31;
-        // inverse of the accumulator map: row = (r&3) + 8*(r>>2) + 4*h
-        const int h = (row >> 2) & 1;
-        const int r = (row & 3) + 4 * (row >> 3);
-        const int src_lane = col + 32 * h;
-        float v = ((part[0][r][src_lane] + part[1][r][src_lane]) + part[2][r][src_lane]) + part[3][r][src_lane];
-        const int mo = m0 + row, no = n0 + col;
-        if (p.ln_mode && no < p.N) {
-            const float s1 = ((ln_part[0][row][0] + ln_part[1][row][0]) + ln_part[2][row][0]) + ln_part[3][row][0];
-            const float s2 = ((ln_part[0][row][1] + ln_part[1][row][1]) + ln_part[2][row][1]) + ln_part[3][row][1];
-            const float mean = s1 / (float)p.K;
-            const float var = fmaxf(s2 / (float)p.K - mean * mean, 0.f);
-            v = (v - mean * p.rowvec[no]) / sqrtf(var + p.ln_eps);
-        }
-        if (mo < p.M && no < p.N) {
-            if (p.ksplit > 1) p.ws[((size_t)blockIdx.z * p.M + mo) * p.N + no] = v;
-            else store_out(p, mo, no, v);
-        }
-    }
-}
-
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(CGParams p) {
     size_t total = (size_t)p.M * p.N;
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
@@ -695,13 +567,13 @@ int launch_conv_gemm(const aed_op* op, hipStream_t s) {
     // K chunk: 32 (two LDS stages of a 128x128 tile = 72 KB -> two blocks per CU); 64 for the 64x64 tile when the
     // channel count allows (half the barriers, still two blocks per CU)
     const bool bk64 = !generic && (Cin % 64 == 0) && i[30] != 1 && cfg == 4;
-    int rc = cg_fill_params(op, p, cfg == 7 ? 8 : (bk64 ? 64 : 32));
+    int rc = cg_fill_params(op, p, bk64 ? 64 : 32);
     if (rc) return rc;
     const bool plain = p.in_act == 0 && p.ln_mode == 0;
     AED_REQUIRE(p.sm_group == 0 && p.w_bs == 0 && p.vec_bs == 0 && p.vec_ld == 1,
                 "conv_gemm: per-batch weights / grouped softmax exist only in the lin_gemm kernels (tile >= 10)");
     if (p.geglu) AED_REQUIRE(cfg == 1 || cfg == 3, "conv_gemm: the GEGLU epilogue needs 64-wide wave tiles: 128x128 or 64x128 (cfg %d)", cfg);
-    if (p.C1 > 0) AED_REQUIRE(!generic && cfg != 7, "conv_gemm: two-source A needs the vector path of a tiled kernel");
+    if (p.C1 > 0) AED_REQUIRE(!generic, "conv_gemm: two-source A needs the vector path of a tiled kernel");
     switch (cfg) {
         case 1: launch_cfg<128, 128, 2, 2, 2, 32>(p, plain, s); break;
         case 2: launch_cfg<128, 64, 2, 2, 2, 32>(p, plain, s); break;
@@ -719,12 +591,6 @@ int launch_conv_gemm(const aed_op* op, hipStream_t s) {
             if (generic) launch_generic<32, 128, 1, 4>(p, s);
             else launch_cfg<32, 128, 1, 4, 3, 32>(p, plain, s);
             break;
-        case 7: {
-            AED_REQUIRE(!generic && p.Cin % 8 == 0, "conv_gemm: wave-split-K needs the vector path");
-            dim3 grid(aed_cdiv(p.N, 32), aed_cdiv(p.M, 32), p.ksplit);
-            hipLaunchKernelGGL((conv_gemm_wsk_kernel<4>), grid, dim3(256), 0, s, p);
-            break;
-        }
         default: AED_REQUIRE(false, "conv_gemm: bad tile cfg %d", cfg);
     }
     AED_CHECK_HIP(hipGetLastError());

@@ -10,34 +10,6 @@ static inline int grid_for(size_t n, int per_thread = 1) {
     return (int)g;
 }
 
-// ------------------------------------------------------------------------------------ GEGLU
-__global__ __launch_bounds__(256) void geglu_kernel(const float* __restrict__ h, float* __restrict__ out, int M,
-                                                     int Dff, int ldh, int ldo) {
-    const int q = Dff >> 2;
-    const size_t total = (size_t)M * q;
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-        const int m = (int)(e / q);
-        const int c = (int)(e - (size_t)m * q) * 4;
-        const float4 a = *reinterpret_cast<const float4*>(h + (size_t)m * ldh + c);
-        const float4 g = *reinterpret_cast<const float4*>(h + (size_t)m * ldh + Dff + c);
-        float4 o;
-        o.x = a.x * (0.5f * g.x * (1.0f + erff(g.x * 0.70710678118654752440f)));
-        o.y = a.y * (0.5f * g.y * (1.0f + erff(g.y * 0.70710678118654752440f)));
-        o.z = a.z * (0.5f * g.z * (1.0f + erff(g.z * 0.70710678118654752440f)));
-        o.w = a.w * (0.5f * g.w * (1.0f + erff(g.w * 0.70710678118654752440f)));
-        *reinterpret_cast<float4*>(out + (size_t)m * ldo + c) = o;
-    }
-}
-// slots: p0=h[M,2*Dff] p1=out ; i0=M i1=Dff i2=ldh i3=ldo
-int launch_geglu(const aed_op* op, hipStream_t s) {
-    const int32_t* i = op->i;
-    AED_REQUIRE(op->p[0] && op->p[1] && i[1] % 4 == 0 && i[2] % 4 == 0 && i[3] % 4 == 0, "geglu: bad args");
-    hipLaunchKernelGGL(geglu_kernel, dim3(grid_for((size_t)i[0] * i[1] / 4)), dim3(256), 0, s, (const float*)op->p[0],
-                       (float*)op->p[1], i[0], i[1], i[2], i[3]);
-    AED_CHECK_HIP(hipGetLastError());
-    return 0;
-}
-
 // ------------------------------------------------------------------------------------ copy2d
 // Optional device-indexed source: src += (idx_off + idx_mul * state[0]) * idx_stride elements, so a
 // captured graph can walk the xts trajectory (inversion_utils.py:78 `xt = xts[idx+1]`).

@@ -385,34 +385,3 @@ int launch_gn_apply(const aed_op* op, hipStream_t s) {
     return 0;
 }
 
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta, float* __restrict__ y,
-                                                         int M, int C, int ldx, int ldy, float eps) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
-    const float* xr = x + (size_t)row * ldx;
-    float s = 0.f;
-    for (int c = lane; c < C; c += 64) s += xr[c];
-    const float mean = wave_sum(s) / (float)C;
-    float ss = 0.f;
-    for (int c = lane; c < C; c += 64) {
-        const float d = xr[c] - mean;
-        ss += d * d;
-    }
-    const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)C + eps);
-    float* yr = y + (size_t)row * ldy;
-    for (int c = lane; c < C; c += 64) yr[c] = (xr[c] - mean) * rstd * gamma[c] + beta[c];
-}
-
-// slots: p0=x p1=gamma p2=beta p3=y ; i0=M i1=C i2=ldx i3=ldy ; f0=eps
-int launch_layernorm(const aed_op* op, hipStream_t s) {
-    const int32_t* i = op->i;
-    AED_REQUIRE(op->p[0] && op->p[1] && op->p[2] && op->p[3], "layernorm: null pointer");
-    hipLaunchKernelGGL(layernorm_kernel, dim3(aed_cdiv(i[0], 4)), dim3(256), 0, s, (const float*)op->p[0],
-                       (const float*)op->p[1], (const float*)op->p[2], (float*)op->p[3], i[0], i[1], i[2], i[3],
-                       op->f[0]);
-    AED_CHECK_HIP(hipGetLastError());
-    return 0;
-}

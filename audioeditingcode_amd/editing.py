@@ -116,7 +116,7 @@ class LoopPlumbing:
         with torch.cuda.stream(stream):
             ev0 = torch.cuda.Event(enable_timing=True)
             ev1 = torch.cuda.Event(enable_timing=True)
-            if use_graph and steps > 1:
+            if use_graph and steps > 1 and not getattr(self, "eager_steps", False):
                 g = plan.get("graph") if plan is not None else None
                 if g is None:
                     g = Tape.graph_capture(body)

@@ -191,6 +191,7 @@ class PipelineWrapper(torch.nn.Module):
         ed.sched = self.model.scheduler
         # inside a clip pipeline (pipeline.ClipPipeline) the loops replay on the caller's CU-partition lane
         ed.lane_stream = self.__dict__.get("_lane_stream")
+        ed.eager_steps = bool(self.__dict__.get("_lane_eager"))       # lanes issue their steps launch by launch
         return ed
 
     def lane_view(self):

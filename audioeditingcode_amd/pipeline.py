@@ -66,14 +66,24 @@ class _DrawGate:
 
 
 class ClipPipeline:
-    def __init__(self, model, lanes=None):
+    def __init__(self, model, lanes=None, launch="eager"):
         if getattr(model, "kind", None) == "stable_audio":
             raise NotImplementedError("ClipPipeline drives the mel-latent families (AudioLDM / AudioLDM2 / TANGO)")
         self.model = model
         self.n_lanes = DEFAULT_LANES if lanes is None else int(lanes)
         if self.n_lanes < 1:
             raise ValueError("lanes must be >= 1")
+        if launch not in ("eager", "graph"):
+            raise ValueError("launch must be 'eager' or 'graph'")
+        # How a lane issues one diffusion step.  "graph": one hipGraphLaunch per step (what the single-clip loops do).
+        # "eager": the step's ~610 launches are issued one by one from C++ (aed_tape_run, GIL released).  On the device the
+        # two are equivalent (same kernels, same dependent-launch boundary cost); on the host a hipGraphLaunch of a
+        # 600-node graph costs milliseconds and the runtime serialises such launches across threads, which starves
+        # concurrent lanes (measured: profiles/r03_lanes.md) -- eager launches from one thread per lane do not.
+        self.launch = launch
         self.views = [model.lane_view() for _ in range(self.n_lanes)]
+        for v in self.views:
+            v._lane_eager = launch == "eager"
         self.streams = [self._new_stream(model.device) for _ in range(self.n_lanes)]
         self._build_lock = threading.Lock()      # first clip of a lane: engines / plans / lazily folded weights are built
         self._warm = [False] * self.n_lanes
@@ -118,7 +128,7 @@ class ClipPipeline:
                         with guard:
                             item = job["items"][i]
                             with torch.inference_mode():
-                                x0 = job["prepare"](item) if job["prepare"] is not None else item
+                                x0 = job["prepare"](view, item) if job["prepare"] is not None else item
                             job["out"][i] = edit_clip(view, x0, *job["args"], **job["kwargs"])
                             self._warm[k] = True
                     except BaseException as e:                      # noqa: BLE001 -- reported by edit_clips
@@ -145,9 +155,9 @@ class ClipPipeline:
     # ------------------------------------------------------------------ driver
     def edit_clips(self, items, source_prompt, target_prompt, target_neg_prompt, cfg_src, cfg_tar, T, tstart, eta=1.0,
                    schedule="sequential", timestep_group=8, prepare=None, seeds=None, **edit_clip_kwargs):
-        """Edit `items` -- mels [1,1,T_mel,64], or anything `prepare(item)` turns into one (e.g. waveforms through
-        get_fn_STFT, so the STFT runs on the lane too) -- with main_run.edit_clip's arguments; clips are handed to the
-        lanes in order.  seeds[i]: `torch.manual_seed(seeds[i])` right before clip i's noise draws (a serial loop's
+        """Edit `items` -- mels [1,1,T_mel,64], or anything `prepare(lane_view, item)` turns into one (e.g. waveforms
+        through `lane_view.get_fn_STFT()`: the STFT engine then belongs to the lane like every other buffer) -- with
+        main_run.edit_clip's arguments; clips are handed to the lanes in order.  seeds[i]: `torch.manual_seed(seeds[i])` right before clip i's noise draws (a serial loop's
         per-clip seeding); None = the global generator simply continues from clip to clip.
         Returns [(edited waveform, original-vocoded waveform, edited latent)] in input order."""
         if schedule != "sequential" and self.n_lanes > 1:

@@ -10,7 +10,6 @@ Layout convention: activations are channels-last fp32 -- a [B,H,W,C] feature map
 """
 import ctypes
 import math
-import os
 
 import torch
 
@@ -19,16 +18,15 @@ from . import _lib as L
 CU_COUNT = 256          # MI355X; tiling heuristics target this, overridable for tests
 
 
-# A/B switch for the K-chunk width of conv_gemm: 0 auto, 1 force 32, 2 allow 64 on the 128x128 tile too
-FORCE_BK = int(os.environ.get("AED_FORCE_BK", "0"))
-ATTN_VARIANT = int(os.environ.get("AED_ATTN_VARIANT", "0"))      # 0 auto (split-KV when Nk > 64), 1 forces single-pass
-GN_VARIANT = int(os.environ.get("AED_GN_VARIANT", "0"))          # 1: never use the register-resident single-launch GroupNorm (A/B)
-GN_FORCE_SMALL = int(os.environ.get("AED_GN_FORCE_SMALL", "0"))    # A/B: always take the single-launch GroupNorm when it fits
-# 1 (default): small contractions go to the latency-regime kernels of lin_gemm.hip; 0: round-1 routing (A/B runs)
-LIN_MODE = int(os.environ.get("AED_LIN_MODE", "1"))
-LATE_EPILOGUE = int(os.environ.get("AED_LATE_EPILOGUE", "0"))     # A/B: lin_gemm fetches the residual after its reduction
-# measured (tile, ksplit) per (M, N, K, geglu), filled from tools/tile_sweep.py runs (see tile_table.py); the
-# environment override "M,N,K,g:tile[:ksplit];..." is what the sweep tool itself uses
+# Build-variant constants.  These were environment switches while the round-2 kernels were being A/B'd; the product has one
+# configuration now, and the profiling tools (tools/unet_profile.py) set the module attributes directly for A/B runs.
+FORCE_BK = 0            # K-chunk width of conv_gemm: 0 auto, 1 force 32, 2 allow 64 on the 128x128 tile too
+ATTN_VARIANT = 0        # 0 auto (transposed-score kernel when Nk > 64), 1 forces the single-pass kernel
+GN_VARIANT = 0          # 1: never use the register-resident single-launch GroupNorm
+GN_FORCE_SMALL = 0      # 1: always take the single-launch GroupNorm when it fits
+LIN_MODE = 1            # 1: small contractions go to the latency-regime kernels of lin_gemm.hip
+LATE_EPILOGUE = 0       # 1: lin_gemm fetches the residual after its reduction (measured slower)
+# measured (tile, ksplit) per (M, N, K, geglu), filled from tools/tile_sweep.py runs (see tile_table.py)
 try:
     from .tile_table import TILE_TABLE
 except ImportError:                                              # pragma: no cover
@@ -39,10 +37,6 @@ try:                                   # the Stable Audio DiT's shapes, swept se
     TILE_TABLE.update(_DIT_TABLE)
 except ImportError:
     pass
-for _ent in filter(None, os.environ.get("AED_TILE_OVERRIDE", "").split(";")):
-    _k, _v = _ent.split(":", 1)
-    _v = [int(t) for t in _v.split(":")]
-    TILE_TABLE[tuple(int(t) for t in _k.split(","))] = (_v[0], _v[1] if len(_v) > 1 else 1)
 
 
 class Tape:
@@ -97,8 +91,8 @@ class Tape:
         return len(self.ops) - 1
 
     # ------------------------------------------------------------------ conv / linear
-    # tile codes of AED_OP_CONV_GEMM (slot i29): 1/2/4/5/6 = LDS-staged block tiles 128x128 / 128x64 / 64x64 / 128x32 /
-    # 32x128 (conv_gemm.hip), 7 = round-1 wave-split-K kernel, 10..17 = latency-regime kernels of lin_gemm.hip:
+    # tile codes of AED_OP_CONV_GEMM (slot i29): 1/2/3/4/5/6 = LDS-staged block tiles 128x128 / 128x64 / 64x128 / 64x64 /
+    # 128x32 / 32x128 (conv_gemm.hip), 10..19 = latency-regime kernels of lin_gemm.hip:
     # (waves, tile) 10 = (4, 32x32), 11 = (8, 32x32), 12 = (16, 32x32), 13 = (4, 32x64), 14 = (8, 32x64),
     # 15 = (4, 64x64), 16 = (4, 64x32), 17 = (8, 64x64), 18 = (10, 32x32), 19 = (12, 32x32)
     LIN_TILES = {10: (32, 32), 11: (32, 32), 12: (32, 32), 13: (32, 64), 14: (32, 64), 15: (64, 64), 16: (64, 32),
@@ -137,8 +131,6 @@ class Tape:
                 # 10-20 % behind them at M = 5120 and is only kept for the GEGLU shapes above)
         if geglu:
             return 1, 1
-        if (not LIN_MODE) and vector_ok and N > 32 and M > 32 and blocks(64, 64) <= 192 and K <= 2560 and K % 8 == 0:
-            return 7, max(1, math.ceil(K / 1024))
         if N <= 32:
             cfg, bm, bn = 5, 128, 32
         elif M <= 32:
@@ -200,10 +192,6 @@ class Tape:
             # fused LayerNorm: `w` carries gamma, `bias` = W.beta (+bias), `ln_rowsum`[n] = sum_k w[n,k]
             assert KH * KW == 1 and rowvec is None and bias is not None and vec_ok
             ln_mode, rowvec, ksplit = 1, ln_rowsum, 1
-            if tile == 7 and K > 1024:
-                tile = 4
-        if x2 is not None and tile == 7:
-            tile = 4
         i = [M, N, K, lda, ldc, ldr or 0, ld_rv, IH, IW, OH, OW, Cin, KH, KW, stride, pad_h, pad_w, dil_h, dil_w, up,
              a_bs, o_mul, o_add, o_len, out_bs, in_act, out_act, accumulate, ksplit, tile, FORCE_BK, ln_mode,
              C1 if x2 is not None else 0, lda2 or 0, a_bs2 or 0, int(geglu), sm_group, w_bs, vec_ld, vec_bs]
@@ -222,7 +210,7 @@ class Tape:
         lda = x.stride(-2) if lda is None else lda
         return self.conv(x, w, bias, out, B=1, IH=M, IW=1, Cin=K, OH=M, OW=1, N=N, lda=lda, a_bs=0, **kw)
 
-    TILE_BM = {1: 128, 2: 128, 3: 64, 4: 64, 5: 128, 6: 32, 7: 32}
+    TILE_BM = {1: 128, 2: 128, 3: 64, 4: 64, 5: 128, 6: 32}
 
     # ------------------------------------------------------------------ norms
     def groupnorm(self, x, gamma, beta, out, *, B, HW, C, G=32, eps=1e-5, act=0, variant=None, x2=None, C1=0,
@@ -258,15 +246,10 @@ class Tape:
                   [x, part, gamma, beta, out, x2], name=name + ".apply", nbytes=2 * nb)
         return out
 
-    def layernorm(self, x, gamma, beta, out, *, M, C, eps=1e-5, name="ln"):
-        self._add(L.OP_LAYERNORM, [M, C, x.stride(-2), out.stride(-2)], [eps], [x, gamma, beta, out], name=name,
-                  nbytes=8 * M * C)
-        return out
-
     # ------------------------------------------------------------------ attention & friends
     def attention(self, q, k, v, out, *, B, H, Nq, Nk, D, ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, scale,
                   bias=None, ld_bias=0, variant=None, name="attn"):
-        """variant: 0 auto (split-KV kernel when Nk > 64), 1 single-pass kernel."""
+        """variant: 0 auto (transposed-score kernel when Nk > 64), 1 single-pass kernel."""
         variant = ATTN_VARIANT if variant is None else variant
         self._add(L.OP_ATTENTION, [B, H, Nq, Nk, D, ldq, ldk, ldv, ldo, ld_bias, bsq, bsk, bsv, bso, variant], [scale],
                   [q, k, v, bias, out], name=name, flops=4 * B * H * Nq * Nk * D,
@@ -277,10 +260,6 @@ class Tape:
         """Per-prompt operands of the folded cross-attention (AED_OP_XATTN_FOLD; see elementwise.hip)."""
         self._add(L.OP_XATTN_FOLD, [B, Lk, H, C, D, kv.stride(-2)], [], [kv, xq, xs, xo, G, gs, VOt], name=name,
                   flops=0, nbytes=4 * (2 * B * H * Lk * C))
-
-    def geglu(self, h, out, *, M, Dff, name="geglu"):
-        self._add(L.OP_GEGLU, [M, Dff, h.stride(-2), out.stride(-2)], [], [h, out], name=name, nbytes=12 * M * Dff)
-        return out
 
     def copy2d(self, src, dst, *, rows, cols, ld_src=None, ld_dst=None, state=None, idx_off=0, idx_mul=0,
                idx_stride=0, coef=None, c_mul=0, c_off=0, c_stride=0, c_col=0, name="copy"):

@@ -14,8 +14,6 @@ Hooks of the reference forward (h-space tap/replace/add models.py:840-847, skip 
 Everything here is host-side graph construction; arithmetic happens in libaed.so.
 Activations are channels-last; the NCHW<->NHWC change happens only at the wrapper boundary.
 """
-import os
-
 import torch
 
 from . import _lib as L
@@ -23,10 +21,10 @@ from .tape import Tape
 from .weights import ctx_dims_per_block, _per_block
 
 
-FUSE_GEGLU = os.environ.get("AED_FUSE_GEGLU", "1") != "0"
-TWO_SOURCE = os.environ.get("AED_TWO_SOURCE", "1") != "0"
-MERGE_FF2_PROJ = os.environ.get("AED_MERGE_FF2_PROJ", "1") != "0"
-FOLD_XATTN = os.environ.get("AED_FOLD_XATTN", "1") != "0"
+# graph-level fusions of DESIGN.md section 2 (module constants; tools/unet_profile.py flips them for A/B runs)
+TWO_SOURCE = True           # up-block concats read in place by GroupNorm and the shortcut conv
+MERGE_FF2_PROJ = True       # FF2 o proj_out as one two-source GEMM with host-folded weights
+FOLD_XATTN = True           # cross-attention over short constant keys as two skinny GEMMs (latency regime)
 
 
 def geglu_pack_index(dff):
@@ -111,26 +109,23 @@ class PackedUNetWeights:
                 blk, which = base.rsplit(".", 1)
                 nrm = blk + (".norm1" if which == "attn1" else ".norm2")
                 if wk.shape[1] == wq.shape[1]:
-                    wqkv = torch.cat([wq, wk, wv], 0)
-                    wd[base + ".qkv.weight"] = self._dev(wqkv)
-                    self._fold_ln(base + ".qkv_ln", wqkv, sd[nrm + ".weight"], sd[nrm + ".bias"], None)
-                wd[base + ".q.weight"] = self._dev(wq)
+                    self._fold_ln(base + ".qkv_ln", torch.cat([wq, wk, wv], 0), sd[nrm + ".weight"], sd[nrm + ".bias"], None)
                 self._fold_ln(base + ".q_ln", wq, sd[nrm + ".weight"], sd[nrm + ".bias"], None)
                 wd[base + ".kv.weight"] = self._dev(torch.cat([wk, wv], 0))
                 continue
             if k.endswith(".ff.net.0.proj.weight"):
+                # FF1: LayerNorm (norm3) folded in, GEGLU fused into the epilogue -- rows packed [32 value | 32 gate] per
+                # 32 features, so one wavefront's adjacent 32-column sub-tiles hold value and gate of the same features
                 blk = k[: -len(".ff.net.0.proj.weight")]
-                self._fold_ln(blk + ".ff1_ln", v, sd[blk + ".norm3.weight"], sd[blk + ".norm3.bias"],
-                              sd[blk + ".ff.net.0.proj.bias"])
                 dff = v.shape[0] // 2
-                if dff % 32 == 0:
-                    # GEGLU fused into the FF1 epilogue: rows packed [32 value | 32 gate] per 32 features, so one
-                    # wavefront's adjacent 32-column sub-tiles hold value and gate of the same features
-                    perm = geglu_pack_index(dff)
-                    b1 = sd[blk + ".ff.net.0.proj.bias"]
-                    self._fold_ln(blk + ".ff1g_ln", v[perm], sd[blk + ".norm3.weight"], sd[blk + ".norm3.bias"], b1[perm])
-                    wd[blk + ".ff1g.weight"] = self._dev(v[perm])
-                    wd[blk + ".ff1g.bias"] = self._dev(b1[perm])
+                if dff % 32:
+                    raise NotImplementedError(f"{k}: feed-forward width {dff} is not a multiple of 32")
+                perm = geglu_pack_index(dff)
+                b1 = sd[blk + ".ff.net.0.proj.bias"]
+                self._fold_ln(blk + ".ff1g_ln", v[perm], sd[blk + ".norm3.weight"], sd[blk + ".norm3.bias"], b1[perm])
+                continue
+            if k.endswith(".ff.net.0.proj.bias") or (".transformer_blocks." in k and k.rsplit(".", 2)[-2].startswith("norm")):
+                continue            # consumed by the folds above (FF1 bias, LayerNorm affine parameters)
             if k.endswith(".ff.net.2.weight"):
                 # FF2 followed by the site's proj_out is one linear map of [f | t2] (exact algebra, folded in fp64):
                 #   proj_out(ff2(f) + t2) = f.(Wp.W2)^T + t2.Wp^T + (Wp.b2 + bp)
@@ -152,12 +147,10 @@ class PackedUNetWeights:
 
 class UNetEngine:
     def __init__(self, cfg, weights, device, batch, H, W, ctx_len0=0, ctx_len1=0, use_ehs=True,
-                 timesteps_dev=None, state_dev=None, fuse_ln=True, fuse_geglu=None, two_source=None):
+                 timesteps_dev=None, state_dev=None, two_source=None):
         self.cfg = cfg
-        self.fuse_ln = fuse_ln
-        # GEGLU gate in the FF1 epilogue (no [M, 8C] round trip, one launch less); up-block concats read in place (no
-        # copy launches).  The environment switches exist for A/B profiling runs only.
-        self.fuse_geglu = FUSE_GEGLU if fuse_geglu is None else fuse_geglu
+        # Every LayerNorm is folded into the GEMM that consumes it and the GEGLU gate rides in the FF1 epilogue (the
+        # standalone kernels were retired in ABI v4); up-block concats are read in place (no copy launches).
         self.two_source = TWO_SOURCE if two_source is None else two_source
         # FF2 and the site's proj_out as one GEMM over [f | t2] with host-folded weights (one dependent launch less)
         self.merge_ff2_proj = MERGE_FF2_PROJ and self.two_source
@@ -213,30 +206,27 @@ class UNetEngine:
                 N=Cout, KH=3, KW=3, pad_h=1, pad_w=1, res=res, name=p + ".conv2")
         return dest
 
-    def _ln_linear(self, x, pfx, plain_w, plain_b, out, M, K, N, ln, name):
-        """Linear on LayerNorm(x).  Fused: raw x + gamma-folded weights + row statistics gathered inside the
-        GEMM (no LayerNorm launch, no normalised copy in HBM).  Unfused: `x` is already normalised."""
+    def _ln_linear(self, x, pfx, out, M, K, N, name):
+        """Linear on LayerNorm(x): raw x + gamma-folded weights + row statistics gathered inside the GEMM (no LayerNorm
+        launch, no normalised copy in HBM)."""
         wd = self.wd
-        if ln:
-            self.tape.linear(x, wd[pfx + ".weight"], wd[pfx + ".t"], out, M=M, K=K, N=N,
-                             ln_rowsum=wd[pfx + ".rowsum"], name=name + "+ln")
-        else:
-            self.tape.linear(x, plain_w, plain_b, out, M=M, K=K, N=N, name=name)
+        self.tape.linear(x, wd[pfx + ".weight"], wd[pfx + ".t"], out, M=M, K=K, N=N, ln_rowsum=wd[pfx + ".rowsum"],
+                         name=name + "+ln")
 
-    def _attn(self, p, x_ln, C, N, heads, out, kv=None, Lk=0, bias=None, ln=False):
-        """attention sub-layer input projections + fused attention.  x_ln: [B*N, C] (LayerNormed, or raw if ln)."""
-        tp, wd, B = self.tape, self.wd, self.B
+    def _attn(self, p, x, C, N, heads, out, kv=None, Lk=0, bias=None):
+        """attention sub-layer: LayerNorm-folded input projections + fused attention.  x: [B*N, C] (raw, un-normalised)."""
+        tp, B = self.tape, self.B
         M = B * N
         D = C // heads
         if kv is None:
             qkv = self.tmp("t_qkv", M, 3 * C)
-            self._ln_linear(x_ln, p + ".qkv_ln", wd[p + ".qkv.weight"], None, qkv, M, C, 3 * C, ln, p + ".qkv")
+            self._ln_linear(x, p + ".qkv_ln", qkv, M, C, 3 * C, p + ".qkv")
             tp.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], out, B=B, H=heads, Nq=N, Nk=N, D=D, ldq=3 * C, ldk=3 * C,
                          ldv=3 * C, ldo=C, bsq=N * 3 * C, bsk=N * 3 * C, bsv=N * 3 * C, bso=N * C,
                          scale=D ** -0.5, name=p + ".sdpa")
         else:
             q = self.tmp("t_q", M, C)
-            self._ln_linear(x_ln, p + ".q_ln", wd[p + ".q.weight"], None, q, M, C, C, ln, p + ".q")
+            self._ln_linear(x, p + ".q_ln", q, M, C, C, p + ".q")
             tp.attention(q, kv, kv[:, C:], out, B=B, H=heads, Nq=N, Nk=Lk, D=D, ldq=C, ldk=2 * C, ldv=2 * C, ldo=C,
                          bsq=N * C, bsk=Lk * 2 * C, bsv=Lk * 2 * C, bso=N * C, scale=D ** -0.5, bias=bias,
                          ld_bias=Lk if bias is not None else 0, name=p + ".sdpa_x")
@@ -252,19 +242,13 @@ class UNetEngine:
                      name=p + ".norm")
         tp.linear(n, wd[p + ".proj_in.weight"], wd[p + ".proj_in.bias"], t0, M=M, K=C, N=C, name=p + ".proj_in")
         b = p + ".transformer_blocks.0"
-        ln = self.tmp("t_l", M, C)
         o = self.tmp("t_o", M, C)
-        F = self.fuse_ln
-        if not F:
-            tp.layernorm(t0, wd[b + ".norm1.weight"], wd[b + ".norm1.bias"], ln, M=M, C=C, name=b + ".norm1")
-        self._attn(b + ".attn1", t0 if F else ln, C, N, heads, o, ln=F)
+        self._attn(b + ".attn1", t0, C, N, heads, o)
         t1 = self.tmp("t_1", M, C)
         tp.linear(o, wd[b + ".attn1.to_out.0.weight"], wd[b + ".attn1.to_out.0.bias"], t1, M=M, K=C, N=C, res=t0,
                   name=b + ".attn1.to_out")
-        if not F:
-            tp.layernorm(t1, wd[b + ".norm2.weight"], wd[b + ".norm2.bias"], ln, M=M, C=C, name=b + ".norm2")
         if kind == "self2":
-            self._attn(b + ".attn2", t1 if F else ln, C, N, heads, o, ln=F)
+            self._attn(b + ".attn2", t1, C, N, heads, o)
         else:
             which = 0 if kind == "cross0" else 1
             Lk = self.L0 if which == 0 else self.L1
@@ -274,18 +258,18 @@ class UNetEngine:
             self.ctx_tape.linear(ctx.view(B * Lk, cdim), wd[b + ".attn2.kv.weight"], None, kv, M=B * Lk, K=cdim,
                                  N=2 * C, name=b + ".attn2.kv")
             bias = self.bias0 if which == 0 else self.bias1
-            if self._fold_xattn_ok(C, N, heads, Lk, F):
+            if self._fold_xattn_ok(C, N, heads, Lk):
                 return self._folded_cross_attention(p, b, t1, kv, Lk, bias, C, N, heads, x, dest)
-            self._attn(b + ".attn2", t1 if F else ln, C, N, heads, o, kv=kv, Lk=Lk, bias=bias, ln=F)
+            self._attn(b + ".attn2", t1, C, N, heads, o, kv=kv, Lk=Lk, bias=bias)
         t2 = self.tmp("t_2", M, C)
         tp.linear(o, wd[b + ".attn2.to_out.0.weight"], wd[b + ".attn2.to_out.0.bias"], t2, M=M, K=C, N=C, res=t1,
                   name=b + ".attn2.to_out")
-        return self._ff_and_out(p, b, t2, ln, C, M, x, dest)
+        return self._ff_and_out(p, b, t2, C, M, x, dest)
 
-    def _fold_xattn_ok(self, C, N, heads, Lk, F):
-        """Folded cross-attention: latency regime only (lin_gemm kernels), LayerNorm fold on, key count a power of two
-        <= 32 (one softmax group per head inside a 32-column tile), 64-row aligned batch items."""
-        return (self.fold_xattn and F and Lk in (8, 16, 32) and N % 64 == 0 and (heads * Lk) % 32 == 0 and
+    def _fold_xattn_ok(self, C, N, heads, Lk):
+        """Folded cross-attention: latency regime only (lin_gemm kernels), key count a power of two <= 32 (one softmax
+        group per head inside a 32-column tile), 64-row aligned batch items."""
+        return (self.fold_xattn and Lk in (8, 16, 32) and N % 64 == 0 and (heads * Lk) % 32 == 0 and
                 self.B * N <= 4096 and C % 32 == 0)
 
     def _folded_cross_attention(self, p, b, t1, kv, Lk, kbias, C, N, heads, x, dest):
@@ -312,27 +296,15 @@ class UNetEngine:
         t2 = self.tmp("t_2", M, C)
         tp.conv(P, VOt, wd[base + ".to_out.0.bias"], t2, B=B, IH=N, IW=1, Cin=HL, OH=N, OW=1, N=C, res=t1, w_bs=C * HL,
                 name=base + ".PV+to_out", alg_flops=2 * M * C * C)                  # what it replaces: to_out
-        return self._ff_and_out(p, b, t2, None, C, M, x, dest)
+        return self._ff_and_out(p, b, t2, C, M, x, dest)
 
-    def _ff_and_out(self, p, b, t2, ln, C, M, x, dest):
+    def _ff_and_out(self, p, b, t2, C, M, x, dest):
         tp, wd = self.tape, self.wd
-        F = self.fuse_ln
-        if not F:
-            tp.layernorm(t2, wd[b + ".norm3.weight"], wd[b + ".norm3.bias"], ln, M=M, C=C, name=b + ".norm3")
         f = self.tmp("t_f", M, 4 * C)
-        if self.fuse_geglu and (b + ".ff1g.weight") in wd:
-            # FF1 with the GEGLU gate in its epilogue: the [M, 8C] projection never reaches HBM
-            if F:
-                tp.linear(t2, wd[b + ".ff1g_ln.weight"], wd[b + ".ff1g_ln.t"], f, M=M, K=C, N=8 * C,
-                          ln_rowsum=wd[b + ".ff1g_ln.rowsum"], geglu=1, name=b + ".ff1+ln+geglu")
-            else:
-                tp.linear(ln, wd[b + ".ff1g.weight"], wd[b + ".ff1g.bias"], f, M=M, K=C, N=8 * C, geglu=1,
-                          name=b + ".ff1+geglu")
-        else:
-            g = self.tmp("t_g", M, 8 * C)
-            self._ln_linear(t2 if F else ln, b + ".ff1_ln", wd[b + ".ff.net.0.proj.weight"],
-                            wd[b + ".ff.net.0.proj.bias"], g, M, C, 8 * C, F, b + ".ff1")
-            tp.geglu(g, f, M=M, Dff=4 * C, name=b + ".geglu")
+        # FF1 with the LayerNorm fold and the GEGLU gate in its epilogue: the [M, 8C] projection never reaches HBM
+        # (the packed rows exist whenever 4C is a multiple of 32 -- always, GroupNorm already needs 32 | C)
+        tp.linear(t2, wd[b + ".ff1g_ln.weight"], wd[b + ".ff1g_ln.t"], f, M=M, K=C, N=8 * C,
+                  ln_rowsum=wd[b + ".ff1g_ln.rowsum"], geglu=1, name=b + ".ff1+ln+geglu")
         if self.merge_ff2_proj and (b + ".ff2_proj.weight") in wd:
             tp.linear(f, wd[b + ".ff2_proj.weight"], wd[b + ".ff2_proj.bias"], dest, M=M, K=5 * C, N=C, x2=t2,
                       C1=4 * C, res=x, name=b + ".ff2+proj_out")

@@ -199,6 +199,8 @@ def main():
     ap.add_argument("--lanes", type=int, default=4,
                     help="clips in flight per GPU, each on its own HIP stream in the reference's step order "
                          "(pipeline.ClipPipeline); 1 = one clip at a time")
+    ap.add_argument("--lane-launch", default="eager", choices=["eager", "graph"],
+                    help="how a lane issues one diffusion step: launch by launch from C++ (default) or one hipGraphLaunch")
     ap.add_argument("--serial-clips", type=int, default=3,
                     help="clips timed in each of the two one-clip-at-a-time legs reported beside the headline")
     ap.add_argument("--no-extras", action="store_true",
@@ -276,8 +278,9 @@ def main():
         torch.cuda.synchronize()
         return
 
-    def wave_to_mel(wave):
-        mel, _, _ = fn.mel_spectrogram(wave)
+    def wave_to_mel(view, wave):
+        """waveform -> mel on the lane's OWN STFT engine (engines hold their activations: never shared between lanes)"""
+        mel, _, _ = view.get_fn_STFT().mel_spectrogram(wave)
         return mel[0].T[:1024][None, None].contiguous()
 
     def finish(t0, lat):
@@ -339,7 +342,7 @@ def main():
     if LANES > 1:
         # Headline: L clips in flight, each in the reference's step order (no timestep regrouping).
         from audioeditingcode_amd.pipeline import ClipPipeline
-        pipe = ClipPipeline(m, lanes=LANES)
+        pipe = ClipPipeline(m, lanes=LANES, launch=args.lane_launch)
         dt, gathered = timed_lanes(args.steps, args.warmup)
         headline = f"reference step order, {LANES} clips in flight per GPU on {LANES} HIP streams"
         extra["pipeline"] = pipe.lane_report()

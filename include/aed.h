@@ -41,9 +41,9 @@ enum aed_opcode {
                                  (skip concat never materialised), fused LayerNorm, fused GEGLU gate (K8)        */
     AED_OP_GN_STATS = 2,      /* GroupNorm partial sums (K4)                                   */
     AED_OP_GN_APPLY = 3,      /* GroupNorm normalise + affine (+SiLU) (K4)                     */
-    AED_OP_LAYERNORM = 4,     /* LayerNorm over the last dim (K8)                              */
+    AED_OP_LAYERNORM = 4,     /* RETIRED in v4 (returns an error): LayerNorm is fused into the consuming GEMM (K8)  */
     AED_OP_ATTENTION = 5,     /* softmax(QK^T*scale + bias)V, flash-style, fp32 MFMA (K7)      */
-    AED_OP_GEGLU = 6,         /* x * gelu(gate) (K8)                                           */
+    AED_OP_GEGLU = 6,         /* RETIRED in v4 (returns an error): the gate rides in the FF1 epilogue (K8)         */
     AED_OP_COPY2D = 7,        /* strided 2-D copy (skip concat, h-space tap/replace) (K10)     */
     AED_OP_TIME_EMBED = 8,    /* sinusoidal timestep embedding (K9)                            */
     AED_OP_SOFTMAX_ROWS = 9,  /* row softmax (VAE single-head attention)                       */

@@ -200,15 +200,6 @@ def gn_scale_shift(op):
     _f32(p[3], B * 2 * C).reshape(B, 2, C).copy_(torch.stack([a, d], 1).float())
 
 
-def layernorm(op):
-    i, p = op.i, op.p
-    M, C, ldx, ldy = [int(i[k]) for k in range(4)]
-    x = _f32(p[0], (M - 1) * ldx + C).as_strided((M, C), (ldx, 1)).double()
-    y = torch.nn.functional.layer_norm(x, (C,), _f32(p[1], C).double(), _f32(p[2], C).double(), float(op.f[0]))
-    _f32(p[3], (M - 1) * ldy + C).as_strided((M, C), (ldy, 1)).copy_(y.float())
-
-
-# ------------------------------------------------------------------------------------------------- attention etc.
 def attention(op):
     i, p = op.i, op.p
     B, H, Nq, Nk, D, ldq, ldk, ldv, ldo, ld_bias, bsq, bsk, bsv, bso = [int(i[k]) for k in range(14)]
@@ -224,15 +215,6 @@ def attention(op):
         s = s + bias[:, None, None, :]
     o = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(s, -1), v)
     mat(p[4], Nq, ldo, bso).copy_(o.float())
-
-
-def geglu(op):
-    i, p = op.i, op.p
-    M, Dff, ldh, ldo = [int(i[k]) for k in range(4)]
-    h = _f32(p[0], (M - 1) * ldh + 2 * Dff).as_strided((M, 2 * Dff), (ldh, 1))
-    a, g = h[:, :Dff], h[:, Dff:]
-    out = a * (0.5 * g * (1.0 + torch.erf(g * 0.70710678118654752440)))
-    _f32(p[1], (M - 1) * ldo + Dff).as_strided((M, Dff), (ldo, 1)).copy_(out)
 
 
 def copy2d(op):
@@ -480,7 +462,7 @@ def gauss_sample(op):
     _f32(p[2], rows * C).reshape(rows, C).copy_(out)
 
 
-DISPATCH = {0: nop, 1: conv_gemm, 2: gn_stats, 3: gn_apply, 4: layernorm, 5: attention, 6: geglu, 7: copy2d,
+DISPATCH = {0: nop, 1: conv_gemm, 2: gn_stats, 3: gn_apply, 5: attention, 7: copy2d,
             8: time_embed, 9: softmax_rows, 10: transpose, 11: axpby, 12: invert_step, 13: reverse_step,
             14: reverse_step, 15: advance, 16: reflect_pad, 17: magnitude, 18: transpose, 19: transpose, 20: nop,
             21: gn_scale_shift, 22: gn_small, 23: xattn_fold, 24: rotary, 25: snake, 26: sa_step, 27: gauss_sample}

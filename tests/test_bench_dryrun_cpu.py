@@ -109,7 +109,8 @@ class _Pipe:
     """pipeline.ClipPipeline stand-in: L lane views / streams, clips handed back in order."""
     made = []
 
-    def __init__(self, model, lanes=None):
+    def __init__(self, model, lanes=None, launch="eager"):
+        assert launch in ("eager", "graph")
         self.n_lanes = lanes
         self.views = [model.lane_view() for _ in range(lanes)]
         self.streams = [_Stream() for _ in range(lanes)]
@@ -121,6 +122,7 @@ class _Pipe:
 
     def edit_clips(self, items, *a, prepare=None, seeds=None, **k):
         assert len(seeds) == len(items) and prepare is not None
+        assert prepare(self.views[0], items[0]).shape == (1, 1, 1024, 64)          # prepare(lane view, item) -> mel
         self.calls.append(("edit_clips", len(items)))
         return [(None, None, torch.ones(1, 8, 256, 16)) for _ in items]
 

@@ -24,18 +24,22 @@ def _serial(m, mels, T, tstart, seeds):
     return out
 
 
-def test_lanes_are_bit_identical_to_one_clip_at_a_time_tiny():
-    """5 clips through 3 lanes == the same clips one at a time (same per-clip seeds): latents and waveforms bit for bit;
-    a second pass without per-clip seeds consumes the global generator in clip order."""
+@pytest.mark.parametrize("launch", ["eager", "graph"])
+def test_lanes_are_bit_identical_to_one_clip_at_a_time_tiny(launch):
+    """5 clips through 3 lanes == the same clips one at a time (same per-clip seeds): latents and waveforms bit for bit,
+    with the waveform -> mel step running on the lanes too (every lane owns its STFT engine); a second pass without
+    per-clip seeds consumes the global generator in clip order.  Both ways a lane can issue a step (launch by launch /
+    one hipGraphLaunch)."""
     T, tstart = 10, 6
     m = models.load_model("tiny/audioldm2", DEV, T, seed=0)
-    mels = [load_audio((synthetic_clip(seconds=1.25, seed=7 + i), 16000), m.get_fn_STFT(), device=DEV, stft=True)[0]
-            for i in range(5)]
+    wavs = [synthetic_clip(seconds=1.25, seed=7 + i) for i in range(5)]
+    to_mel = lambda view, wav: load_audio((wav, 16000), view.get_fn_STFT(), device=DEV, stft=True)[0]     # noqa: E731
+    mels = [to_mel(m, w) for w in wavs]
     seeds = [40 + i for i in range(5)]
     ref = _serial(m, mels, T, tstart, seeds)
-    pipe = ClipPipeline(m, lanes=3)
-    pipe.warm_up(mels[0], *ARGS, T, tstart)
-    got = pipe.edit_clips(mels, *ARGS, T, tstart, seeds=seeds)
+    pipe = ClipPipeline(m, lanes=3, launch=launch)
+    pipe.warm_up(wavs[0], *ARGS, T, tstart, prepare=to_mel)
+    got = pipe.edit_clips(wavs, *ARGS, T, tstart, seeds=seeds, prepare=to_mel)
     for i, ((a, o, w), (a2, o2, w2)) in enumerate(zip(got, ref)):
         assert torch.equal(w, w2), (i, float((w - w2).abs().max()))
         assert torch.equal(a, a2) and torch.equal(o, o2), i

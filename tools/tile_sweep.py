@@ -84,8 +84,6 @@ def candidates(M, N, K, taps, geglu, generic):
         if t4 < 256 and K >= 256:          # legacy split-K + reduce
             nch = -(-K // 32)
             c.append((4, max(1, min(-(-512 // t4), nch // 4, 32))))
-        if M * N <= 64 * 64 * 192 and K <= 2560:
-            c.append((7, max(1, -(-K // 1024))))
     big = M * N >= 4096 * 1024
     if big:                                 # throughput regime: the 32x32 lin tiles only add L2 traffic
         c = [x for x in c if x[0] in (1, 2, 3, 4, 15, 17)]
@@ -140,8 +138,6 @@ for key, (op, count, name, flops) in reps.items():
     if auto not in cands:
         cands.append(auto)
     for tile, ks in cands:
-        if two and tile == 7:
-            continue
         us, err = time_cfg(op, tile, ks)
         if us is not None:
             res[f"{tile}:{ks}"] = us

@@ -2,8 +2,9 @@
 weights): eager time, hipGraph replay time, HIP-event pair per op, and a JSON dump of every op's shape + time.
 
     PYTHONPATH=. python tools/unet_profile.py <B> [variant ...]
-variant = comma list of lin=0|1, geglu=0|1, two=0|1, late=0|1, merge=0|1  (default: the package defaults), e.g.
-    python tools/unet_profile.py 2 lin=0,geglu=0,two=0 "" attn=2 gn=1"""
+variant = comma list of lin=0|1, two=0|1, late=0|1, merge=0|1, fold=0|1, attn=0|1, gn=0|1, gnreg=0|1  (default: the package
+defaults; the tool flips the module constants of tape.py / unet.py), e.g.
+    python tools/unet_profile.py 2 lin=0,two=0 "" attn=1 gn=1"""
 import collections
 import json
 import os
@@ -20,7 +21,7 @@ variants = sys.argv[2:] or [""]
 fam = configs.FAMILIES["audioldm2"]
 sd = weights.random_state_dict(weights.unet_param_shapes(fam["unet"]), seed=0)
 packed = PackedUNetWeights(sd, "cuda:0")
-DEFAULTS = dict(lin=tape_mod.LIN_MODE, geglu=int(unet_mod.FUSE_GEGLU), two=int(unet_mod.TWO_SOURCE),
+DEFAULTS = dict(lin=tape_mod.LIN_MODE, two=int(unet_mod.TWO_SOURCE),
                 attn=tape_mod.ATTN_VARIANT, gn=tape_mod.GN_FORCE_SMALL, late=tape_mod.LATE_EPILOGUE,
                 merge=int(unet_mod.MERGE_FF2_PROJ), fold=int(unet_mod.FOLD_XATTN), gnreg=1 - tape_mod.GN_VARIANT)
 st = torch.cuda.Stream()
@@ -31,9 +32,8 @@ for spec in variants:
     tape_mod.LIN_MODE, tape_mod.ATTN_VARIANT, tape_mod.GN_FORCE_SMALL = v["lin"], v["attn"], v["gn"]
     tape_mod.LATE_EPILOGUE, unet_mod.MERGE_FF2_PROJ, unet_mod.FOLD_XATTN = v["late"], bool(v["merge"]), bool(v["fold"])
     tape_mod.GN_VARIANT = 1 - v["gnreg"]
-    tag = "_".join(f"{k}{v[k]}" for k in ("lin", "geglu", "two", "late", "merge", "attn", "gn", "fold", "gnreg"))
-    eng = UNetEngine(fam["unet"], packed, "cuda:0", B, 256, 16, ctx_len0=8, ctx_len1=16, fuse_geglu=bool(v["geglu"]),
-                     two_source=bool(v["two"]))
+    tag = "_".join(f"{k}{v[k]}" for k in ("lin", "two", "late", "merge", "attn", "gn", "fold", "gnreg"))
+    eng = UNetEngine(fam["unet"], packed, "cuda:0", B, 256, 16, ctx_len0=8, ctx_len1=16, two_source=bool(v["two"]))
     g = torch.Generator().manual_seed(1)
     eng.set_conditioning(ehs0=torch.randn(B, 8, 768, generator=g), ehs1=torch.randn(B, 16, 1024, generator=g),
                          bias1=torch.zeros(B, 16))

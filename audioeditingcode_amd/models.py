@@ -729,13 +729,17 @@ class StableAudWrapper(PipelineWrapper):
 
     def reverse_step_with_custom_noise(self, model_output, timestep, sample, variance_noise=None,
                                        first_order: bool = False, **kwargs):
-        """models.py:1282-1329 with the noise supplied (the Brownian-tree branch for variance_noise=None is not built:
-        the editing loops always pass the inverted noise maps)."""
-        if variance_noise is None:
-            raise NotImplementedError("reverse_step_with_custom_noise without variance_noise (BrownianTreeNoiseSampler)")
+        """models.py:1282-1329.  The editing loops always pass the inverted noise maps; with variance_noise=None the step
+        draws from a Brownian path over sigma (models.py:1305-1312; scheduler.BrownianTreeNoiseSampler)."""
         s = self.model.scheduler
         if s.step_index is None:
             s._init_step_index(timestep)
+        if variance_noise is None:
+            if s.noise_sampler is None:
+                from .scheduler import BrownianTreeNoiseSampler
+                s.noise_sampler = BrownianTreeNoiseSampler(model_output, sigma_min=s.config.sigma_min,
+                                                           sigma_max=s.config.sigma_max, seed=None)
+            variance_noise = s.noise_sampler(s.sigmas[s.step_index], s.sigmas[s.step_index + 1]).to(model_output.device)
         i, order = self._coef(first_order)
         c = sa_step_coefficients(s, i, order)
         cf = (ctypes.c_float * L.SA_COEF_STRIDE)(*c.tolist())

@@ -177,6 +177,56 @@ def coefficient_table(sched, timesteps, eta=1.0, kind="ddpm"):
 
 
 # =============================================================================================== Stable Audio Open
+class BrownianTreeNoiseSampler:
+    """The noise source of the reference's `reverse_step_with_custom_noise(variance_noise=None)` branch
+    (models.py:1305-1312: diffusers' BrownianTreeNoiseSampler over torchsde's Brownian tree, both un-vendored, created
+    with `seed=None`, i.e. fresh entropy per sampler -- there is no stream to reproduce, the contract is the
+    distribution).  One Brownian path W per latent element over sigma; a call returns
+        sign * (W(hi) - W(lo)) / sqrt(hi - lo),   lo/hi = the ordered pair, sign = -1 when sigma > sigma_next,
+    i.e. N(0, 1) per element, identical for a repeated interval, independent over disjoint intervals and additive over
+    adjacent ones.  The path is built lazily at the queried sigmas: a new point between two known ones is drawn from the
+    Brownian bridge between them (Levy construction), one outside the known range from an independent increment."""
+
+    def __init__(self, x, sigma_min, sigma_max, seed=None):
+        self.shape, self.device = tuple(x.shape), x.device
+        self.gen = torch.Generator()
+        if seed is None:
+            self.gen.seed()
+        else:
+            self.gen.manual_seed(int(seed))
+        t0, t1 = sorted((float(sigma_min), float(sigma_max)))
+        self.times = [t0, t1]
+        self.values = [torch.zeros(self.shape), self._randn() * (t1 - t0) ** 0.5]
+
+    def _randn(self):
+        return torch.randn(self.shape, generator=self.gen, dtype=torch.float32)
+
+    def _at(self, t):
+        import bisect
+        t = float(t)
+        k = bisect.bisect_left(self.times, t)
+        if k < len(self.times) and self.times[k] == t:
+            return self.values[k]
+        if k == 0:                                        # left of every known point
+            w = self.values[0] - self._randn() * (self.times[0] - t) ** 0.5
+        elif k == len(self.times):                        # right of every known point
+            w = self.values[-1] + self._randn() * (t - self.times[-1]) ** 0.5
+        else:                                             # Brownian bridge between the neighbours
+            a, b = self.times[k - 1], self.times[k]
+            wa, wb = self.values[k - 1], self.values[k]
+            w = wa + (t - a) / (b - a) * (wb - wa) + self._randn() * ((t - a) * (b - t) / (b - a)) ** 0.5
+        self.times.insert(k, t)
+        self.values.insert(k, w)
+        return w
+
+    def __call__(self, sigma, sigma_next):
+        a, b = float(sigma), float(sigma_next)
+        if a == b:
+            raise ValueError("BrownianTreeNoiseSampler: empty interval")
+        lo, hi, sign = (a, b, 1.0) if a < b else (b, a, -1.0)
+        return (sign * (self._at(hi) - self._at(lo)) / (hi - lo) ** 0.5).to(self.device)
+
+
 class CosineDPMSolverMultistepScheduler:
     """The scheduler duck type StableAudWrapper reads (/root/reference/code/models.py:1066-1068, :1142-1329): `.sigmas`,
     `.timesteps` (float, atan(sigma)*2/pi), `.config.{solver_order,final_sigmas_type,lower_order_final,euler_at_final,

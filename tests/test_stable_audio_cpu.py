@@ -243,6 +243,22 @@ def test_host_driven_methods_follow_the_reference_call_pattern(cpu_stack):
         cnd = m.unet_forward(xi, timestep=t, encoder_hidden_states=hs, encoder_attention_mask=mk)[0].sample
         xt = m.reverse_step_with_custom_noise(u + 5.0 * (cnd - u), t, xt, variance_noise=zs2[idx].unsqueeze(0))
     assert float((xt - w).abs().max() / w.abs().max()) < 2e-3
+    # variance_noise=None (models.py:1305-1312): the step draws from the scheduler's Brownian path; given the noise the
+    # sampler returned for that sigma interval, the step is the same arithmetic as with an explicit map
+    xt = xts2[tstart].unsqueeze(0)
+    m.setup_extra_inputs(xt, extra_info=extra2, init_timestep=s.timesteps[-tstart], audio_end_in_s=0.2)
+    t = s.timesteps[-tstart]
+    v = m.unet_forward(s.scale_model_input(xt, t), timestep=t, encoder_hidden_states=uhs, encoder_attention_mask=umk)[0].sample
+    assert s.noise_sampler is None
+    i0 = s.step_index
+    out_none = m.reverse_step_with_custom_noise(v, t, xt)
+    assert s.noise_sampler is not None and torch.isfinite(out_none).all()
+    drawn = s.noise_sampler(s.sigmas[i0], s.sigmas[i0 + 1])               # the same interval returns the same noise
+    sampler = s.noise_sampler
+    m.setup_extra_inputs(xt, extra_info=extra2, init_timestep=s.timesteps[-tstart], audio_end_in_s=0.2)
+    s.noise_sampler = sampler
+    out_given = m.reverse_step_with_custom_noise(v, t, xt, variance_noise=drawn)
+    assert torch.equal(out_none, out_given)
 
 
 def test_step_coefficients_and_interpreter_reproduce_the_reference_step_vectors(golden_dir):
@@ -271,3 +287,27 @@ def test_step_coefficients_and_interpreter_reproduce_the_reference_step_vectors(
                                                  zin.data_ptr(), prev.data_ptr(), xt.numel(), None)
         for got, name in ((z, "z"), (xtm1, "xfix"), (hist, "d"), (prev, "prev")):
             np.testing.assert_array_equal(got.numpy(), g[f"step.{name}{k}"])
+
+
+def test_brownian_tree_noise_sampler_is_a_consistent_brownian_path():
+    """scheduler.BrownianTreeNoiseSampler (the variance_noise=None branch of reverse_step_with_custom_noise,
+    models.py:1305-1312): unit-variance noise per step, the same value for a repeated interval, additive over adjacent
+    intervals (one underlying path, whatever the query order), independent over disjoint ones, sign flip with direction,
+    queries beyond [sigma_min, sigma_max] (the final step ends at sigma = 0) extend the path."""
+    from audioeditingcode_amd.scheduler import BrownianTreeNoiseSampler
+    x = torch.zeros(4, 64, 256)
+    bs = BrownianTreeNoiseSampler(x, 0.3, 500.0, seed=5)
+    n1 = bs(200.0, 80.0)
+    assert n1.shape == x.shape and abs(float(n1.mean())) < 0.02 and abs(float(n1.std()) - 1.0) < 0.02
+    assert torch.equal(bs(200.0, 80.0), n1) and torch.equal(bs(80.0, 200.0), -n1)
+    a, b = bs(200.0, 120.0), bs(120.0, 80.0)                 # refining a known interval keeps the whole
+    whole = (a * (80.0 ** 0.5) + b * (40.0 ** 0.5)) / (120.0 ** 0.5)
+    assert torch.allclose(whole, n1, atol=1e-5)
+    c = bs(80.0, 30.0)
+    corr = float((c * n1).mean())
+    assert abs(corr) < 0.02                                   # disjoint intervals: independent increments
+    last = bs(0.3, 0.0)                                       # beyond sigma_min
+    assert torch.isfinite(last).all() and abs(float(last.std()) - 1.0) < 0.02
+    other = BrownianTreeNoiseSampler(x, 0.3, 500.0, seed=6)(200.0, 80.0)
+    assert not torch.equal(other, n1)
+    assert not torch.equal(BrownianTreeNoiseSampler(x, 0.3, 500.0)(200.0, 80.0), BrownianTreeNoiseSampler(x, 0.3, 500.0)(200.0, 80.0))

@@ -1,35 +1,46 @@
-"""Several clips in flight on one MI355X: L independent edit lanes (BASELINE config 2 served as a stream of clips).
+"""Several clips in flight on one MI355X (BASELINE config 2 served as a stream of independent clips).
 
-Why.  One clip of the reference path is a strictly sequential chain -- 200 inversion steps + 100 edit steps
-(inversion_utils.py:75-133, :221-315), each one U-Net forward at batch 2 (uncond | cond) = ~600 dependent kernel launches
-of 5-30 us.  That chain is bound by launch / first-operand latency, not by arithmetic: measured on the MI355X
-(profiles/r03_lanes.md) one chain keeps the chip ~25 % busy (8.6 ms per step), while 2 / 3 / 4 INDEPENDENT chains on
-separate HIP streams run at 10.3 / 11.9 / 11.9 ms per step each, i.e. 5.1 / 4.0 / 3.0 ms of chip time per clip-step.  The
-idle resource is compute units, and the only work that can use them without touching a clip's arithmetic is ANOTHER
-clip.  (A CU-partitioned two-clip variant -- edit loop of clip i beside the batch-200 inversion of clip i+1 on disjoint
-CU masks, streams.PartitionStream -- was measured first and is slower: both partitions become CU-time bound,
-profiles/r03_cu_partition.md.)
+Why.  One clip of the reference path is a sequential chain of two regimes: the forward inversion
+(inversion_utils.py:75-133; timestep-batched here: two U-Net calls at batch 200, throughput-bound, ~0.63 of the fp32 MFMA
+peak on the CUs it gets) and the 100-step edit loop (:221-315; ~600 dependent launches per step at U-Net batch 2, bound by
+launch / first-operand latency: 8.6 ms per step on 256 CUs, 12.7 ms on 128 -- it cannot use the chip).  A clip's own
+arithmetic cannot be reordered, so the only work that can fill the idle compute units is ANOTHER clip.
 
-What.  `ClipPipeline` owns L lanes = (HIP stream, lane view of the wrapper, host thread).  A lane view shares the frozen
-weights / scheduler / text encoders of the wrapper and owns every mutable buffer (U-Net, VAE, vocoder and STFT engines,
-loop plans, hipGraphs).  Each lane thread pulls the next clip and runs the UNCHANGED per-clip path on its stream --
-main_run.edit_clip: mel -> VAE encode -> forward inversion -> edit loop -> VAE decode -> vocoder -- in the reference's
-step order by default (`schedule="sequential"`: no timestep regrouping at all).  Every clip's launches, values and
-results are those of the serial run, bit for bit (tests/test_gpu_pipeline.py); only the interleaving on the GPU differs.
+Plans (measured on the MI355X, profiles/r03_cu_partition.md and profiles/r03_lanes.md):
+  * "partition" (default): a two-stage pipeline on DISJOINT CU partitions (streams.PartitionStream: hardware queues with
+    CU masks).  Stage "front" (one worker, CUs [edit_cus, total)): waveform -> mel -> VAE encode -> forward inversion.
+    Stage "back" (edit_lanes workers sharing CUs [0, edit_cus)): edit loop -> VAE decode -> vocoder.  While clip i is in
+    its edit loop, clip i+1 is being inverted; the two kernel classes never queue behind each other's workgroups (without
+    masks a batch-2 kernel waits for 128x128-tile workgroups that hold a CU for 0.2-1 ms: 28.9 ms per edit step).
+    Fill and drain (no other stage to share with) run on the whole chip.
+  * "lanes": L workers, each running whole clips in the reference's step order on its own stream, unpartitioned.
+    Measured: chip time per U-Net forward 8.6 -> 6.0 / 5.2 / 6.1 ms at L = 2 / 3 / 4 -- the batch-2 kernels' CU-time
+    saturates the chip at ~1.6x, i.e. 1.6-1.9 s per clip: no better than one clip at a time with the batched inversion.
+    Kept as a plan because it is the only one that needs no timestep regrouping.
 
-RNG.  The reference draws a clip's T noise maps from torch's global CPU generator (models.py:76-81).  Lanes keep that
-stream and its order: clip i draws (after an optional `torch.manual_seed(seeds[i])`) only when clips 0..i-1 have drawn
-(`_DrawGate`), so the noise every clip sees is what a serial loop over the clips would have produced.
+Nothing about a clip's computation changes: the same plans, tapes, hipGraphs and kernels run in the same order on the
+same values as in main_run.edit_clip -- only the stream they are launched on differs -- so a pipelined clip is
+bit-identical to the same clip edited alone (tests/test_gpu_pipeline.py).
+
+Workers are host threads (one per lane; the HIP calls release the GIL), each with a lane view of the wrapper
+(models.PipelineWrapper.lane_view: shares the frozen weights / scheduler / text encoders, owns every mutable buffer --
+engines, loop plans, hipGraphs).  RNG: the reference draws a clip's T noise maps from torch's global CPU generator
+(models.py:76-81); clip i draws (after an optional `torch.manual_seed(seeds[i])`) only when clips 0..i-1 have drawn
+(`_DrawGate`), so every clip sees the noise a serial loop over the clips would have given it.
 """
 import contextlib
+import queue
 import threading
 import time
 
 import torch
 
-from .main_run import edit_clip
+from .ddm_inversion.inversion_utils import inversion_forward_process, inversion_reverse_process
+from .streams import PartitionStream
 
-DEFAULT_LANES = 4
+DEFAULT_EDIT_CUS = 128          # CUs of the edit-loop partition (the two stages' per-clip times cross near 128 of 256)
+DEFAULT_LANES = 3
+_STOP = object()
 
 
 class _DrawGate:
@@ -65,40 +76,100 @@ class _DrawGate:
             self.cv.notify_all()
 
 
+class _Worker:
+    """One lane: a lane view of the model, its stream on the stage's CU partition and (partition plan) an unmasked
+    stream for fill / drain."""
+
+    def __init__(self, stage, k, view, lane, full):
+        self.stage, self.k, self.view, self.lane, self.full = stage, k, view, lane, full
+        self.last = None            # (event, stream) of this worker's previous job
+        self.warm = False
+
+
 class ClipPipeline:
-    def __init__(self, model, lanes=None, launch="eager"):
+    # the HIP touch points (the CPU host-logic tests substitute recording stand-ins)
+    lane_type = PartitionStream
+    event_type = torch.cuda.Event
+
+    def __init__(self, model, plan="partition", edit_cus=None, edit_lanes=1, lanes=None, launch="graph",
+                 timestep_group=100):
         if getattr(model, "kind", None) == "stable_audio":
             raise NotImplementedError("ClipPipeline drives the mel-latent families (AudioLDM / AudioLDM2 / TANGO)")
-        self.model = model
-        self.n_lanes = DEFAULT_LANES if lanes is None else int(lanes)
-        if self.n_lanes < 1:
-            raise ValueError("lanes must be >= 1")
+        if plan not in ("partition", "lanes"):
+            raise ValueError("plan must be 'partition' or 'lanes'")
         if launch not in ("eager", "graph"):
             raise ValueError("launch must be 'eager' or 'graph'")
-        # How a lane issues one diffusion step.  "graph": one hipGraphLaunch per step (what the single-clip loops do).
-        # "eager": the step's ~610 launches are issued one by one from C++ (aed_tape_run, GIL released).  On the device the
-        # two are equivalent (same kernels, same dependent-launch boundary cost); on the host a hipGraphLaunch of a
-        # 600-node graph costs milliseconds and the runtime serialises such launches across threads, which starves
-        # concurrent lanes (measured: profiles/r03_lanes.md) -- eager launches from one thread per lane do not.
-        self.launch = launch
-        self.views = [model.lane_view() for _ in range(self.n_lanes)]
-        for v in self.views:
-            v._lane_eager = launch == "eager"
-        self.streams = [self._new_stream(model.device) for _ in range(self.n_lanes)]
-        self._build_lock = threading.Lock()      # first clip of a lane: engines / plans / lazily folded weights are built
-        self._warm = [False] * self.n_lanes
+        self.model, self.plan, self.launch = model, plan, launch
+        self.timestep_group = int(timestep_group)
+        dev = model.device
+        Lane = self.lane_type
+        self.full = Lane(dev)                                      # the whole chip
+        self.total = self.full.total
+        self.stages = []                                           # [(name, halves, [workers])]
+        if plan == "partition":
+            self.edit_cus = DEFAULT_EDIT_CUS if edit_cus is None else int(edit_cus)
+            if not 0 < self.edit_cus < self.total:
+                raise ValueError(f"edit_cus={self.edit_cus} must leave CUs for both partitions of {self.total}")
+            if self.timestep_group < 2:
+                raise ValueError("the partition plan needs the timestep-batched inversion (timestep_group >= 2): the "
+                                 "front stage must not share the edit loop's batch-2 engine regime")
+            self.edit_lanes = max(1, int(edit_lanes))
+            front = [_Worker("front", 0, self._view(), Lane(dev, cus=range(self.edit_cus, self.total), total=self.total),
+                             self.full)]
+            back = [_Worker("back", k, self._view(), Lane(dev, cus=range(self.edit_cus), total=self.total), Lane(dev))
+                    for k in range(self.edit_lanes)]
+            self.stages = [("front", ("front",), front), ("back", ("back",), back)]
+        else:
+            n = DEFAULT_LANES if lanes is None else int(lanes)
+            if n < 1:
+                raise ValueError("lanes must be >= 1")
+            self.edit_cus, self.edit_lanes = None, n
+            self.stages = [("clip", ("front", "back"), [_Worker("clip", k, self._view(), Lane(dev), None)
+                                                        for k in range(n)])]
+        self._build_lock = threading.Lock()     # an un-warmed worker builds engines (and lazily folds shared weights)
         self.stats = []
 
-    # the two HIP touch points (the CPU host-logic tests substitute stand-ins; the product uses HIP streams)
-    @staticmethod
-    def _new_stream(device):
-        return torch.cuda.Stream(device=device)
+    def _view(self):
+        v = self.model.lane_view()
+        # "graph": one hipGraphLaunch per diffusion step (0.28 ms of host time for ~610 kernel nodes); "eager": the step's
+        # launches issued one by one from C++ (2.2 ms).  Same kernels and values either way; measured equal on the device.
+        v._lane_eager = self.launch == "eager"
+        return v
+
+    @property
+    def workers(self):
+        return [w for _, _, ws in self.stages for w in ws]
+
+    @property
+    def clips_in_flight(self):
+        return len(self.workers)
 
     @staticmethod
     def _stream_ctx(stream):
         return torch.cuda.stream(stream)
 
-    # ------------------------------------------------------------------ one lane
+    # ------------------------------------------------------------------ lane plumbing
+    @contextlib.contextmanager
+    def _on(self, w, lane):
+        """Run the enclosed host code with `lane.stream` as torch's current stream and as the loop engines' replay stream.
+        A worker's engines and plans are reused clip after clip: when it moves to its other stream (fill / drain), that
+        stream first waits for the worker's previous job."""
+        st = lane.stream
+        if w.last is not None and w.last[1] is not st:
+            st.wait_event(w.last[0])
+        w.view._lane_stream = st
+        t0, t1 = self.event_type(enable_timing=True), self.event_type(enable_timing=True)
+        try:
+            with self._stream_ctx(st):
+                t0.record(st)
+                yield st
+                t1.record(st)
+        finally:
+            w.view._lane_stream = None
+        w.last = (t1, st)
+        self.stats.append((w.stage, w.k, "chip" if (lane is w.full and w.full is not None) else "lane", t0, t1))
+
+    # ------------------------------------------------------------------ the two halves of main_run.edit_clip
     def _gated_sample(self, view, gate):
         """view.sample_xts_from_x0 with the clip's T draws taken from the global generator in clip order."""
         def sample_xts_from_x0(x0, num_inference_steps=50):
@@ -110,88 +181,211 @@ class ClipPipeline:
             return ed.sample_xts(x, noise=noise)[:, 0]
         return sample_xts_from_x0
 
-    def _lane(self, k, job):
-        view, gate = self.views[k], job["gate"]
-        view.sample_xts_from_x0 = self._gated_sample(view, gate)
+    def _front(self, w, st, job, i):
+        """main_run.py:113-150: (waveform -> mel ->) VAE encode -> forward inversion."""
+        v, a = w.view, job["a"]
+        item = job["items"][i]
+        x0 = job["prepare"](v, item) if job["prepare"] is not None else item
+        w0 = v.vae_encode(x0)
+        _, zs, wts, _ = inversion_forward_process(v, w0, etas=a["eta"], prompts=a["src"], cfg_scales=a["cfg_src"],
+                                                  num_inference_steps=a["T"], numerical_fix=True,
+                                                  schedule=a["schedule"], timestep_group=a["group"])
+        done = self.event_type()
+        done.record(st)
+        return dict(x0=x0, zs=zs, wts=wts, done=done)
+
+    def _back(self, w, st, job, f):
+        """main_run.py:152-185: edit loop from x_tstart -> VAE decode -> vocoder (edited + original)."""
+        v, a = w.view, job["a"]
+        st.wait_event(f["done"])
+        for t in (f["x0"], f["zs"], f["wts"]):
+            if t.is_cuda:
+                t.record_stream(st)
+        tstart = a["tstart"]
+        w_edit, _ = inversion_reverse_process(v, xT=f["wts"], tstart=torch.tensor([tstart], dtype=torch.int),
+                                              etas=a["eta"], prompts=a["tgt"], neg_prompts=a["neg"],
+                                              cfg_scales=a["cfg_tar"], zs=f["zs"][:tstart])
+        x0_dec = v.vae_decode(w_edit)
+        if x0_dec.dim() < 4:
+            x0_dec = x0_dec[None]
+        audio = v.decode_to_mel(x0_dec)                  # CPU tensors: the host blocks here until this clip is done
+        orig = v.decode_to_mel(f["x0"])
+        return audio, orig, w_edit
+
+    # ------------------------------------------------------------------ workers
+    def _pick_lane(self, w, job, stage_idx):
+        """The worker's partition -- or the whole chip while no other stage has work (fill / drain)."""
+        if w.full is None or len(self.stages) == 1:
+            return w.lane
+        with job["lock"]:
+            if stage_idx == 0:
+                idle = job["busy"][1] == 0 and job["queues"][1].qsize() == 0
+            else:       # drain: the front stage has issued everything AND its last job has finished on the device
+                ev = job["front_event"]
+                idle = job["stage_done"][0] and (ev is None or ev.query())
+        return w.full if idle else w.lane
+
+    def _process(self, w, stage_idx, halves, job, i, payload, lane):
+        """One clip through this worker's halves on `lane`."""
+        guard = self._build_lock if not w.warm else contextlib.nullcontext()
+        with guard, torch.inference_mode(), self._on(w, lane) as st:
+            if "front" in halves:
+                payload = self._front(w, st, job, i)
+            if "back" in halves:
+                payload = self._back(w, st, job, payload)
+        w.warm = True
+        return payload
+
+    def _run_worker(self, w, stage_idx, halves, job):
+        gate = job["gate"]
+        v = w.view
+        if "front" in halves:
+            v.sample_xts_from_x0 = self._gated_sample(v, gate)
+        last_stage = stage_idx == len(self.stages) - 1
         try:
-            with self._stream_ctx(self.streams[k]):
-                while True:
+            while True:
+                if stage_idx == 0:
                     with job["lock"]:
                         i = job["next"]
                         job["next"] += 1
                     if i >= len(job["items"]) or job["error"] is not None:
                         return
-                    view._clip_index, view._clip_seed, view._clip_drew = i, job["seeds"][i], False
-                    t0 = time.perf_counter()
-                    try:
-                        guard = self._build_lock if not self._warm[k] else contextlib.nullcontext()
-                        with guard:
-                            item = job["items"][i]
-                            with torch.inference_mode():
-                                x0 = job["prepare"](view, item) if job["prepare"] is not None else item
-                            job["out"][i] = edit_clip(view, x0, *job["args"], **job["kwargs"])
-                            self._warm[k] = True
-                    except BaseException as e:                      # noqa: BLE001 -- reported by edit_clips
-                        with job["lock"]:
-                            if job["error"] is None:
-                                job["error"] = (i, e)
-                        gate.done(i, failed=not view._clip_drew)
+                    payload = None
+                else:
+                    got = job["queues"][stage_idx].get()
+                    if got is _STOP or job["error"] is not None:
                         return
-                    self.stats.append(dict(clip=i, lane=k, start=t0 - job["t0"], end=time.perf_counter() - job["t0"]))
+                    i, payload = got
+                v._clip_index, v._clip_seed, v._clip_drew = i, job["seeds"][i], False
+                with job["lock"]:
+                    job["busy"][stage_idx] += 1
+                t0 = time.perf_counter()
+                try:
+                    payload = self._process(w, stage_idx, halves, job, i, payload, self._pick_lane(w, job, stage_idx))
+                except BaseException as e:                          # noqa: BLE001 -- reported by edit_clips
+                    with job["lock"]:
+                        if job["error"] is None:
+                            job["error"] = (i, e)
+                    if "front" in halves:
+                        gate.done(i, failed=not v._clip_drew)
+                    return
+                finally:
+                    with job["lock"]:
+                        job["busy"][stage_idx] -= 1
+                job["times"].append(dict(clip=i, stage=w.stage, worker=w.k, start=t0 - job["t0"],
+                                         end=time.perf_counter() - job["t0"]))
+                if last_stage:
+                    job["out"][i] = payload
+                else:
+                    job["front_event"] = payload["done"]
+                    job["queues"][stage_idx + 1].put((i, payload))
         finally:
-            view.__dict__.pop("sample_xts_from_x0", None)
+            v.__dict__.pop("sample_xts_from_x0", None)
 
-    def warm_up(self, item, *args, **kwargs):
-        """Build every lane's engines, loop plans and hipGraphs by running one clip per lane, one lane at a time (engine
-        construction folds shared weights lazily and is not meant to race).  Same arguments as edit_clips, one item."""
-        for k in range(self.n_lanes):
-            if not self._warm[k]:
-                only = ClipPipeline.__new__(ClipPipeline)
-                only.__dict__.update(self.__dict__)
-                only.n_lanes, only.views, only.streams, only._warm = 1, [self.views[k]], [self.streams[k]], [False]
-                only.edit_clips([item], *args, **kwargs)
-                self._warm[k] = True
+    def _run_stage(self, stage_idx, job):
+        """Start the stage's workers, wait for them, then tell the next stage that nothing more will come."""
+        _, halves, ws = self.stages[stage_idx]
+        ths = [threading.Thread(target=self._run_worker, args=(w, stage_idx, halves, job),
+                                name=f"aed-{w.stage}-{w.k}", daemon=True) for w in ws]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        with job["lock"]:
+            job["stage_done"][stage_idx] = True
+        if stage_idx + 1 < len(self.stages):
+            for _ in self.stages[stage_idx + 1][2]:
+                job["queues"][stage_idx + 1].put(_STOP)
 
     # ------------------------------------------------------------------ driver
-    def edit_clips(self, items, source_prompt, target_prompt, target_neg_prompt, cfg_src, cfg_tar, T, tstart, eta=1.0,
-                   schedule="sequential", timestep_group=8, prepare=None, seeds=None, **edit_clip_kwargs):
-        """Edit `items` -- mels [1,1,T_mel,64], or anything `prepare(lane_view, item)` turns into one (e.g. waveforms
-        through `lane_view.get_fn_STFT()`: the STFT engine then belongs to the lane like every other buffer) -- with
-        main_run.edit_clip's arguments; clips are handed to the lanes in order.  seeds[i]: `torch.manual_seed(seeds[i])` right before clip i's noise draws (a serial loop's
-        per-clip seeding); None = the global generator simply continues from clip to clip.
-        Returns [(edited waveform, original-vocoded waveform, edited latent)] in input order."""
-        if schedule != "sequential" and self.n_lanes > 1:
-            # the timestep-batched inversion holds ~0.75 GB of activations per U-Net batch row (150 GB at batch 200):
-            # one engine per lane does not fit, and lanes at batch 2 already fill the chip
-            raise ValueError("lanes run the reference's step order (schedule='sequential'); the timestep-batched "
-                             "inversion is the single-clip latency mode of main_run.edit_clip")
+    def _job(self, items, seeds, prepare, a):
         K = len(items)
         seeds = [None] * K if seeds is None else list(seeds)
         if len(seeds) != K:
             raise ValueError("one seed (or None) per clip")
-        job = dict(items=list(items), seeds=seeds, prepare=prepare, out=[None] * K, next=0, lock=threading.Lock(),
-                   error=None, gate=_DrawGate(), t0=time.perf_counter(),
-                   args=(source_prompt, target_prompt, target_neg_prompt, cfg_src, cfg_tar, T, tstart),
-                   kwargs=dict(eta=eta, schedule=schedule, timestep_group=timestep_group, **edit_clip_kwargs))
-        self.stats = []
-        threads = [threading.Thread(target=self._lane, args=(k, job), name=f"aed-lane-{k}", daemon=True)
-                   for k in range(min(self.n_lanes, max(K, 1)))]
-        for th in threads:
+        return dict(items=list(items), seeds=seeds, prepare=prepare, a=a, out=[None] * K, next=0,
+                    lock=threading.Lock(), error=None, gate=_DrawGate(), t0=time.perf_counter(), times=[],
+                    queues=[queue.Queue() for _ in self.stages], busy=[0] * len(self.stages),
+                    stage_done=[False] * len(self.stages), front_event=None)
+
+    def _args(self, source_prompt, target_prompt, target_neg_prompt, cfg_src, cfg_tar, T, tstart, eta):
+        if len(source_prompt) != 1 or len(target_prompt) != 1:
+            raise ValueError("ClipPipeline edits with one source and one target prompt")
+        if isinstance(tstart, (list, tuple)):
+            tstart = tstart[0]
+        batched = self.plan == "partition"
+        return dict(src=source_prompt, tgt=target_prompt, neg=target_neg_prompt, cfg_src=cfg_src, cfg_tar=cfg_tar, T=T,
+                    tstart=int(tstart), eta=eta, schedule="batched" if batched else "sequential",
+                    group=self.timestep_group if batched else 1)
+
+    def edit_clips(self, items, source_prompt, target_prompt, target_neg_prompt, cfg_src, cfg_tar, T, tstart, eta=1.0,
+                   prepare=None, seeds=None):
+        """Edit `items` -- mels [1,1,T_mel,64], or anything `prepare(lane_view, item)` turns into one (e.g. waveforms
+        through `lane_view.get_fn_STFT()`: the STFT engine then belongs to the lane like every other buffer) -- with
+        main_run.edit_clip's arguments; clips enter the pipeline in order.  seeds[i]: `torch.manual_seed(seeds[i])` right
+        before clip i's noise draws (a serial loop's per-clip seeding); None = the global generator simply continues
+        from clip to clip.  Returns [(edited waveform, original-vocoded waveform, edited latent)] in input order."""
+        job = self._job(items, seeds, prepare, self._args(source_prompt, target_prompt, target_neg_prompt, cfg_src,
+                                                          cfg_tar, T, tstart, eta))
+        self.stats, self._times = [], job["times"]
+        if not job["items"]:
+            return []
+        ths = [threading.Thread(target=self._run_stage, args=(s, job), daemon=True) for s in range(len(self.stages))]
+        for th in ths:
             th.start()
-        for th in threads:
+        for th in ths:
             th.join()
         if job["error"] is not None:
             i, e = job["error"]
             raise RuntimeError(f"clip {i} failed in the clip pipeline: {e!r}") from e
         return job["out"]
 
-    def lane_report(self):
-        """Per-lane clip counts and the clip latency (host wall, start of its lane slot -> waveforms on the host)."""
-        if not self.stats:
-            return {}
-        lat = [s["end"] - s["start"] for s in self.stats]
-        per_lane = {}
-        for s in self.stats:
-            per_lane[s["lane"]] = per_lane.get(s["lane"], 0) + 1
-        return dict(lanes=self.n_lanes, clips=len(self.stats), clips_per_lane=[per_lane.get(k, 0) for k in range(self.n_lanes)],
-                    clip_latency_ms_avg=1e3 * sum(lat) / len(lat), clip_latency_ms_max=1e3 * max(lat))
+    def warm_up(self, item, source_prompt, target_prompt, target_neg_prompt, cfg_src, cfg_tar, T, tstart, eta=1.0,
+                prepare=None, seeds=None):
+        """Build every worker's engines, loop plans and hipGraphs by pushing one clip through each worker, one worker at a
+        time, on the caller's thread (engine construction folds shared weights lazily and is not meant to race)."""
+        a = self._args(source_prompt, target_prompt, target_neg_prompt, cfg_src, cfg_tar, T, tstart, eta)
+        seed = None if seeds is None else seeds[0]
+        payload = None
+        for s, (_, halves, ws) in enumerate(self.stages):
+            outs = []
+            for w in ws:
+                job = self._job([item], [seed], prepare, a)
+                v = w.view
+                v._clip_index, v._clip_seed, v._clip_drew = 0, seed, False
+                if "front" in halves:
+                    v.sample_xts_from_x0 = self._gated_sample(v, job["gate"])
+                try:
+                    outs.append(self._process(w, s, halves, job, 0, payload, w.lane))
+                finally:
+                    v.__dict__.pop("sample_xts_from_x0", None)
+            payload = outs[0]
+        self.stats = []
+
+    # ------------------------------------------------------------------ reporting
+    def report(self):
+        """Plan, partitions, and the average device time of each stage's jobs (HIP events on the lane streams) split by
+        where they ran (their CU partition, or the whole chip during fill / drain)."""
+        if self.model.device.type == "cuda":
+            torch.cuda.synchronize(self.model.device)
+        acc = {}
+        for stage, k, where, t0, t1 in self.stats:
+            acc.setdefault(f"{stage}_{where}", []).append(t0.elapsed_time(t1))
+        lat = {}
+        for t in getattr(self, "_times", []):
+            d = lat.setdefault(t["clip"], [t["start"], t["end"]])
+            d[0], d[1] = min(d[0], t["start"]), max(d[1], t["end"])
+        lats = [1e3 * (b - a) for a, b in lat.values()]
+        return dict(plan=self.plan, launch=self.launch, clips_in_flight=self.clips_in_flight, total_cus=self.total,
+                    edit_cus=self.edit_cus, edit_lanes=self.edit_lanes,
+                    inversion_cus=None if self.edit_cus is None else self.total - self.edit_cus,
+                    device_ms={k: dict(n=len(v), avg=sum(v) / len(v)) for k, v in acc.items()},
+                    clip_latency_ms_avg=(sum(lats) / len(lats)) if lats else None,
+                    clip_latency_ms_max=max(lats) if lats else None)
+
+    def close(self):
+        for w in self.workers:
+            for ps in (w.lane, w.full):
+                if ps is not None and ps is not self.full:
+                    ps.close()
+        self.full.close()

@@ -8,11 +8,12 @@ seeded-random weights of the real architecture (no checkpoints exist offline), s
 One "step" = one whole clip.  N GPUs = N independent clips per step (weak scaling, no data-path
 collective; weights broadcast once from rank 0 over RCCL, edited latents gathered to rank 0).
 
-Headline schedule (round 3): every clip runs the reference's own step order (200 + 100 sequential steps, one U-Net
-forward at batch 2 each); `--lanes L` clips are in flight per GPU on L HIP streams (pipeline.ClipPipeline) because one
-such chain is latency-bound and leaves ~3/4 of the chip idle.  Reported beside it: the same clips one at a time in the
-reference order (`value_reference_order`), one at a time with the timestep-batched inversion (`value_single_clip_batched`,
-the round-1/2 headline), parity against the CPU oracle (`parity`), and BASELINE configs 3/4/5 as sub-benchmarks.
+Headline schedule (round 3, `--plan partition`): a two-stage clip pipeline (pipeline.ClipPipeline) -- while clip i runs
+its latency-bound 100-step edit loop on one CU partition, clip i+1 runs its timestep-batched forward inversion on the
+complementary partition (hardware queues with disjoint CU masks); every clip's own launches, order and values are those of
+the clip edited alone.  Reported beside it: the same clips one at a time in the reference order (`value_reference_order`),
+one at a time with the timestep-batched inversion (`value_single_clip_batched`, the round-1/2 headline), parity against the
+CPU oracle (`parity`), and BASELINE configs 3/4/5 as sub-benchmarks.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
@@ -196,11 +197,15 @@ def main():
     ap.add_argument("--clips-per-gpu", type=int, default=1,
                     help="independent clips edited together per step and GPU (BASELINE configs[2]: 8; default: the "
                          "headline configs[1] shape, 1)")
-    ap.add_argument("--lanes", type=int, default=4,
-                    help="clips in flight per GPU, each on its own HIP stream in the reference's step order "
-                         "(pipeline.ClipPipeline); 1 = one clip at a time")
-    ap.add_argument("--lane-launch", default="eager", choices=["eager", "graph"],
-                    help="how a lane issues one diffusion step: launch by launch from C++ (default) or one hipGraphLaunch")
+    ap.add_argument("--plan", default="partition", choices=["partition", "lanes", "serial"],
+                    help="how clips share the GPU (pipeline.ClipPipeline): 'partition' = clip i's edit loop and clip i+1's "
+                         "inversion on disjoint CU partitions; 'lanes' = --lanes whole clips at once in the reference's "
+                         "step order; 'serial' = one clip at a time")
+    ap.add_argument("--edit-cus", type=int, default=128, help="partition plan: CUs of the edit-loop partition")
+    ap.add_argument("--edit-lanes", type=int, default=1, help="partition plan: edit loops sharing the edit partition")
+    ap.add_argument("--lanes", type=int, default=3, help="lanes plan: clips in flight")
+    ap.add_argument("--lane-launch", default="graph", choices=["eager", "graph"],
+                    help="how a pipeline worker issues one diffusion step: one hipGraphLaunch (default) or launch by launch")
     ap.add_argument("--serial-clips", type=int, default=3,
                     help="clips timed in each of the two one-clip-at-a-time legs reported beside the headline")
     ap.add_argument("--no-extras", action="store_true",
@@ -319,14 +324,14 @@ def main():
             lat.append(step(2000 + i, waves[i]))
         return finish(t0, lat)
 
-    LANES = max(1, args.lanes) if NC == 1 else 1
+    PLAN = args.plan if NC == 1 else "serial"
     pipe = None
 
-    def timed_lanes(K, W):
-        """K clips through L lanes (pipeline.ClipPipeline): every clip in the reference's step order on its own HIP
-        stream.  Same waveforms and per-clip seeds as `timed`, so the serial legs below edit the same clips."""
+    def timed_pipeline(K, W):
+        """K clips through pipeline.ClipPipeline.  Same waveforms and per-clip seeds as `timed`, so the serial legs below
+        edit the same clips."""
         edit_args = (src, tgt, neg, [3.0], [12.0], args.T, args.tstart)
-        pipe.warm_up(clip_wave(rank * 100000 + 99), *edit_args, prepare=wave_to_mel, seeds=[999])   # builds the lanes
+        pipe.warm_up(clip_wave(rank * 100000 + 99), *edit_args, prepare=wave_to_mel, seeds=[999])   # builds the workers
         if W:
             pipe.edit_clips([clip_wave(rank * 100000 + i) for i in range(W)], *edit_args, prepare=wave_to_mel,
                             seeds=[1000 + i for i in range(W)])
@@ -339,14 +344,19 @@ def main():
 
     log(f"model ready ({m.weights_source}); timing {args.steps} clip(s) after {args.warmup} warm-up")
     extra = {}
-    if LANES > 1:
-        # Headline: L clips in flight, each in the reference's step order (no timestep regrouping).
+    if PLAN != "serial":
         from audioeditingcode_amd.pipeline import ClipPipeline
-        pipe = ClipPipeline(m, lanes=LANES, launch=args.lane_launch)
-        dt, gathered = timed_lanes(args.steps, args.warmup)
-        headline = f"reference step order, {LANES} clips in flight per GPU on {LANES} HIP streams"
-        extra["pipeline"] = pipe.lane_report()
-        log(f"{LANES} lanes: {dt / args.steps:.3f} s/clip")
+        pipe = ClipPipeline(m, plan=PLAN, edit_cus=args.edit_cus, edit_lanes=args.edit_lanes, lanes=args.lanes,
+                            launch=args.lane_launch, timestep_group=args.group)
+        dt, gathered = timed_pipeline(args.steps, args.warmup)
+        extra["pipeline"] = pipe.report()
+        if PLAN == "partition":
+            headline = (f"{pipe.clips_in_flight} clips in flight per GPU: clip i+1's forward inversion ({args.group} timesteps "
+                        f"per U-Net call) on {pipe.total - pipe.edit_cus} CUs beside clip i's edit loop "
+                        f"({pipe.edit_lanes} lane(s)) on {pipe.edit_cus} CUs")
+        else:
+            headline = f"reference step order, {pipe.clips_in_flight} whole clips in flight per GPU on as many HIP streams"
+        log(f"{PLAN} pipeline: {dt / args.steps:.3f} s/clip  {json.dumps(extra['pipeline'])}")
     else:
         dt, gathered = timed(args.schedule, args.steps, args.warmup)
         headline = (f"one clip at a time; forward inversion schedule: {args.schedule}"
@@ -358,15 +368,15 @@ def main():
     # Every one of the 600 sample-forwards of a clip is computed in all three schedules; batched only regroups the
     # inversion's U-Net calls (the edit-friendly inversion draws all x_t independently from x_0, models.py:67-83).
     if not args.no_batched:
-        n_ser = max(1, min(args.serial_clips, args.steps)) if LANES > 1 else args.steps
+        n_ser = max(1, min(args.serial_clips, args.steps)) if PLAN != "serial" else args.steps
         legs = {}
         for sched_name in ("sequential", "batched"):
-            if LANES == 1 and sched_name == args.schedule:
+            if PLAN == "serial" and sched_name == args.schedule:
                 legs[sched_name] = (dt, gathered)
                 continue
             legs[sched_name] = timed(sched_name, n_ser, 1)
             log(f"one clip at a time, {sched_name}: {legs[sched_name][0] / n_ser:.3f} s/clip ({n_ser} clips)")
-        n_of = {k: (args.steps if (LANES == 1 and k == args.schedule) else n_ser) for k in legs}
+        n_of = {k: (args.steps if (PLAN == "serial" and k == args.schedule) else n_ser) for k in legs}
         extra["value_reference_order"] = world * NC * n_of["sequential"] / legs["sequential"][0]
         extra["ms_per_step_reference_order"] = 1e3 * legs["sequential"][0] / n_of["sequential"]
         extra["value_single_clip_batched"] = world * NC * n_of["batched"] / legs["batched"][0]
@@ -381,14 +391,17 @@ def main():
             # the batched inversion lets x_t enter the U-Net before its ~1-ulp numerical fix: anything beyond the loop
             # tolerance of the GPU parity tests (5e-3) means the regrouping broke the arithmetic
             assert dev_l2 < 5e-3, f"timestep-batched inversion deviates from the reference order by {dev_l2:.3e}"
-            if LANES > 1:
-                # lanes only interleave clips on the GPU: each clip's result must be the serial reference-order result
-                n_cmp = min(n_of["sequential"], args.steps)
-                same = all(torch.equal(a[:n_cmp], b[:n_cmp]) for a, b in zip(gathered, legs["sequential"][1]))
-                worst = max(float((a[:n_cmp] - b[:n_cmp]).abs().max()) for a, b in zip(gathered, legs["sequential"][1]))
-                extra["lanes_vs_serial"] = dict(clips_compared=n_cmp, bit_identical=same, max_abs_diff=worst)
-                log(f"lanes vs one-at-a-time (reference order), {n_cmp} clips: bit-identical={same}, max |diff| {worst:.2e}")
-                assert same, f"clip results changed under the lane pipeline (max |diff| {worst:.3e})"
+            if PLAN != "serial":
+                # the pipeline only changes WHERE and WHEN a clip's launches run: each clip must equal the same clip edited
+                # alone with the same inversion schedule (partition: batched; lanes: reference order), bit for bit
+                twin = "batched" if PLAN == "partition" else "sequential"
+                n_cmp = min(n_of[twin], args.steps)
+                same = all(torch.equal(a[:n_cmp], b[:n_cmp]) for a, b in zip(gathered, legs[twin][1]))
+                worst = max(float((a[:n_cmp] - b[:n_cmp]).abs().max()) for a, b in zip(gathered, legs[twin][1]))
+                extra["pipeline_vs_one_clip_at_a_time"] = dict(schedule=twin, clips_compared=n_cmp, bit_identical=same,
+                                                               max_abs_diff=worst)
+                log(f"pipeline vs one clip at a time ({twin}), {n_cmp} clips: bit-identical={same}, max |diff| {worst:.2e}")
+                assert same, f"clip results changed under the clip pipeline (max |diff| {worst:.3e})"
 
     # ---- where one clip's time goes when it has the GPU to itself (single-clip latency mode: batched inversion)
     phases = None
@@ -409,7 +422,7 @@ def main():
     # fewer than the reference formulation it replaces) -- the algorithmic count is used for the path-level figures only.
     roof = None
     if rank == 0:
-        roof = roofline_leg(m, pipe, args, NC, LANES, dt)
+        roof = roofline_leg(m, pipe, args, NC, dt)
     parity = None
     if rank == 0 and world == 1 and not args.no_extras:
         try:
@@ -438,6 +451,7 @@ def main():
         torch.cuda.empty_cache()
         subs = sub_benchmarks(time.time() - T_START)
 
+    pipe_info = extra.get("pipeline")
     if rank == 0:
         out = {"metric": "edited-clips/sec (200-step inv+edit, 10 s@16 kHz)", "value": value,
                "unit": "edited-clips/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -446,8 +460,9 @@ def main():
                "config": {"workload": f"AudioLDM2 ({args.model_id}, 346.9M-param U-Net, seeded-random weights) "
                                       f"text-based edit, T={args.T}, tstart={args.tstart}, cfg 3/12, {NC} clip(s) of 10 s "
                                       f"@16 kHz per U-Net batch; {headline}",
-                          "clips_per_gpu_per_step": NC, "clips_in_flight_per_gpu": LANES * NC,
-                          "parallelism": f"clip-dp{world}" + (f" x {LANES} lanes" if LANES > 1 else ""),
+                          "clips_per_gpu_per_step": NC,
+                          "clips_in_flight_per_gpu": NC if pipe_info is None else pipe_info["clips_in_flight"],
+                          "parallelism": f"clip-dp{world}" + ("" if pipe_info is None else f" x {PLAN} pipeline"),
                           "weights_broadcast_s": t_bcast if world > 1 else 0.0,
                           "gathered_latents": None if gathered is None else [list(g.shape) for g in gathered][:2]},
                "roofline": roof, "cpu_baseline": base, "parity": parity, "phases_ms_one_clip_alone": phases}
@@ -457,83 +472,81 @@ def main():
         print(json.dumps(out))
 
 
-def roofline_leg(m, pipe, args, NC, LANES, dt):
-    """See the comment at the call site."""
+def roofline_leg(m, pipe, args, NC, dt):
+    """See the comment at the call site.  One group per U-Net batch shape of the headline schedule: the engines that run
+    it, the streams (CU partitions) they run on, and the fraction of the chip those streams may use."""
     dev = m.device
-    views = pipe.views if pipe is not None else [m]
-    streams = pipe.streams if pipe is not None else [torch.cuda.Stream(device=dev)]
-    detail, tot_fl, tot_ms, n_launch, per_clip_flops, per_clip_exec = {}, 0.0, 0.0, 0, 0.0, 0.0
-    # U-Net calls of one clip in the headline schedule, by batch size
-    if LANES > 1 or args.schedule == "sequential":
-        calls = {2 * NC: args.T + args.tstart}
+    if pipe is None or pipe.plan == "lanes":
+        sequential = pipe is not None or args.schedule == "sequential"
+        G = 1
+        if not sequential:
+            G = max(1, min(args.group // NC if NC > 1 else args.group, args.T))
+            while args.T % G:
+                G -= 1
+        calls = {2 * NC: args.T + args.tstart} if sequential else {2 * NC: args.tstart, 2 * G * NC: args.T // G}
+        if pipe is None:
+            st = torch.cuda.Stream(device=dev)
+            groups = {B: dict(n=n, members=[(m, st)], cu_frac=1.0) for B, n in calls.items()}
+        else:
+            groups = {B: dict(n=n, members=[(w.view, w.lane.stream) for w in pipe.workers], cu_frac=1.0)
+                      for B, n in calls.items()}
     else:
-        G = max(1, min(args.group // NC if NC > 1 else args.group, args.T))
+        G = max(1, min(args.group, args.T))
         while args.T % G:
             G -= 1
-        calls = {2 * NC: args.tstart, 2 * G * NC: args.T // G}
-    for B, n_calls in calls.items():
+        front = [w for w in pipe.workers if w.stage == "front"]
+        back = [w for w in pipe.workers if w.stage == "back"]
+        groups = {2: dict(n=args.tstart, members=[(w.view, w.lane.stream) for w in back],
+                          cu_frac=pipe.edit_cus / pipe.total),
+                  2 * G: dict(n=args.T // G, members=[(w.view, w.lane.stream) for w in front],
+                              cu_frac=(pipe.total - pipe.edit_cus) / pipe.total)}
+    detail, tot_fl, tot_ms, n_launch, per_clip_flops, per_clip_exec = {}, 0.0, 0.0, 0, 0.0, 0.0
+    for B, g in groups.items():
         engs = []
-        for v in views:
+        for v, st in g["members"]:
             ed = v.editor(256, 16)
             cand = [e for (b, _, _), e in ed._unets.items() if b == B]
             if cand:
-                engs.append((ed, cand[0]))
+                engs.append((ed, cand[0], st))
         if not engs:
             continue
-        if len(engs) != len(views):
-            engs = engs[:1]
-        for ed, _ in engs:
+        for ed, _, _ in engs:
             for pl in ed._plans.values():
                 pl["state"].zero_()        # the time-embedding op indexes the timestep table with the loop counter
         torch.cuda.synchronize()
-        ed0, eng0 = engs[0]
-        with torch.cuda.stream(streams[0]):
+        _, eng0, st0 = engs[0]
+        with torch.cuda.stream(st0):
             eng0.tape.profile()
             ms = [eng0.tape.profile() for _ in range(3)]
             ms = [sum(x) / len(ms) for x in zip(*ms)]
-        graphs = []
-        for (ed, eng), st in zip(engs, streams):
+        for _, eng, st in engs:
             with torch.cuda.stream(st):
                 eng.tape.capture()
                 for _ in range(2):
                     eng.tape.replay()
-            graphs.append((eng, st))
         torch.cuda.synchronize()
         n_rep = 40 if B <= 8 else 5
-        evs = []
-        for eng, st in graphs:
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            with torch.cuda.stream(st):
-                ev0.record(st)
-                for _ in range(n_rep):
+        t0 = time.perf_counter()
+        for k in range(n_rep):                      # round-robin: every member's queue fills at the same rate
+            for _, eng, st in engs:
+                with torch.cuda.stream(st):
                     eng.tape.replay()
-                ev1.record(st)
-            evs.append((ev0, ev1))
         torch.cuda.synchronize()
-        lane_ms = max(a.elapsed_time(b) for a, b in evs) / n_rep
-        fwd_ms = lane_ms / len(graphs)                                   # chip time per forward
-        # one lane alone, for reference
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        with torch.cuda.stream(streams[0]):
-            ev0.record(streams[0])
-            for _ in range(n_rep):
-                eng0.tape.replay()
-            ev1.record(streams[0])
-        ev1.synchronize()
-        alone_ms = ev0.elapsed_time(ev1) / n_rep
-        conv = [(mt["exec_flops"], mt["flops"], t) for mt, t in zip(eng0.tape.meta, ms) if mt["code"] == 1]
-        fl = sum(f for f, _, _ in conv)
-        share = sum(t for _, _, t in conv) / sum(ms)
+        group_ms = 1e3 * (time.perf_counter() - t0) / n_rep          # wall time in which EVERY member did one forward
+        fwd_ms = group_ms / len(engs) * g["cu_frac"]                 # chip-equivalent time of one forward
+        conv = [(mt["exec_flops"], t) for mt, t in zip(eng0.tape.meta, ms) if mt["code"] == 1]
+        fl = sum(f for f, _ in conv)
+        share = sum(t for _, t in conv) / sum(ms)
         tt = fwd_ms * share
-        tot_fl += n_calls * fl
-        tot_ms += n_calls * tt
-        n_launch += n_calls * len(conv)
-        per_clip_flops += n_calls * eng0.tape.flops
-        per_clip_exec += n_calls * eng0.tape.exec_flops
+        tot_fl += g["n"] * fl
+        tot_ms += g["n"] * tt
+        n_launch += g["n"] * len(conv)
+        per_clip_flops += g["n"] * eng0.tape.flops
+        per_clip_exec += g["n"] * eng0.tape.exec_flops
         detail[f"unet_batch_{B}"] = dict(
-            forwards_per_clip=n_calls, launches_per_forward=len(eng0.tape.ops), conv_gemm_launches=len(conv),
-            lanes_measured=len(graphs), forward_ms_per_lane=lane_ms, forward_ms_chip_time=fwd_ms,
-            forward_ms_one_lane_alone=alone_ms, forward_tflops_algorithmic=eng0.tape.flops / (fwd_ms * 1e-3) / 1e12,
+            forwards_per_clip=g["n"], launches_per_forward=len(eng0.tape.ops), conv_gemm_launches=len(conv),
+            streams_measured=len(engs), cu_fraction_of_chip=g["cu_frac"], forward_ms_on_its_streams=group_ms,
+            forward_ms_chip_equivalent=fwd_ms, forward_tflops_algorithmic=eng0.tape.flops / (fwd_ms * 1e-3) / 1e12,
             forward_tflops_executed=eng0.tape.exec_flops / (fwd_ms * 1e-3) / 1e12, conv_gemm_share_of_forward=share,
             conv_gemm_tflops_executed=fl / (tt * 1e-3) / 1e12, eager_event_per_op_sum_ms=sum(ms),
             algorithmic_gflop=eng0.tape.flops / 1e9, executed_gflop=eng0.tape.exec_flops / 1e9)
@@ -565,10 +578,11 @@ def roofline_leg(m, pipe, args, NC, LANES, dt):
     return dict(bound="mfma", achieved=achieved, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
                 frac=achieved / PEAK_FP32_MFMA_TFLOPS, traffic=traffic, traffic_note=traffic_note,
                 kernel="conv_gemm_kernel + lin_gemm_kernel (every conv / Linear of the U-Net forwards of one clip)",
-                method="executed flops (2MNK per launch) / [chip time per forward x GEMM share]; chip time per forward = "
-                       "HIP events around graph replays running on all lanes at once / lanes; share from one eager "
-                       "event-per-op pass (see comment in bench.py)",
-                launches_per_clip=n_launch, avg_launch_us_chip_time=1e3 * tot_ms / n_launch, by_batch=detail,
+                method="executed flops (2MNK per launch) / [chip-equivalent time per forward x GEMM share].  Chip-equivalent "
+                       "time = wall time (host clock around hipGraph replays, every stream of the batch shape's pipeline "
+                       "stage replaying at once on its own CU partition) / streams x the partition's fraction of the "
+                       "chip's CUs; GEMM share from one eager pass with a HIP-event pair per op",
+                launches_per_clip=n_launch, avg_launch_us_chip_equivalent=1e3 * tot_ms / n_launch, by_batch=detail,
                 csrc_hash=csrc_hash(), clip_unet_tflop=per_clip_flops / 1e12, clip_unet_tflop_executed=per_clip_exec / 1e12,
                 path_tflops=per_clip_flops / s_clip / 1e12, path_frac=per_clip_flops / s_clip / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                 path_frac_executed=per_clip_exec / s_clip / 1e12 / PEAK_FP32_MFMA_TFLOPS)

@@ -105,15 +105,24 @@ def _stream_ctx(s):
     yield
 
 
+class _W:
+    def __init__(self, stage, view):
+        self.stage, self.view = stage, view
+        self.lane = type("Lane", (), dict(stream=_Stream()))()
+
+
 class _Pipe:
-    """pipeline.ClipPipeline stand-in: L lane views / streams, clips handed back in order."""
+    """pipeline.ClipPipeline stand-in: workers with lane views / streams, clips handed back in order."""
     made = []
 
-    def __init__(self, model, lanes=None, launch="eager"):
-        assert launch in ("eager", "graph")
-        self.n_lanes = lanes
-        self.views = [model.lane_view() for _ in range(lanes)]
-        self.streams = [_Stream() for _ in range(lanes)]
+    def __init__(self, model, plan="partition", edit_cus=None, edit_lanes=1, lanes=None, launch="graph", timestep_group=100):
+        assert launch in ("eager", "graph") and plan in ("partition", "lanes")
+        self.plan, self.total, self.edit_cus, self.edit_lanes = plan, 256, edit_cus, edit_lanes
+        if plan == "partition":
+            self.workers = [_W("front", _Model([2 * timestep_group]))] + [_W("back", _Model([2])) for _ in range(edit_lanes)]
+        else:
+            self.workers = [_W("clip", _Model([2])) for _ in range(lanes)]
+        self.clips_in_flight = len(self.workers)
         self.calls = []
         _Pipe.made.append(self)
 
@@ -122,12 +131,12 @@ class _Pipe:
 
     def edit_clips(self, items, *a, prepare=None, seeds=None, **k):
         assert len(seeds) == len(items) and prepare is not None
-        assert prepare(self.views[0], items[0]).shape == (1, 1, 1024, 64)          # prepare(lane view, item) -> mel
+        assert prepare(self.workers[0].view, items[0]).shape == (1, 1, 1024, 64)          # prepare(lane view, item) -> mel
         self.calls.append(("edit_clips", len(items)))
         return [(None, None, torch.ones(1, 8, 256, 16)) for _ in items]
 
-    def lane_report(self):
-        return dict(lanes=self.n_lanes, clips=self.calls[-1][1])
+    def report(self):
+        return dict(plan=self.plan, clips_in_flight=self.clips_in_flight, edit_cus=self.edit_cus)
 
 
 def _run(argv, batches, extra_patches=()):
@@ -160,33 +169,43 @@ REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
 
 
 def test_default_line_has_the_contract_keys():
-    """Default mode: L lanes in the reference order + the two one-clip-at-a-time legs + roofline measured on all lanes."""
+    """Default mode: the two-stage partition pipeline + the two one-clip-at-a-time legs + the roofline measured per stage."""
     _Pipe.made.clear()
-    out = _run(["--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-extras", "--group", "20", "--lanes", "3",
-                "--serial-clips", "2"], [2, 40])
+    out = _run(["--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-extras", "--group", "20", "--edit-cus", "96",
+                "--edit-lanes", "2", "--serial-clips", "2"], [2, 40])
     assert all(k in out for k in REQUIRED)
     assert out["n_gpus"] == 1 and out["steps"] == 4 and out["warmup"] == 2 and out["scaling"] == "weak"
     assert out["dtype"] == "f32" and out["vs_baseline"] is None and out["higher_is_better"] is True
     assert "workload" in out["config"] and out["config"]["clips_per_gpu_per_step"] == 1
-    assert out["config"]["clips_in_flight_per_gpu"] == 3 and "reference step order" in out["config"]["workload"]
-    assert _Pipe.made[0].calls == [("warm_up", 1), ("edit_clips", 2), ("edit_clips", 4)]      # lanes built, W warm, K timed
+    assert out["config"]["clips_in_flight_per_gpu"] == 3 and "96 CUs" in out["config"]["workload"]
+    assert _Pipe.made[0].calls == [("warm_up", 1), ("edit_clips", 2), ("edit_clips", 4)]      # workers built, W warm, K timed
     r = out["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
-    assert set(r["by_batch"]) == {"unet_batch_2"} and r["by_batch"]["unet_batch_2"]["lanes_measured"] == 3
-    assert r["launches_per_clip"] == 300 * 1                        # T + tstart forwards at batch 2, one GEMM op each
+    assert set(r["by_batch"]) == {"unet_batch_2", "unet_batch_40"}
+    assert r["by_batch"]["unet_batch_2"]["streams_measured"] == 2 and r["by_batch"]["unet_batch_40"]["streams_measured"] == 1
+    assert abs(r["by_batch"]["unet_batch_2"]["cu_fraction_of_chip"] - 96 / 256) < 1e-12
+    assert r["launches_per_clip"] == 100 * 1 + 10 * 1               # tstart edit forwards + T/G inversion forwards
     assert r["traffic"] is None or r["traffic"] > 0
     assert r["path_frac_executed"] < r["path_frac"]
     assert "value_reference_order" in out and "value_single_clip_batched" in out and out["serial_legs_clips"] == 2
     assert out["schedule_deviation_rel_l2"] == 0.0          # the mocked edit returns the same latent for every schedule
-    assert out["lanes_vs_serial"] == dict(clips_compared=2, bit_identical=True, max_abs_diff=0.0)
+    assert out["pipeline_vs_one_clip_at_a_time"] == dict(schedule="batched", clips_compared=2, bit_identical=True,
+                                                         max_abs_diff=0.0)
 
 
-def test_single_lane_schedules_and_multi_clip_mode():
-    out = _run(["--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--lanes", "1", "--schedule",
+def test_lanes_plan_single_clip_schedules_and_multi_clip_mode():
+    _Pipe.made.clear()
+    out = _run(["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--plan", "lanes", "--lanes", "3",
+                "--group", "20"], [2, 40])
+    assert out["config"]["clips_in_flight_per_gpu"] == 3 and "reference step order" in out["config"]["workload"]
+    assert set(out["roofline"]["by_batch"]) == {"unet_batch_2"} and out["roofline"]["launches_per_clip"] == 300
+    assert out["roofline"]["by_batch"]["unet_batch_2"]["streams_measured"] == 3
+    assert out["pipeline_vs_one_clip_at_a_time"]["schedule"] == "sequential"
+    out = _run(["--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--plan", "serial", "--schedule",
                 "sequential", "--group", "20"], [2, 40])
     assert "value_single_clip_batched" in out and "reference order" in out["config"]["workload"]
     assert out["roofline"]["launches_per_clip"] == 300
-    out = _run(["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--lanes", "1", "--group", "20"],
+    out = _run(["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--plan", "serial", "--group", "20"],
                [2, 40])
     assert set(out["roofline"]["by_batch"]) == {"unet_batch_2", "unet_batch_40"}
     assert out["roofline"]["launches_per_clip"] == 100 * 1 + 10 * 1         # tstart edit forwards + T/G inversion forwards
@@ -205,7 +224,7 @@ def test_extras_are_reported_and_never_fatal():
             return subprocess.CompletedProcess(cmd, 3, stdout="", stderr="boom")
         return subprocess.CompletedProcess(cmd, 0, stdout='noise\n{"metric": "m", "value": 2.5, "unit": "u", "roofline": '
                                                           '{"frac": 0.5, "by_batch": {}}}\n', stderr="")
-    out = _run(["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--lanes", "2", "--group", "20"], [2, 40],
+    out = _run(["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--group", "20"], [2, 40],
                extra_patches=[mock.patch.object(bench, "parity_leg", lambda *a, **k: dict(latent_rel_l2=1e-4)),
                               mock.patch.object(bench.subprocess, "run", fake_run)])
     assert out["parity"] == dict(latent_rel_l2=1e-4)

@@ -24,27 +24,55 @@ def _serial(m, mels, T, tstart, seeds):
     return out
 
 
-@pytest.mark.parametrize("launch", ["eager", "graph"])
-def test_lanes_are_bit_identical_to_one_clip_at_a_time_tiny(launch):
-    """5 clips through 3 lanes == the same clips one at a time (same per-clip seeds): latents and waveforms bit for bit,
-    with the waveform -> mel step running on the lanes too (every lane owns its STFT engine); a second pass without
-    per-clip seeds consumes the global generator in clip order.  Both ways a lane can issue a step (launch by launch /
-    one hipGraphLaunch)."""
-    T, tstart = 10, 6
+def _serial_b(m, mels, T, tstart, seeds, group):
+    out = []
+    for x0, s in zip(mels, seeds):
+        torch.manual_seed(s)
+        out.append(edit_clip(m, x0, *ARGS, T, tstart, schedule="batched", timestep_group=group))
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("edit_lanes,launch", [(1, "graph"), (2, "graph"), (1, "eager")])
+def test_partition_pipeline_is_bit_identical_to_one_clip_at_a_time_tiny(edit_lanes, launch):
+    """5 clips through the two-stage partition pipeline (inversion of clip i+1 on CUs [96,256) beside the edit loop of clip
+    i on CUs [0,96)) == the same clips one at a time with the same (batched) inversion schedule and per-clip seeds:
+    latents and waveforms bit for bit; the waveform -> mel step runs on the front lane's own STFT engine."""
+    T, tstart, G = 10, 6, 5
     m = models.load_model("tiny/audioldm2", DEV, T, seed=0)
     wavs = [synthetic_clip(seconds=1.25, seed=7 + i) for i in range(5)]
     to_mel = lambda view, wav: load_audio((wav, 16000), view.get_fn_STFT(), device=DEV, stft=True)[0]     # noqa: E731
     mels = [to_mel(m, w) for w in wavs]
     seeds = [40 + i for i in range(5)]
-    ref = _serial(m, mels, T, tstart, seeds)
-    pipe = ClipPipeline(m, lanes=3, launch=launch)
+    ref = _serial_b(m, mels, T, tstart, seeds, G)
+    pipe = ClipPipeline(m, plan="partition", edit_cus=96, edit_lanes=edit_lanes, launch=launch, timestep_group=G)
     pipe.warm_up(wavs[0], *ARGS, T, tstart, prepare=to_mel)
     got = pipe.edit_clips(wavs, *ARGS, T, tstart, seeds=seeds, prepare=to_mel)
     for i, ((a, o, w), (a2, o2, w2)) in enumerate(zip(got, ref)):
         assert torch.equal(w, w2), (i, float((w - w2).abs().max()))
         assert torch.equal(a, a2) and torch.equal(o, o2), i
-    rep = pipe.lane_report()
-    assert rep["clips"] == 5 and sum(rep["clips_per_lane"]) == 5
+    rep = pipe.report()
+    assert rep["plan"] == "partition" and rep["edit_cus"] == 96 and rep["clips_in_flight"] == 1 + edit_lanes
+    assert rep["device_ms"]["front_chip"]["n"] >= 1               # the first inversion ran on the whole chip (fill)
+    assert sum(v["n"] for k, v in rep["device_ms"].items() if k.startswith("back")) == 5
+    pipe.close()
+
+
+def test_lanes_plan_is_bit_identical_to_one_clip_at_a_time_tiny():
+    """Whole clips in the reference's step order on 3 streams == one at a time, with per-clip seeds and with one
+    continuous global generator stream (the lanes draw in clip order)."""
+    T, tstart = 10, 6
+    m = models.load_model("tiny/audioldm2", DEV, T, seed=0)
+    mels = [load_audio((synthetic_clip(seconds=1.25, seed=7 + i), 16000), m.get_fn_STFT(), device=DEV, stft=True)[0]
+            for i in range(5)]
+    seeds = [40 + i for i in range(5)]
+    ref = _serial(m, mels, T, tstart, seeds)
+    pipe = ClipPipeline(m, plan="lanes", lanes=3)
+    pipe.warm_up(mels[0], *ARGS, T, tstart)
+    got = pipe.edit_clips(mels, *ARGS, T, tstart, seeds=seeds)
+    for i, ((a, o, w), (a2, o2, w2)) in enumerate(zip(got, ref)):
+        assert torch.equal(w, w2), (i, float((w - w2).abs().max()))
+        assert torch.equal(a, a2) and torch.equal(o, o2), i
     torch.manual_seed(99)
     ref2 = [edit_clip(m, x0, *ARGS, T, tstart) for x0 in mels]
     torch.manual_seed(99)
@@ -53,23 +81,23 @@ def test_lanes_are_bit_identical_to_one_clip_at_a_time_tiny(launch):
         assert torch.equal(w, w2) and torch.equal(a, a2)
 
 
-def test_lanes_full_size_audioldm2_bit_identical_and_finite():
-    """BASELINE config 2's model (346.9 M-parameter U-Net, latent 8x256x16) at a short schedule: 4 clips on 4 lanes ==
-    one at a time, bit for bit; every lane was used."""
-    T, tstart = 6, 4
+def test_partition_pipeline_full_size_audioldm2_bit_identical_and_finite():
+    """BASELINE config 2's model (346.9 M-parameter U-Net, latent 8x256x16) at a short schedule: 4 clips through the
+    partition pipeline (128 | 128 CUs) == one at a time, bit for bit."""
+    T, tstart, G = 8, 4, 4
     m = models.load_model("cvssp/audioldm2", DEV, T, allow_synthetic=True)
     mels = [load_audio((synthetic_clip(seconds=10.0, seed=3 + i), 16000), m.get_fn_STFT(), device=DEV, stft=True)[0]
             for i in range(4)]
     seeds = [7, 8, 9, 10]
-    ref = _serial(m, mels, T, tstart, seeds)
-    pipe = ClipPipeline(m, lanes=4)
+    ref = _serial_b(m, mels, T, tstart, seeds, G)
+    pipe = ClipPipeline(m, plan="partition", edit_cus=128, timestep_group=G)
     pipe.warm_up(mels[0], *ARGS, T, tstart)
     got = pipe.edit_clips(mels, *ARGS, T, tstart, seeds=seeds)
     for i, ((a, o, w), (a2, o2, w2)) in enumerate(zip(got, ref)):
         assert torch.isfinite(w).all() and torch.isfinite(a).all()
         assert torch.equal(w, w2), (i, float((w - w2).abs().max()))
         assert torch.equal(a, a2), i
-    assert pipe.lane_report()["clips_per_lane"] == [1, 1, 1, 1]
+    pipe.close()
 
 
 def test_cu_masked_streams_census_and_results():

@@ -306,16 +306,57 @@ def test_prefetched_noise_equals_inline_draws(cpu_stack):
     assert torch.equal(m._take_prefetched_noise(w_odd.shape, T), noise_inline)
 
 
-def test_clip_pipeline_lanes_equal_serial_edit_clip(cpu_stack, monkeypatch):
-    """pipeline.ClipPipeline (L clips in flight, one lane = stream + lane view + host thread) on the CPU stack: every
-    clip's outputs are bit-identical to main_run.edit_clip run clip by clip -- with per-clip seeds and with one continuous
-    global generator stream (the lanes draw in clip order) --, lane views share the frozen weights and own their engines,
-    an error in one clip surfaces, and the batched inversion is refused with more than one lane."""
+def _fake_hip_for_pipeline(monkeypatch, log):
     import contextlib
 
     from audioeditingcode_amd.pipeline import ClipPipeline
-    monkeypatch.setattr(ClipPipeline, "_new_stream", staticmethod(lambda device: None))
+
+    class FakeStream:
+        def __init__(self, name):
+            self.name = name
+
+        def wait_event(self, ev):
+            log.append(("wait", self.name, ev.tag))
+
+    class FakeLane:
+        def __init__(self, device, cus=None, total=None, priority=0):
+            self.total = 256 if total is None else total
+            self.cus = None if cus is None else list(cus)
+            self.stream = FakeStream("chip" if cus is None else f"cus{self.cus[0]}-{self.cus[-1]}")
+
+        def close(self):
+            pass
+
+    class FakeEvent:
+        n = 0
+
+        def __init__(self, enable_timing=False):
+            FakeEvent.n += 1
+            self.tag = FakeEvent.n
+
+        def record(self, st):
+            log.append(("record", st.name, self.tag))
+
+        def query(self):
+            return True
+
+        def elapsed_time(self, other):
+            return 0.0
+    monkeypatch.setattr(ClipPipeline, "lane_type", FakeLane)
+    monkeypatch.setattr(ClipPipeline, "event_type", FakeEvent)
     monkeypatch.setattr(ClipPipeline, "_stream_ctx", staticmethod(lambda st: contextlib.nullcontext()))
+    return ClipPipeline
+
+
+def test_clip_pipeline_plans_equal_serial_edit_clip(cpu_stack, monkeypatch):
+    """pipeline.ClipPipeline on the CPU stack with recording stand-ins for the HIP streams / events.
+    Partition plan (front stage: inversion on CUs [96,256) | back stage: edit loop on CUs [0,96), 2 edit lanes): every
+    clip equals main_run.edit_clip with the batched inversion, bit for bit, with per-clip seeds; fill runs on the whole
+    chip, steady state on the partitions; every back half waits for its clip's front-half event.  Lanes plan (whole clips
+    in the reference order, 2 lanes): equals the sequential edit_clip with per-clip seeds and with one continuous global
+    generator stream.  Lane views share the frozen weights and own their engines; a failing clip surfaces."""
+    log = []
+    ClipPipeline = _fake_hip_for_pipeline(monkeypatch, log)
     threads = torch.get_num_threads()
     torch.set_num_threads(2)                    # lane threads x intra-op threads would oversubscribe the test box
     try:
@@ -324,39 +365,62 @@ def test_clip_pipeline_lanes_equal_serial_edit_clip(cpu_stack, monkeypatch):
         mels = [load_audio((synthetic_clip(seconds=0.32, seed=7 + i), 16000), m.get_fn_STFT(), device="cpu", stft=True)[0]
                 for i in range(3)]
         args = (["a dog barking"], ["a cat meowing"], [""], [3.0], [12.0], T, tstart)
-        serial_seeded = []
+        serial_b, serial_s = [], []
         for i, x0 in enumerate(mels):
             torch.manual_seed(40 + i)
-            serial_seeded.append(edit_clip(m, x0, *args))
-        torch.manual_seed(99)
-        serial_stream = [edit_clip(m, x0, *args) for x0 in mels[:2]]
-        after = torch.randn(2)
-        pipe = ClipPipeline(m, lanes=2)
-        v0, v1 = pipe.views
+            serial_b.append(edit_clip(m, x0, *args, schedule="batched", timestep_group=3))
+            torch.manual_seed(40 + i)
+            serial_s.append(edit_clip(m, x0, *args))
+        # ---- partition plan
+        seen = []
+        ed_cls = type(m.editor(mels[0].shape[-2] // 4, mels[0].shape[-1] // 4))
+        orig_invert, orig_edit = ed_cls.invert, ed_cls.edit
+        monkeypatch.setattr(ed_cls, "invert", lambda self, *a, **k: (seen.append(("invert", self.loop_stream().name)),
+                                                                     orig_invert(self, *a, **k))[1])
+        monkeypatch.setattr(ed_cls, "edit", lambda self, *a, **k: (seen.append(("edit", self.loop_stream().name)),
+                                                                   orig_edit(self, *a, **k))[1])
+        pipe = ClipPipeline(m, plan="partition", edit_cus=96, edit_lanes=2, timestep_group=3)
+        assert [w.stage for w in pipe.workers] == ["front", "back", "back"] and pipe.clips_in_flight == 3
+        assert pipe.workers[0].lane.cus == list(range(96, 256)) and pipe.workers[1].lane.cus == list(range(96))
+        v0, v1 = pipe.workers[0].view, pipe.workers[1].view
         assert v0.unet_weights is m.unet_weights and v0.state_dicts is m.state_dicts and v0.model is m.model
         assert v0._engines is not m._engines and v0._editors is not v1._editors
         pipe.warm_up(mels[0], *args)
-        assert all(pipe._warm) and all(len(v._editors) == 1 for v in pipe.views)
+        assert all(w.warm for w in pipe.workers)
+        seen.clear()
+        log.clear()
         got = pipe.edit_clips(mels, *args, seeds=[40, 41, 42])
-        for (a, o, w), (a2, o2, w2) in zip(got, serial_seeded):
+        for (a, o, w), (a2, o2, w2) in zip(got, serial_b):
             assert torch.equal(a, a2) and torch.equal(o, o2) and torch.equal(w, w2)
-        rep = pipe.lane_report()
-        assert rep["clips"] == 3 and sum(rep["clips_per_lane"]) == 3 and rep["lanes"] == 2
-        torch.manual_seed(99)
-        got = pipe.edit_clips(mels[:2], *args)              # no per-clip seeds: one global stream, consumed in clip order
-        for (a, o, w), (a2, o2, w2) in zip(got, serial_stream):
-            assert torch.equal(a, a2) and torch.equal(w, w2)
-        assert torch.equal(torch.randn(2), after)           # and the generator ends where the serial loop leaves it
-        assert "sample_xts_from_x0" not in v0.__dict__      # the gated draw hook is removed again
-        with pytest.raises(ValueError):
-            pipe.edit_clips(mels, *args, schedule="batched", timestep_group=2)
+        inv = [s for k, s in seen if k == "invert"]
+        assert inv[0] == "chip" and set(inv[1:]) <= {"cus96-255", "chip"} and len(inv) == 3      # fill on the whole chip
+        assert sum(1 for k, s in seen if k == "edit") == 3
+        assert sum(1 for e in log if e[0] == "wait") >= 3                  # each back half waited for its front half
+        rep = pipe.report()
+        assert rep["plan"] == "partition" and rep["edit_cus"] == 96 and rep["inversion_cus"] == 160
+        assert m.__dict__.get("_lane_stream") is None and m.editor(8, 8).lane_stream is None      # outside the pipeline
+        monkeypatch.setattr(ed_cls, "invert", orig_invert)
+        monkeypatch.setattr(ed_cls, "edit", orig_edit)
         with pytest.raises(RuntimeError, match="clip 0 failed"):
             pipe.edit_clips([torch.zeros(1, 1, 3, 5), mels[1]], *args)
-        one = ClipPipeline(m, lanes=1)
-        torch.manual_seed(40)
-        a, o, w = one.edit_clips([mels[0]], *args, schedule="batched", timestep_group=3)[0]
-        torch.manual_seed(40)
-        a2, o2, w2 = edit_clip(m, mels[0], *args, schedule="batched", timestep_group=3)
-        assert torch.equal(w, w2) and torch.equal(a, a2)
+        with pytest.raises(ValueError):
+            ClipPipeline(m, plan="partition", edit_cus=256)
+        with pytest.raises(ValueError):
+            ClipPipeline(m, plan="partition", timestep_group=1)
+        # ---- lanes plan (reference order)
+        lanes = ClipPipeline(m, plan="lanes", lanes=2)
+        lanes.warm_up(mels[0], *args)
+        got = lanes.edit_clips(mels, *args, seeds=[40, 41, 42])
+        for (a, o, w), (a2, o2, w2) in zip(got, serial_s):
+            assert torch.equal(a, a2) and torch.equal(o, o2) and torch.equal(w, w2)
+        torch.manual_seed(99)
+        ref = [edit_clip(m, x0, *args) for x0 in mels[:2]]
+        after = torch.randn(2)
+        torch.manual_seed(99)
+        got = lanes.edit_clips(mels[:2], *args)             # no per-clip seeds: one global stream, consumed in clip order
+        for (a, o, w), (a2, o2, w2) in zip(got, ref):
+            assert torch.equal(a, a2) and torch.equal(w, w2)
+        assert torch.equal(torch.randn(2), after)           # and the generator ends where the serial loop leaves it
+        assert "sample_xts_from_x0" not in lanes.workers[0].view.__dict__      # the gated draw hook is removed again
     finally:
         torch.set_num_threads(threads)

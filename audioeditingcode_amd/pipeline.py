@@ -102,7 +102,12 @@ class ClipPipeline:
         self.model, self.plan, self.launch = model, plan, launch
         self.timestep_group = int(timestep_group)
         dev = model.device
-        Lane = self.lane_type
+        acquire = getattr(self.lane_type, "acquire", None)
+
+        def Lane(device, cus=None, total=None, index=0):           # process-lifetime streams (streams.PartitionStream)
+            if acquire is not None:
+                return acquire(device, cus=cus, total=total, index=index)
+            return self.lane_type(device, cus=cus, total=total)
         self.full = Lane(dev)                                      # the whole chip
         self.total = self.full.total
         self.stages = []                                           # [(name, halves, [workers])]
@@ -116,15 +121,15 @@ class ClipPipeline:
             self.edit_lanes = max(1, int(edit_lanes))
             front = [_Worker("front", 0, self._view(), Lane(dev, cus=range(self.edit_cus, self.total), total=self.total),
                              self.full)]
-            back = [_Worker("back", k, self._view(), Lane(dev, cus=range(self.edit_cus), total=self.total), Lane(dev))
-                    for k in range(self.edit_lanes)]
+            back = [_Worker("back", k, self._view(), Lane(dev, cus=range(self.edit_cus), total=self.total, index=k),
+                            Lane(dev, index=1 + k)) for k in range(self.edit_lanes)]
             self.stages = [("front", ("front",), front), ("back", ("back",), back)]
         else:
             n = DEFAULT_LANES if lanes is None else int(lanes)
             if n < 1:
                 raise ValueError("lanes must be >= 1")
             self.edit_cus, self.edit_lanes = None, n
-            self.stages = [("clip", ("front", "back"), [_Worker("clip", k, self._view(), Lane(dev), None)
+            self.stages = [("clip", ("front", "back"), [_Worker("clip", k, self._view(), Lane(dev, index=1 + k), None)
                                                         for k in range(n)])]
         self._build_lock = threading.Lock()     # an un-warmed worker builds engines (and lazily folds shared weights)
         self.stats = []
@@ -205,11 +210,23 @@ class ClipPipeline:
         w_edit, _ = inversion_reverse_process(v, xT=f["wts"], tstart=torch.tensor([tstart], dtype=torch.int),
                                               etas=a["eta"], prompts=a["tgt"], neg_prompts=a["neg"],
                                               cfg_scales=a["cfg_tar"], zs=f["zs"][:tstart])
-        x0_dec = v.vae_decode(w_edit)
-        if x0_dec.dim() < 4:
-            x0_dec = x0_dec[None]
-        audio = v.decode_to_mel(x0_dec)                  # CPU tensors: the host blocks here until this clip is done
-        orig = v.decode_to_mel(f["x0"])
+        # VAE decode + vocoder are throughput kernels (45 ms on 256 CUs, 170 ms on a 128-CU partition): they run unmasked,
+        # sharing the inversion's CUs for those milliseconds, while this worker's edit partition is idle anyway
+        cs = st
+        if w.full is not None and w.full.stream is not st:
+            cs = w.full.stream
+            edited = self.event_type()
+            edited.record(st)
+            cs.wait_event(edited)
+            for t in (w_edit, f["x0"]):
+                if t.is_cuda:
+                    t.record_stream(cs)
+        with self._stream_ctx(cs):
+            x0_dec = v.vae_decode(w_edit)
+            if x0_dec.dim() < 4:
+                x0_dec = x0_dec[None]
+            audio = v.decode_to_mel(x0_dec)              # CPU tensors: the host blocks here until this clip is done
+            orig = v.decode_to_mel(f["x0"])
         return audio, orig, w_edit
 
     # ------------------------------------------------------------------ workers
@@ -384,8 +401,9 @@ class ClipPipeline:
                     clip_latency_ms_max=max(lats) if lats else None)
 
     def close(self):
+        """Drain every lane (the streams themselves are process-lifetime objects, see streams.PartitionStream)."""
         for w in self.workers:
             for ps in (w.lane, w.full):
-                if ps is not None and ps is not self.full:
+                if ps is not None:
                     ps.close()
         self.full.close()

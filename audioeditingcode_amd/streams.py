@@ -30,7 +30,23 @@ def cu_mask_words(bits, total):
 
 class PartitionStream:
     """A hipStream_t owned by libaed.so (masked to the CU bits `cus`, or unmasked with a priority when `cus` is None),
-    exposed as a torch stream so torch allocations, events and `wait_stream` work on it."""
+    exposed as a torch stream so torch allocations, events and `wait_stream` work on it.
+
+    Lifetime: `acquire()` hands out process-lifetime streams from a cache keyed by (device, CU set, index) and nothing
+    destroys them.  torch's caching allocator tags blocks with the stream they were allocated / `record_stream`-ed on and
+    touches that stream again when such a block is freed; a hipStreamDestroy in between (from an explicit close or a
+    garbage-collected wrapper) crashed the GPU test process once.  A handful of queues per process is all a pipeline
+    needs, so they are simply kept."""
+    _cache = {}
+
+    @classmethod
+    def acquire(cls, device, cus=None, total=None, index=0):
+        dev = torch.device(device)
+        key = (str(dev), None if cus is None else tuple(sorted(set(int(b) for b in cus))), int(index))
+        ps = cls._cache.get(key)
+        if ps is None:
+            ps = cls._cache[key] = cls(dev, cus=cus, total=total)
+        return ps
 
     def __init__(self, device, cus=None, total=None, priority=0):
         self.device = torch.device(device)
@@ -64,14 +80,11 @@ class PartitionStream:
         v = out.cpu().view(n_blocks, 2).tolist()
         return sorted({(x & 0xF, (h >> 13) & 0x7, (h >> 12) & 1, (h >> 8) & 0xF) for h, x in v})
 
-    def close(self):
+    def close(self, destroy=False):
+        """Drain the stream.  `destroy=True` also calls aed_stream_destroy -- only safe when no tensor was ever allocated
+        or `record_stream`-ed on it (see the class docstring); cached streams are never destroyed."""
         if self.handle is not None:
             self.stream.synchronize()
-            L.check(L.lib().aed_stream_destroy(self.handle), "aed_stream_destroy")
-            self.handle = None
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
+            if destroy and self not in self._cache.values():
+                L.check(L.lib().aed_stream_destroy(self.handle), "aed_stream_destroy")
+                self.handle = None

@@ -510,9 +510,10 @@ def roofline_leg(m, pipe, args, NC, dt):
                 engs.append((ed, cand[0], st))
         if not engs:
             continue
-        for ed, _, _ in engs:
-            for pl in ed._plans.values():
-                pl["state"].zero_()        # the time-embedding op indexes the timestep table with the loop counter
+        with torch.inference_mode():
+            for ed, _, _ in engs:
+                for pl in ed._plans.values():
+                    pl["state"].zero_()    # the time-embedding op indexes the timestep table with the loop counter
         torch.cuda.synchronize()
         _, eng0, st0 = engs[0]
         with torch.cuda.stream(st0):

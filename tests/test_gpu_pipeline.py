@@ -105,16 +105,17 @@ def test_cu_masked_streams_census_and_results():
     the hardware's XCC / SE / CU ids); a hipGraph replayed on a masked stream gives the same values as on a plain one."""
     from audioeditingcode_amd import configs, weights
     from audioeditingcode_amd.unet import UNetEngine
-    full = PartitionStream(DEV)
+    full = PartitionStream.acquire(DEV)
+    assert PartitionStream.acquire(DEV) is full                   # process-lifetime streams come from a cache
     total = full.total
     assert len(full.census()) == total
-    low = PartitionStream(DEV, cus=range(64))
+    low = PartitionStream.acquire(DEV, cus=range(64))
     cs = low.census()
     per_xcc = {}
     for x, se, sh, cu in cs:
         per_xcc[x] = per_xcc.get(x, 0) + 1
     assert len(cs) == 64 and sorted(per_xcc) == list(range(8)) and set(per_xcc.values()) == {8}, per_xcc
-    rest = PartitionStream(DEV, cus=range(64, total))
+    rest = PartitionStream.acquire(DEV, cus=range(64, total))
     assert len(rest.census()) == total - 64 and not set(rest.census()) & set(cs)
     fam = configs.tiny_family("audioldm2")
     sd = weights.random_state_dict(weights.unet_param_shapes(fam["unet"]), seed=0)

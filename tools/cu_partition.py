@@ -82,7 +82,7 @@ for name, bits in (("low64", range(64)), ("high192", range(64, 256)), ("low8", r
     ps = PartitionStream(dev, cus=bits)
     out["census_" + name] = census_summary(ps)
     print(f"census {name}:", out["census_" + name], flush=True)
-    ps.close()
+    ps.close(destroy=True)
 
 # ---------------------------------------------------------------- (a) alone, masked
 out["alone_b2_ms"], out["alone_big_ms"] = {}, {}
@@ -94,12 +94,12 @@ for c in (256, 192, 160, 128, 96, 64, 48, 32):
     ps = PartitionStream(dev, cus=range(c))
     out["alone_b2_ms"][str(c)] = alone(e2, ps, 30)
     print(f"alone batch 2 on {c} CUs: {out['alone_b2_ms'][str(c)]:.3f} ms", flush=True)
-    ps.close()
+    ps.close(destroy=True)
 for c in (256, 224, 192, 160, 128):
     ps = PartitionStream(dev, cus=range(TOTAL - c, TOTAL))
     out["alone_big_ms"][str(c)] = alone(eb, ps, 2)
     print(f"alone batch {2 * G} on {c} CUs: {out['alone_big_ms'][str(c)]:.2f} ms", flush=True)
-    ps.close()
+    ps.close(destroy=True)
 assert torch.equal(ref2, e2.eps) and torch.equal(refb, eb.eps), "masked replays changed the results"
 
 
@@ -137,20 +137,20 @@ def together(ps_edit, ps_inv, label):
 for x in (48, 64, 80, 96, 128):
     pe, pi = PartitionStream(dev, cus=range(x)), PartitionStream(dev, cus=range(x, TOTAL))
     together(pe, pi, f"edit{x}_inv{TOTAL - x}")
-    pe.close()
-    pi.close()
+    pe.close(destroy=True)
+    pi.close(destroy=True)
 for nx in (2, 3):     # whole XCDs for the edit loop (its own L2s)
     pe = PartitionStream(dev, cus=[b for b in range(TOTAL) if b % 8 < nx])
     pi = PartitionStream(dev, cus=[b for b in range(TOTAL) if b % 8 >= nx])
     together(pe, pi, f"edit_{nx}xcd_inv_{8 - nx}xcd")
-    pe.close()
-    pi.close()
+    pe.close(destroy=True)
+    pi.close(destroy=True)
 # overlapping masks: the edit stream may use every CU, the inversion leaves x free
 for x in (64, 96):
     pe, pi = PartitionStream(dev, cus=range(TOTAL)), PartitionStream(dev, cus=range(x, TOTAL))
     together(pe, pi, f"edit256_inv{TOTAL - x}")
-    pe.close()
-    pi.close()
+    pe.close(destroy=True)
+    pi.close(destroy=True)
 hi, lo = PartitionStream(dev, priority=-1), PartitionStream(dev, priority=0)
 together(hi, lo, "unmasked_edit_high_priority")
 together(un, lo, "unmasked_equal_priority")

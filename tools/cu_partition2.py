@@ -79,7 +79,7 @@ for c in (256, 128, 64):
     rows = [dict(name=m["name"], code=m["code"], ms=t, flops=m["flops"], i=list(op.i))
             for m, t, op in zip(lanes[0].tape.meta, ms, lanes[0].tape.ops)]
     json.dump(rows, open(f"gpurun_out/perop_B2_cus{c}.json", "w"))
-    ps.close()
+    ps.close(destroy=True)
 
 
 # ---------------------------------------------------------------- (2) k edit lanes on one partition || inversion
@@ -117,7 +117,7 @@ def lanes_case(x, k, with_inv=True, n_edit=60):
           + ("" if inv_ms is None else f"; inversion fwd {inv_ms:.1f} ms -> {(200 // G) * inv_ms:.0f} ms per clip")
           + f"; steady state {r['steady_state_ms_per_clip']:.0f} ms per clip", flush=True)
     for p in pes + ([pi] if pi is not None else []):
-        p.close()
+        p.close(destroy=True)
 
 
 for k in (1, 2, 3, 4):

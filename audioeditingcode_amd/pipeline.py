@@ -35,6 +35,7 @@ import time
 
 import torch
 
+from . import tape as tape_mod
 from .ddm_inversion.inversion_utils import inversion_forward_process, inversion_reverse_process
 from .streams import PartitionStream
 
@@ -80,8 +81,9 @@ class _Worker:
     """One lane: a lane view of the model, its stream on the stage's CU partition and (partition plan) an unmasked
     stream for fill / drain."""
 
-    def __init__(self, stage, k, view, lane, full):
+    def __init__(self, stage, k, view, lane, full, regime=None):
         self.stage, self.k, self.view, self.lane, self.full = stage, k, view, lane, full
+        self.regime = regime        # tile regime its engines are built under (tape.tile_regime)
         self.last = None            # (event, stream) of this worker's previous job
         self.warm = False
 
@@ -121,8 +123,11 @@ class ClipPipeline:
             self.edit_lanes = max(1, int(edit_lanes))
             front = [_Worker("front", 0, self._view(), Lane(dev, cus=range(self.edit_cus, self.total), total=self.total),
                              self.full)]
+            # the edit loop's batch-2 kernels on half the chip are no longer purely latency-bound: their tiles come from
+            # the sweep taken on a 128-CU stream (tile_table_cus128.py) when the partition is about that size
+            regime = "cus128" if (96 <= self.edit_cus <= 160 and "cus128" in tape_mod.REGIME_TABLES) else None
             back = [_Worker("back", k, self._view(), Lane(dev, cus=range(self.edit_cus), total=self.total, index=k),
-                            Lane(dev, index=1 + k)) for k in range(self.edit_lanes)]
+                            Lane(dev, index=1 + k), regime=regime) for k in range(self.edit_lanes)]
             self.stages = [("front", ("front",), front), ("back", ("back",), back)]
         else:
             n = DEFAULT_LANES if lanes is None else int(lanes)
@@ -175,14 +180,45 @@ class ClipPipeline:
         self.stats.append((w.stage, w.k, "chip" if (lane is w.full and w.full is not None) else "lane", t0, t1))
 
     # ------------------------------------------------------------------ the two halves of main_run.edit_clip
-    def _gated_sample(self, view, gate):
-        """view.sample_xts_from_x0 with the clip's T draws taken from the global generator in clip order."""
+    @staticmethod
+    def _draw(gate, index, seed, shape, T):
+        """Clip `index`'s T noise maps from the global CPU generator, when its turn comes (models.py:76-81 order)."""
+        with gate.turn(index, seed):
+            noise = torch.stack([torch.randn(shape, dtype=torch.float32) for _ in range(T)])
+        return noise.pin_memory() if torch.cuda.is_available() else noise
+
+    def _gated_sample(self, view, job):
+        """view.sample_xts_from_x0 with the clip's T draws taken from the global generator in clip order.  When every clip
+        has the same shape, clip i+1's maps (40 ms of single-threaded CPU RNG for a 10 s clip) are drawn on a helper thread
+        right after clip i's -- same generator, same order -- so they are ready when clip i+1 reaches this point."""
+        gate = job["gate"]
+
         def sample_xts_from_x0(x0, num_inference_steps=50):
             ed = view.editor(x0.shape[-2], x0.shape[-1])
             x = x0.reshape(1, *x0.shape[-3:])
-            with gate.turn(view._clip_index, view._clip_seed):
-                noise = torch.stack([torch.randn(x.shape, dtype=torch.float32) for _ in range(num_inference_steps)])
+            i, T = view._clip_index, int(num_inference_steps)
+            pre = job["prefetch"].pop(i, None)
+            if pre is not None:
+                pre["thread"].join()
+                if "error" in pre:
+                    raise pre["error"]
+                assert pre["shape"] == tuple(x.shape) and pre["T"] == T, "uniform clips were promised (prefetched noise)"
+                noise = pre["noise"]
+            else:
+                noise = self._draw(gate, i, view._clip_seed, tuple(x.shape), T)
             view._clip_drew = True
+            nxt = i + 1
+            if job["uniform"] and nxt < len(job["items"]) and nxt not in job["prefetch"]:
+                box = dict(shape=tuple(x.shape), T=T)
+
+                def work():
+                    try:
+                        box["noise"] = self._draw(gate, nxt, job["seeds"][nxt], box["shape"], T)
+                    except BaseException as e:                      # noqa: BLE001 -- re-raised by the consumer
+                        box["error"] = e
+                box["thread"] = threading.Thread(target=work, name=f"aed-noise-{nxt}", daemon=True)
+                job["prefetch"][nxt] = box
+                box["thread"].start()
             return ed.sample_xts(x, noise=noise)[:, 0]
         return sample_xts_from_x0
 
@@ -245,7 +281,7 @@ class ClipPipeline:
     def _process(self, w, stage_idx, halves, job, i, payload, lane):
         """One clip through this worker's halves on `lane`."""
         guard = self._build_lock if not w.warm else contextlib.nullcontext()
-        with guard, torch.inference_mode(), self._on(w, lane) as st:
+        with guard, tape_mod.tile_regime(w.regime), torch.inference_mode(), self._on(w, lane) as st:
             if "front" in halves:
                 payload = self._front(w, st, job, i)
             if "back" in halves:
@@ -257,7 +293,7 @@ class ClipPipeline:
         gate = job["gate"]
         v = w.view
         if "front" in halves:
-            v.sample_xts_from_x0 = self._gated_sample(v, gate)
+            v.sample_xts_from_x0 = self._gated_sample(v, job)
         last_stage = stage_idx == len(self.stages) - 1
         try:
             while True:
@@ -320,8 +356,13 @@ class ClipPipeline:
         seeds = [None] * K if seeds is None else list(seeds)
         if len(seeds) != K:
             raise ValueError("one seed (or None) per clip")
-        return dict(items=list(items), seeds=seeds, prepare=prepare, a=a, out=[None] * K, next=0,
-                    lock=threading.Lock(), error=None, gate=_DrawGate(), t0=time.perf_counter(), times=[],
+        shapes = {tuple(it.shape) if torch.is_tensor(it) else None for it in items}
+        # noise prefetch needs the next clip's latent shape before that clip is prepared: only when all clips look alike,
+        # and only with ONE front worker (several would each need the draw order of clips they have not reached yet)
+        n_front = sum(len(ws) for _, halves, ws in self.stages if "front" in halves)
+        uniform = len(shapes) == 1 and None not in shapes and n_front == 1
+        return dict(items=list(items), seeds=seeds, prepare=prepare, a=a, out=[None] * K, next=0, uniform=uniform,
+                    prefetch={}, lock=threading.Lock(), error=None, gate=_DrawGate(), t0=time.perf_counter(), times=[],
                     queues=[queue.Queue() for _ in self.stages], busy=[0] * len(self.stages),
                     stage_done=[False] * len(self.stages), front_event=None)
 
@@ -371,7 +412,7 @@ class ClipPipeline:
                 v = w.view
                 v._clip_index, v._clip_seed, v._clip_drew = 0, seed, False
                 if "front" in halves:
-                    v.sample_xts_from_x0 = self._gated_sample(v, job["gate"])
+                    v.sample_xts_from_x0 = self._gated_sample(v, job)
                 try:
                     outs.append(self._process(w, s, halves, job, 0, payload, w.lane))
                 finally:

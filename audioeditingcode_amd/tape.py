@@ -8,8 +8,10 @@ kernel, and the whole tape can be captured in a hipGraph (`Tape.capture()` / `Ta
 Layout convention: activations are channels-last fp32 -- a [B,H,W,C] feature map IS the
 [B*H*W, C] token matrix; convolution weights are [Cout, KH, KW, Cin].
 """
+import contextlib
 import ctypes
 import math
+import threading
 
 import torch
 
@@ -37,6 +39,29 @@ try:                                   # the Stable Audio DiT's shapes, swept se
     TILE_TABLE.update(_DIT_TABLE)
 except ImportError:
     pass
+
+# Tile tables of other REGIMES than "one chain alone on the whole chip".  The regime is a property of the thread that builds an
+# engine (a pipeline worker builds its lane's engines on its own thread): `with tile_regime("cus128"): ...`.
+REGIME_TABLES = {}
+try:
+    from .tile_table_cus128 import TILE_TABLE as _CUS128
+    REGIME_TABLES["cus128"] = dict(_CUS128)
+except ImportError:                                              # pragma: no cover
+    pass
+_regime = threading.local()
+
+
+@contextlib.contextmanager
+def tile_regime(name):
+    """Engines built inside this context (on this thread) take their tile choices from REGIME_TABLES[name] first."""
+    if name is not None and name not in REGIME_TABLES:
+        raise KeyError(f"unknown tile regime {name!r} (have {sorted(REGIME_TABLES)})")
+    prev = getattr(_regime, "name", None)
+    _regime.name = name
+    try:
+        yield
+    finally:
+        _regime.name = prev
 
 
 class Tape:
@@ -106,9 +131,12 @@ class Tape:
         tile the fewer tiles there are and the longer K is; otherwise the LDS-staged kernel with the largest tile that
         still fills the chip, split-K (deterministic slab reduce) when the grid would be < 1 block per CU."""
         cus = cus or CU_COUNT
-        hit = TILE_TABLE.get((M, N, K, int(bool(geglu))))
-        if hit is not None and (lin_ok or hit[0] < 10):
-            return hit
+        key = (M, N, K, int(bool(geglu)))
+        reg = getattr(_regime, "name", None)
+        for table in ((REGIME_TABLES[reg],) if reg else ()) + (TILE_TABLE,):
+            hit = table.get(key)
+            if hit is not None and (lin_ok or hit[0] < 10):
+                return hit
 
         def blocks(bm, bn):
             return math.ceil(M / bm) * math.ceil(N / bn)

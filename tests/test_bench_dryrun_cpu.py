@@ -178,7 +178,8 @@ def test_default_line_has_the_contract_keys():
     assert out["dtype"] == "f32" and out["vs_baseline"] is None and out["higher_is_better"] is True
     assert "workload" in out["config"] and out["config"]["clips_per_gpu_per_step"] == 1
     assert out["config"]["clips_in_flight_per_gpu"] == 3 and "96 CUs" in out["config"]["workload"]
-    assert _Pipe.made[0].calls == [("warm_up", 1), ("edit_clips", 2), ("edit_clips", 4)]      # workers built, W warm, K timed
+    # workers built, W warm, K timed, then the compared clips one per call through the same engines
+    assert _Pipe.made[0].calls == [("warm_up", 1), ("edit_clips", 2), ("edit_clips", 4), ("edit_clips", 1), ("edit_clips", 1)]
     r = out["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert set(r["by_batch"]) == {"unet_batch_2", "unet_batch_40"}
@@ -189,8 +190,9 @@ def test_default_line_has_the_contract_keys():
     assert r["path_frac_executed"] < r["path_frac"]
     assert "value_reference_order" in out and "value_single_clip_batched" in out and out["serial_legs_clips"] == 2
     assert out["schedule_deviation_rel_l2"] == 0.0          # the mocked edit returns the same latent for every schedule
-    assert out["pipeline_vs_one_clip_at_a_time"] == dict(schedule="batched", clips_compared=2, bit_identical=True,
-                                                         max_abs_diff=0.0)
+    assert out["pipeline_vs_one_clip_at_a_time"] == dict(
+        clips_compared=2, bit_identical_to_same_engines_alone=True, max_abs_diff=0.0, rel_l2_vs_plain_serial_leg=0.0,
+        plain_serial_schedule="batched")
 
 
 def test_lanes_plan_single_clip_schedules_and_multi_clip_mode():
@@ -200,7 +202,7 @@ def test_lanes_plan_single_clip_schedules_and_multi_clip_mode():
     assert out["config"]["clips_in_flight_per_gpu"] == 3 and "reference step order" in out["config"]["workload"]
     assert set(out["roofline"]["by_batch"]) == {"unet_batch_2"} and out["roofline"]["launches_per_clip"] == 300
     assert out["roofline"]["by_batch"]["unet_batch_2"]["streams_measured"] == 3
-    assert out["pipeline_vs_one_clip_at_a_time"]["schedule"] == "sequential"
+    assert out["pipeline_vs_one_clip_at_a_time"]["plain_serial_schedule"] == "sequential"
     out = _run(["--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--plan", "serial", "--schedule",
                 "sequential", "--group", "20"], [2, 40])
     assert "value_single_clip_batched" in out and "reference order" in out["config"]["workload"]

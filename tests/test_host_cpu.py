@@ -194,3 +194,21 @@ def test_cosine_dpm_scheduler_index_fallback_matches_diffusers():
     s.set_timesteps(10)
     assert s.index_for_timestep(s.timesteps[3]) == 3
     assert s.index_for_timestep(torch.tensor(123.456)) == len(s.timesteps) - 1
+
+
+def test_tile_tables_name_only_kernels_that_exist():
+    """Every (tile, ksplit) of the measured tables (whole chip, Stable Audio DiT, 128-CU partition regime) is a tile code
+    the launchers still have: 1-6 = LDS-staged block tiles, 10-19 = lin_gemm configurations (the round-1 wave-split-K
+    kernel, code 7, was retired)."""
+    from audioeditingcode_amd import tape
+    alive = {1, 2, 3, 4, 5, 6, *range(10, 20)}
+    for name, table in [("whole chip", tape.TILE_TABLE), *tape.REGIME_TABLES.items()]:
+        bad = {k: v for k, v in table.items() if v[0] not in alive or v[1] < 1}
+        assert not bad, (name, bad)
+    assert tape.Tape.pick_tile(2048, 256, 256) != (4, 1)
+    with tape.tile_regime("cus128"):
+        assert tape.Tape.pick_tile(2048, 256, 256) == (4, 1)           # the partition regime prefers the 64x64 block tile
+    assert tape.Tape.pick_tile(2048, 256, 256) != (4, 1)
+    with pytest.raises(KeyError):
+        with tape.tile_regime("no-such-regime"):
+            pass

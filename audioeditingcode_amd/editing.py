@@ -179,19 +179,38 @@ class EditEngine(LoopPlumbing):
                                           timesteps_dev=self.ts_dev, state_dev=self.state)
         return self._unets[key]
 
-    def _set_cond(self, eng, groups):
-        """groups: list of Conditioning, concatenated along the batch in order."""
+    def _set_cond(self, eng, groups, repeat=1):
+        """groups: list of Conditioning, concatenated along the batch in order; the whole list `repeat` times (the
+        timestep-batched inversion evaluates the same [uncond | prompt] rows for G timesteps: the rows are padded /
+        concatenated once and tiled, not rebuilt G times on the host)."""
+        tile = (lambda t: t) if repeat == 1 else (lambda t: t.repeat(repeat, *([1] * (t.dim() - 1))))
         if self.kind == "audioldm":
             d0 = groups[0].class_labels.device
-            eng.set_conditioning(class_labels=torch.cat([g.class_labels.float().to(d0) for g in groups], 0))
+            eng.set_conditioning(class_labels=tile(torch.cat([g.class_labels.float().to(d0) for g in groups], 0)))
         elif self.kind == "audioldm2":
             d0 = groups[0].ehs0.device
             e0 = torch.cat([g.ehs0.float().to(d0) for g in groups], 0)
             e1, b1 = _pad_ctx(groups, eng.L1, "ehs1", "mask1")
-            eng.set_conditioning(ehs0=e0, ehs1=e1, bias1=b1)
+            eng.set_conditioning(ehs0=tile(e0), ehs1=tile(e1), bias1=tile(b1))
         else:
             e0, b0 = _pad_ctx(groups, eng.L0, "ehs0", "mask0")
-            eng.set_conditioning(ehs0=e0, bias0=b0)
+            eng.set_conditioning(ehs0=tile(e0), bias0=tile(b0))
+
+    def _coef_table(self, s, ts, eta, kind):
+        """scheduler.coefficient_table, memoised: the rows are host scalar arithmetic in the reference's expression order
+        (23 ms of Python for T = 200) and depend only on the schedule, eta and the table kind -- a serving loop asks for
+        the same table clip after clip."""
+        key = (kind, tuple(int(t) for t in ts), tuple(eta) if isinstance(eta, (list, tuple)) else float(eta),
+               int(s.config.num_train_timesteps), int(s.num_inference_steps), str(s.config.prediction_type),
+               float(s.alphas_cumprod[0]), float(s.alphas_cumprod[-1]), float(s.final_alpha_cumprod))
+        cache = self.__dict__.setdefault("_coef_cache", {})
+        tab = cache.pop(key, None)
+        if tab is None:
+            tab = coefficient_table(s, ts, eta=eta, kind=kind)
+            while len(cache) >= 8:
+                cache.pop(next(iter(cache)))
+        cache[key] = tab
+        return tab
 
     @staticmethod
     def _round_len(n):
@@ -324,12 +343,12 @@ class EditEngine(LoopPlumbing):
         eng, pre, post = plan["eng"], plan["pre"], plan["post"]
         xts = self.to_nhwc(xts, out=plan["xts"])                  # [T+1, n, H, W, C]
         zs = plan["zs"]
-        plan["coef"].copy_(coefficient_table(s, s.timesteps.cpu(), eta=self._etas_in_loop_order(eta, T), kind="ddpm"))
+        plan["coef"].copy_(self._coef_table(s, s.timesteps.cpu(), self._etas_in_loop_order(eta, T), "ddpm"))
         self._upload_timesteps(s.timesteps, T)
         if cfg_tensor is not None:
             self.to_nhwc(cfg_tensor.reshape(P, n, self.C, self.H, self.W), out=plan["cfgt"])
         # batch rows: for g in G: [uncond x n | prompt_p x n ...]
-        self._set_cond(eng, [c for _ in range(G) for c in groups])
+        self._set_cond(eng, groups, repeat=G)
         self._patch_time(eng, self.ts_dev, G, rows_per_t, state=plan["state"])
         plan["state"].zero_()
 
@@ -404,7 +423,7 @@ class EditEngine(LoopPlumbing):
         cur.copy_(xts[Z])                                          # inversion_utils.py:203
         if has_noise:
             plan["zs"].copy_(zs[:Z])
-        plan["coef"].copy_(coefficient_table(s, ts, eta=eta_rows, kind=table_kind))
+        plan["coef"].copy_(self._coef_table(s, ts, eta_rows, table_kind))
         self._upload_timesteps(s.timesteps, T)
         if cfg_tensor is not None:
             self.to_nhwc(cfg_tensor.reshape(P, n, self.C, self.H, self.W), out=plan["cfgt"])

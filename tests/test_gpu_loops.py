@@ -203,11 +203,12 @@ def test_plan_cache_is_bounded():
 
 
 def test_full_size_headline_length_batched_vs_sequential():
-    """BASELINE config 2 at its real LENGTH: AudioLDM2 U-Net, latent 8x256x16, T=200, tstart=100, G=20 timesteps per
-    U-Net call (the bench's headline schedule) against the reference step order on the same device path -- the CPU oracle
-    needs ~6 minutes per clip at this size, so the oracle comparison stays at T=8 above and this test pins the
-    size-independent properties: finiteness, batched == sequential within the stated tolerance, the replay invariant."""
-    T, tstart, G = 200, 100, 20
+    """BASELINE config 2 at its real LENGTH and the bench's real SHAPE: AudioLDM2 U-Net, latent 8x256x16, T=200, tstart=100,
+    G=100 timesteps per U-Net call (U-Net batch 200, ~150 GB of activations: the engine the bench times) against the
+    reference step order on the same device path -- the CPU oracle needs ~6 minutes per clip at this size, so the oracle
+    comparison stays at T=8 above and this test pins the size-independent properties: finiteness, batched == sequential
+    within the stated tolerance, the replay invariant."""
+    T, tstart, G = 200, 100, 100
     fam = configs.FAMILIES["audioldm2"]
     cfg = fam["unet"]
     sd = weights.random_state_dict(weights.unet_param_shapes(cfg), seed=0)
@@ -236,6 +237,34 @@ def test_full_size_headline_length_batched_vs_sequential():
     assert rel(xts_b[1:], xts_s[1:]) < 1e-5, rel(xts_b[1:], xts_s[1:])
     assert rel(zs_b[1:], zs_s[1:]) < 5e-3, rel(zs_b[1:], zs_s[1:])
     assert rel(w_b, w_s) < 5e-3, rel(w_b, w_s)
+
+
+def test_eight_clips_per_engine_full_size_audioldm2():
+    """BASELINE config 3's per-rank shape at FULL size: 8 clips of the 346.9 M-parameter AudioLDM2 U-Net (latent 8x256x16)
+    edited as one U-Net batch per step (edit: batch 16; batched inversion, 2 timesteps per call: batch 32) against
+    single-clip runs with the same per-clip noise, at a short schedule."""
+    T, tstart, n = 4, 2, 8
+    fam = configs.FAMILIES["audioldm2"]
+    cfg = fam["unet"]
+    sd = weights.random_state_dict(weights.unet_param_shapes(cfg), seed=0)
+    g = torch.Generator().manual_seed(11)
+    mk = lambda L1: Conditioning(ehs0=torch.randn(1, 8, 768, generator=g), ehs1=torch.randn(1, L1, 1024, generator=g),  # noqa: E731
+                                 mask1=torch.ones(1, L1))
+    src, tgt, unc = mk(7), mk(9), mk(1)
+    sched = DDIMScheduler()
+    sched.set_timesteps(T)
+    eng = EditEngine(cfg, sd, sched, DEV, 256, 16, "audioldm2")
+    x0s = torch.randn(n, 8, 256, 16, generator=g) * 0.8
+    noise = torch.randn(T, n, 8, 256, 16, generator=g)
+    w8 = eng.edit_latents(x0s, src, unc, tgt, unc, [3.0], [12.0], tstart, schedule="batched", group=2, noise=noise)
+    torch.cuda.synchronize()
+    assert w8.shape == (n, 8, 256, 16) and torch.isfinite(w8).all()
+    assert {b for (b, _, _) in eng._unets} >= {16, 32}
+    for i in (0, 5):
+        w1 = eng.edit_latents(x0s[i:i + 1], src, unc, tgt, unc, [3.0], [12.0], tstart, schedule="sequential",
+                              noise=noise[:, i:i + 1])
+        torch.cuda.synchronize()
+        assert rel(w8[i:i + 1].cpu(), w1.cpu()) < 3e-3, (i, rel(w8[i:i + 1].cpu(), w1.cpu()))
 
 
 def test_eight_clips_per_engine_equal_eight_single_runs():

@@ -190,7 +190,7 @@ def main():
     ap.add_argument("--no-batched", action="store_true", help="skip the extra timestep-batched-inversion timing")
     ap.add_argument("--group", type=int, default=100,
                     help="timesteps per U-Net call in the batched inversion (measured on the MI355X: U-Net batch 40 / 80 / 200\n"
-                         "-> 85 / 92 / 99 TFLOP/s per forward; 200 needs ~150 GB of activations, well inside 288 GB)")
+                         "-> 85 / 92 / 99 TFLOP/s per forward; batch 200 holds ~24 GB of activations)")
     ap.add_argument("--schedule", default="batched", choices=["batched", "sequential"],
                     help="headline schedule of the forward inversion (the other one is timed as an extra)")
     ap.add_argument("--profile-forward", action="store_true", help="only run U-Net forwards (for rocprofv3)")

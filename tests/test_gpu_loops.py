@@ -204,7 +204,7 @@ def test_plan_cache_is_bounded():
 
 def test_full_size_headline_length_batched_vs_sequential():
     """BASELINE config 2 at its real LENGTH and the bench's real SHAPE: AudioLDM2 U-Net, latent 8x256x16, T=200, tstart=100,
-    G=100 timesteps per U-Net call (U-Net batch 200, ~150 GB of activations: the engine the bench times) against the
+    G=100 timesteps per U-Net call (U-Net batch 200, ~24 GB of activations: the engine the bench times) against the
     reference step order on the same device path -- the CPU oracle needs ~6 minutes per clip at this size, so the oracle
     comparison stays at T=8 above and this test pins the size-independent properties: finiteness, batched == sequential
     within the stated tolerance, the replay invariant."""

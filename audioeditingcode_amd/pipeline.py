@@ -246,8 +246,9 @@ class ClipPipeline:
         w_edit, _ = inversion_reverse_process(v, xT=f["wts"], tstart=torch.tensor([tstart], dtype=torch.int),
                                               etas=a["eta"], prompts=a["tgt"], neg_prompts=a["neg"],
                                               cfg_scales=a["cfg_tar"], zs=f["zs"][:tstart])
-        # VAE decode + vocoder are throughput kernels (45 ms on 256 CUs, 170 ms on a 128-CU partition): they run unmasked,
-        # sharing the inversion's CUs for those milliseconds, while this worker's edit partition is idle anyway
+        # VAE decode + vocoder are throughput kernels (44 ms alone on 256 CUs, 71 ms on the 128-CU partition, 64 ms unmasked
+        # beside a busy inversion partition: profiles/r03_codec_partition.md): they run unmasked, and the edit partition is
+        # free for the next clip's set-up meanwhile
         cs = st
         if w.full is not None and w.full.stream is not st:
             cs = w.full.stream

@@ -212,3 +212,16 @@ def test_tile_tables_name_only_kernels_that_exist():
     with pytest.raises(KeyError):
         with tape.tile_regime("no-such-regime"):
             pass
+
+
+def test_cu_mask_words():
+    """streams.cu_mask_words: bit k of the 32-bit words = CU k (aed_stream_create_cu_mask's layout); the two partitions of the
+    clip pipeline are complementary; out-of-range and empty masks are refused."""
+    from audioeditingcode_amd.streams import cu_mask_words
+    lo, hi = cu_mask_words(range(128), 256), cu_mask_words(range(128, 256), 256)
+    assert lo == [0xFFFFFFFF] * 4 + [0] * 4 and hi == [0] * 4 + [0xFFFFFFFF] * 4
+    assert [a | b for a, b in zip(lo, hi)] == [0xFFFFFFFF] * 8 and all(a & b == 0 for a, b in zip(lo, hi))
+    assert cu_mask_words([0, 33, 33, 255], 256) == [1, 2, 0, 0, 0, 0, 0, 0x80000000]
+    for bad in ([], [256], [-1]):
+        with pytest.raises(ValueError):
+            cu_mask_words(bad, 256)

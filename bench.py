@@ -19,7 +19,6 @@ CPU oracle (`parity`), and BASELINE configs 3/4/5 as sub-benchmarks.
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 """
 import argparse
-import glob
 import hashlib
 import json
 import os

@@ -80,13 +80,16 @@ def inversion_forward_process(model, x0: torch.Tensor, etas: Optional[float] = N
     if extract_h_space or extract_skipconns:
         return _forward_with_taps(model, x0, etas, prompts, cfg_scales, num_inference_steps, cutoff_points,
                                   numerical_fix, extract_h_space, extract_skipconns)
+    prepared = prepare_forward(model, x0, prompts, cfg_scales, num_inference_steps, cutoff_points)
+    return run_forward(model, x0, prepared, etas, cfg_scales, numerical_fix, schedule, timestep_group)
+
+
+def prepare_forward(model, x0, prompts, cfg_scales, num_inference_steps, cutoff_points=None):
+    """Everything of the fast-path forward process that does not touch the loop engine: text conditioning, the per-prompt
+    cfg tensor, the x_t draws (models.py:67-83).  Split from `run_forward` so that a clip pipeline can issue it on a side
+    stream while the loop engine is still busy with the previous clip (pipeline.ClipPipeline); called back to back on one
+    stream it is exactly the first half of inversion_forward_process."""
     has_src = len(prompts) > 1 or prompts[0] != ""
-    sched = model.model.scheduler
-    if type(etas) in [int, float]:
-        etas = [etas] * sched.num_inference_steps
-    # one eta, or the reference's per-step list (`eta=etas[idx]`, inversion_utils.py:124): the device loop reads a
-    # coefficient row per step either way
-    eta = 0.0 if etas is None else (float(etas[0]) if all(float(e) == float(etas[0]) for e in etas) else list(etas))
     cond_src, cfg_tensor = None, None
     P = len(prompts)
     if has_src:
@@ -94,10 +97,21 @@ def inversion_forward_process(model, x0: torch.Tensor, etas: Optional[float] = N
         if P > 1:
             cfg_tensor, _ = _segment_tensors(P, x0.shape[1:], cfg_scales, cutoff_points, x0.dtype, prompts)
     cond_unc = conditioning_from_text(model, model.encode_text([""], negative=True))
-    ed = model.editor(x0.shape[-2], x0.shape[-1])
     xts0 = model.sample_xts_from_x0(x0, num_inference_steps=num_inference_steps).unsqueeze(1)
-    zs, xts = ed.invert(x0, cond_src, cond_unc, cfg_scales, eta=eta, numerical_fix=numerical_fix, xts=xts0,
-                        cfg_tensor=cfg_tensor, mode=schedule, group=timestep_group)
+    return dict(cond_src=cond_src, cond_unc=cond_unc, cfg_tensor=cfg_tensor, xts0=xts0)
+
+
+def run_forward(model, x0, prepared, etas, cfg_scales, numerical_fix, schedule="sequential", timestep_group=8):
+    """The loop half of the fast-path forward process: EditEngine.invert + the NCHW views the callers expect."""
+    sched = model.model.scheduler
+    if type(etas) in [int, float]:
+        etas = [etas] * sched.num_inference_steps
+    # one eta, or the reference's per-step list (`eta=etas[idx]`, inversion_utils.py:124): the device loop reads a
+    # coefficient row per step either way
+    eta = 0.0 if etas is None else (float(etas[0]) if all(float(e) == float(etas[0]) for e in etas) else list(etas))
+    ed = model.editor(x0.shape[-2], x0.shape[-1])
+    zs, xts = ed.invert(x0, prepared["cond_src"], prepared["cond_unc"], cfg_scales, eta=eta, numerical_fix=numerical_fix,
+                        xts=prepared["xts0"], cfg_tensor=prepared["cfg_tensor"], mode=schedule, group=timestep_group)
     zs_n = ed.to_nchw(zs)[:, 0]
     xts_n = ed.to_nchw(xts)[:, 0]
     xt = xts_n[1][None]

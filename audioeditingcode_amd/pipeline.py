@@ -36,7 +36,7 @@ import time
 import torch
 
 from . import tape as tape_mod
-from .ddm_inversion.inversion_utils import inversion_forward_process, inversion_reverse_process
+from .ddm_inversion.inversion_utils import inversion_reverse_process, prepare_forward, run_forward
 from .streams import PartitionStream
 
 DEFAULT_EDIT_CUS = 128          # CUs of the edit-loop partition (the two stages' per-clip times cross near 128 of 256)
@@ -81,9 +81,10 @@ class _Worker:
     """One lane: a lane view of the model, its stream on the stage's CU partition and (partition plan) an unmasked
     stream for fill / drain."""
 
-    def __init__(self, stage, k, view, lane, full, regime=None):
+    def __init__(self, stage, k, view, lane, full, regime=None, prep=None):
         self.stage, self.k, self.view, self.lane, self.full = stage, k, view, lane, full
         self.regime = regime        # tile regime its engines are built under (tape.tile_regime)
+        self.prep = prep            # side stream for the part of a front half that does not touch the loop engine
         self.last = None            # (event, stream) of this worker's previous job
         self.warm = False
 
@@ -94,7 +95,7 @@ class ClipPipeline:
     event_type = torch.cuda.Event
 
     def __init__(self, model, plan="partition", edit_cus=None, edit_lanes=1, lanes=None, launch="graph",
-                 timestep_group=100):
+                 timestep_group=100, overlap_prep=True):
         if getattr(model, "kind", None) == "stable_audio":
             raise NotImplementedError("ClipPipeline drives the mel-latent families (AudioLDM / AudioLDM2 / TANGO)")
         if plan not in ("partition", "lanes"):
@@ -121,8 +122,12 @@ class ClipPipeline:
                 raise ValueError("the partition plan needs the timestep-batched inversion (timestep_group >= 2): the "
                                  "front stage must not share the edit loop's batch-2 engine regime")
             self.edit_lanes = max(1, int(edit_lanes))
+            # The next clip's mel / VAE encode / text conditioning / x_t draws + upload do not touch the batch-2G loop engine:
+            # they go to a side stream, so their host-blocking copies and checks wait for THAT stream and the work itself
+            # overlaps the inversion still running on the partition (otherwise ~50 ms of set-up per clip sit exposed
+            # between two inversions: `assert min(y) >= -1` alone drains the lane before anything else is enqueued).
             front = [_Worker("front", 0, self._view(), Lane(dev, cus=range(self.edit_cus, self.total), total=self.total),
-                             self.full)]
+                             self.full, prep=Lane(dev, index=17) if overlap_prep else None)]
             # the edit loop's batch-2 kernels on half the chip are no longer purely latency-bound: their tiles come from
             # the sweep taken on a 128-CU stream (tile_table_cus128.py) when the partition is about that size
             regime = "cus128" if (96 <= self.edit_cus <= 160 and "cus128" in tape_mod.REGIME_TABLES) else None
@@ -226,11 +231,21 @@ class ClipPipeline:
         """main_run.py:113-150: (waveform -> mel ->) VAE encode -> forward inversion."""
         v, a = w.view, job["a"]
         item = job["items"][i]
-        x0 = job["prepare"](v, item) if job["prepare"] is not None else item
-        w0 = v.vae_encode(x0)
-        _, zs, wts, _ = inversion_forward_process(v, w0, etas=a["eta"], prompts=a["src"], cfg_scales=a["cfg_src"],
-                                                  num_inference_steps=a["T"], numerical_fix=True,
-                                                  schedule=a["schedule"], timestep_group=a["group"])
+        ps = st if w.prep is None else w.prep.stream
+        with self._stream_ctx(ps):
+            x0 = job["prepare"](v, item) if job["prepare"] is not None else item
+            w0 = v.vae_encode(x0)
+            prepared = prepare_forward(v, w0, a["src"], a["cfg_src"], a["T"])
+        if ps is not st:
+            ready = self.event_type()
+            ready.record(ps)
+            st.wait_event(ready)
+            conds = [getattr(c, n) for c in (prepared["cond_src"], prepared["cond_unc"]) if c is not None
+                     for n in ("ehs0", "ehs1", "mask0", "mask1", "class_labels")]
+            for t in (x0, w0, prepared["xts0"], *conds):
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(st)
+        _, zs, wts, _ = run_forward(v, w0, prepared, a["eta"], a["cfg_src"], True, a["schedule"], a["group"])
         done = self.event_type()
         done.record(st)
         return dict(x0=x0, zs=zs, wts=wts, done=done)

@@ -205,6 +205,8 @@ def main():
     ap.add_argument("--lanes", type=int, default=3, help="lanes plan: clips in flight")
     ap.add_argument("--lane-launch", default="graph", choices=["eager", "graph"],
                     help="how a pipeline worker issues one diffusion step: one hipGraphLaunch (default) or launch by launch")
+    ap.add_argument("--no-overlap-prep", action="store_true",
+                    help="partition plan: prepare the next clip on the front lane itself instead of a side stream (A/B)")
     ap.add_argument("--serial-clips", type=int, default=3,
                     help="clips timed in each of the two one-clip-at-a-time legs reported beside the headline")
     ap.add_argument("--no-extras", action="store_true",
@@ -346,7 +348,7 @@ def main():
     if PLAN != "serial":
         from audioeditingcode_amd.pipeline import ClipPipeline
         pipe = ClipPipeline(m, plan=PLAN, edit_cus=args.edit_cus, edit_lanes=args.edit_lanes, lanes=args.lanes,
-                            launch=args.lane_launch, timestep_group=args.group)
+                            launch=args.lane_launch, timestep_group=args.group, overlap_prep=not args.no_overlap_prep)
         dt, gathered = timed_pipeline(args.steps, args.warmup)
         extra["pipeline"] = pipe.report()
         if PLAN == "partition":

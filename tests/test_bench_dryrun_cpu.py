@@ -115,7 +115,8 @@ class _Pipe:
     """pipeline.ClipPipeline stand-in: workers with lane views / streams, clips handed back in order."""
     made = []
 
-    def __init__(self, model, plan="partition", edit_cus=None, edit_lanes=1, lanes=None, launch="graph", timestep_group=100):
+    def __init__(self, model, plan="partition", edit_cus=None, edit_lanes=1, lanes=None, launch="graph", timestep_group=100,
+                 overlap_prep=True):
         assert launch in ("eager", "graph") and plan in ("partition", "lanes")
         self.plan, self.total, self.edit_cus, self.edit_lanes = plan, 256, edit_cus, edit_lanes
         if plan == "partition":

@@ -33,11 +33,13 @@ def _serial_b(m, mels, T, tstart, seeds, group):
     return out
 
 
-@pytest.mark.parametrize("edit_lanes,launch", [(1, "graph"), (2, "graph"), (1, "eager")])
-def test_partition_pipeline_is_bit_identical_to_one_clip_at_a_time_tiny(edit_lanes, launch):
+@pytest.mark.parametrize("edit_lanes,launch,overlap", [(1, "graph", True), (2, "graph", True), (1, "eager", True),
+                                                        (1, "graph", False)])
+def test_partition_pipeline_is_bit_identical_to_one_clip_at_a_time_tiny(edit_lanes, launch, overlap):
     """5 clips through the two-stage partition pipeline (inversion of clip i+1 on CUs [96,256) beside the edit loop of clip
     i on CUs [0,96)) == the same clips one at a time with the same (batched) inversion schedule and per-clip seeds:
-    latents and waveforms bit for bit; the waveform -> mel step runs on the front lane's own STFT engine."""
+    latents and waveforms bit for bit; the waveform -> mel step runs on the front lane's own STFT engine; with and without
+    the next clip's preparation on a side stream."""
     T, tstart, G = 10, 6, 5
     m = models.load_model("tiny/audioldm2", DEV, T, seed=0)
     wavs = [synthetic_clip(seconds=1.25, seed=7 + i) for i in range(5)]
@@ -45,7 +47,9 @@ def test_partition_pipeline_is_bit_identical_to_one_clip_at_a_time_tiny(edit_lan
     mels = [to_mel(m, w) for w in wavs]
     seeds = [40 + i for i in range(5)]
     ref = _serial_b(m, mels, T, tstart, seeds, G)
-    pipe = ClipPipeline(m, plan="partition", edit_cus=96, edit_lanes=edit_lanes, launch=launch, timestep_group=G)
+    pipe = ClipPipeline(m, plan="partition", edit_cus=96, edit_lanes=edit_lanes, launch=launch, timestep_group=G,
+                        overlap_prep=overlap)
+    assert (pipe.workers[0].prep is not None) == overlap
     pipe.warm_up(wavs[0], *ARGS, T, tstart, prepare=to_mel)
     got = pipe.edit_clips(wavs, *ARGS, T, tstart, seeds=seeds, prepare=to_mel)
     for i, ((a, o, w), (a2, o2, w2)) in enumerate(zip(got, ref)):

@@ -1,4 +1,5 @@
-// norm.hip -- GroupNorm (+SiLU) and LayerNorm on channels-last activations.
+// norm.hip -- GroupNorm (+SiLU) on channels-last activations.  (LayerNorm, K8, has no kernel of its own any
+// more: its statistics are gathered inside the consuming GEMM, conv_gemm.hip / lin_gemm.hip ln_mode.)
 //
 // GroupNorm over [B, HW, C] with G groups of C/G contiguous channels.  HBM-bound: the activation
 // is read twice and written once.  Two launches:
@@ -6,7 +7,6 @@
 //              lane) and emits per-group partial (sum, sumsq) -- deterministic tree, no atomics;
 //   gn_apply : every block re-reduces the <= few-hundred partials of its batch item in fp64,
 //              then normalises + affine (+SiLU) its slab.
-// LayerNorm: one 64-lane wavefront per token, two-pass variance, DPP/shuffle reductions.
 #include "aed_common.h"
 
 // Two-source rows: channel c < C1 of row `row` lives in x (stride ldx), c >= C1 in x2 (stride ldx2) at c - C1 -- the

@@ -57,6 +57,14 @@ def lib():
         L.aed_stream_create_cu_mask.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_uint32), ci, ci]
         L.aed_stream_destroy.argtypes = [vp]
         L.aed_cu_census.argtypes = [vp, ci, ci, vp]
+        u64 = ctypes.c_uint64
+        L.aed_image_load.argtypes = [ctypes.c_char_p, ci, ctypes.POINTER(vp)]
+        L.aed_image_free.argtypes = [vp]
+        L.aed_image_run.argtypes = [vp, ctypes.c_char_p, vp]
+        L.aed_image_program.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.POINTER(aed_op)), ctypes.POINTER(ci)]
+        L.aed_image_buffer.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(vp), ctypes.POINTER(u64)]
+        L.aed_image_copy_in.argtypes = [vp, ctypes.c_char_p, vp, u64, vp]
+        L.aed_image_copy_out.argtypes = [vp, ctypes.c_char_p, vp, u64, vp]
         L.aed_event_create.argtypes = [ctypes.POINTER(vp)]
         L.aed_event_record.argtypes = [vp, vp]
         L.aed_event_elapsed_ms.argtypes = [vp, vp, ctypes.POINTER(cf)]
@@ -69,7 +77,8 @@ def lib():
         L.aed_sa_reverse_step_with_custom_noise.argtypes = [vp, vp, vp, cf, fp, vp, vp, vp, ctypes.c_int64, vp]
         for name in ("aed_launch", "aed_tape_run", "aed_tape_profile", "aed_graph_begin", "aed_graph_end",
                      "aed_graph_launch", "aed_graph_destroy", "aed_stream_create_cu_mask", "aed_stream_destroy",
-                     "aed_cu_census", "aed_event_create", "aed_event_record", "aed_event_elapsed_ms", "aed_event_destroy", "aed_get_zs_from_xts",
+                     "aed_cu_census", "aed_image_load", "aed_image_free", "aed_image_run", "aed_image_program",
+                     "aed_image_buffer", "aed_image_copy_in", "aed_image_copy_out", "aed_event_create", "aed_event_record", "aed_event_elapsed_ms", "aed_event_destroy", "aed_get_zs_from_xts",
                      "aed_reverse_step_with_custom_noise", "aed_sample_xts_from_x0", "aed_device_info",
                      "aed_sa_get_zs_from_xts", "aed_sa_reverse_step_with_custom_noise"):
             getattr(L, name).restype = ci
@@ -81,7 +90,8 @@ def lib():
 
 EXPORTS = ["aed_version", "aed_last_error", "aed_device_info", "aed_launch", "aed_tape_run", "aed_tape_profile",
            "aed_graph_begin", "aed_graph_end", "aed_graph_launch", "aed_graph_destroy", "aed_stream_create_cu_mask",
-           "aed_stream_destroy", "aed_cu_census", "aed_event_create",
+           "aed_stream_destroy", "aed_cu_census", "aed_image_load", "aed_image_free", "aed_image_run", "aed_image_program",
+           "aed_image_buffer", "aed_image_copy_in", "aed_image_copy_out", "aed_event_create",
            "aed_event_record", "aed_event_elapsed_ms", "aed_event_destroy", "aed_get_zs_from_xts",
            "aed_reverse_step_with_custom_noise", "aed_sample_xts_from_x0", "aed_sa_get_zs_from_xts",
            "aed_sa_reverse_step_with_custom_noise"]

@@ -13,6 +13,7 @@ hipcc $FLAGS -c norm.hip -o obj/norm.o & pids+=($!)
 hipcc $FLAGS -ffp-contract=off -c elementwise.hip -o obj/elementwise.o & pids+=($!)
 hipcc $FLAGS -ffp-contract=off -c stable_audio.hip -o obj/stable_audio.o & pids+=($!)
 hipcc $FLAGS -c api.hip -o obj/api.o & pids+=($!)
+hipcc $FLAGS -c image.hip -o obj/image.o & pids+=($!)
 for p in "${pids[@]}"; do wait $p; done
 hipcc --offload-arch=$ARCH -shared -fPIC obj/*.o -o ../libaed.so
 echo "built $(cd .. && pwd)/libaed.so"

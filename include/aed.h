@@ -113,6 +113,24 @@ int aed_stream_destroy(void* stream);
  * for the CU partition). */
 int aed_cu_census(uint32_t* out_dev, int n_blocks, int spin_clocks, void* stream);
 
+/* ----------------------------------------------------------------------------------------
+ * tape images: a compiled model for hosts without the Python graph compiler
+ * --------------------------------------------------------------------------------------
+ * audioeditingcode_amd/image.py writes a model's op tapes, every buffer they reference (weights, tables, activations, inputs,
+ * outputs) and a snapshot of those buffers into ONE relocatable file.  aed_image_load() puts the arena on the device and
+ * relocates the ops; a host then fills the named inputs, runs a named program (= aed_tape_run on the image's ops) and reads
+ * the named outputs -- e.g. for a U-Net image: copy_in "x_in" / "ehs0" / "ehs1" / "bias1" / "timesteps", run "context" once
+ * per prompt, run "forward" per step, copy_out "eps".  (This is the model-level boundary SURVEY 8(b) sketched as
+ * aed_create / aed_unet_forward / aed_vae_encode / ...: one loader and one runner instead of one entry point per model.)
+ * flags bit 0: keep the arena in HOST memory (inspection and tests; aed_image_run refuses such an image).             */
+int aed_image_load(const char* path, int flags, void** image_out);
+int aed_image_free(void* image);
+int aed_image_run(void* image, const char* program, void* stream);
+int aed_image_program(void* image, const char* program, const aed_op** ops_out, int* n_out);   /* the relocated ops */
+int aed_image_buffer(void* image, const char* name, void** ptr_out, uint64_t* nbytes_out);
+int aed_image_copy_in(void* image, const char* name, const void* host, uint64_t nbytes, void* stream);     /* synchronous */
+int aed_image_copy_out(void* image, const char* name, void* host, uint64_t nbytes, void* stream);          /* synchronous */
+
 /* HIP-event helpers so hosts without a HIP binding can time a stream region. */
 int aed_event_create(void** ev_out);
 int aed_event_record(void* ev, void* stream);

@@ -97,3 +97,73 @@ def test_folded_cross_attention_unet_matches_oracle(kind, L0, L1):
     got, ref, hs, ref_h, _ = _run_case(fam, B=2, H=32, W=16, L0=L0, L1=L1, t=401, want_folded=4)
     assert (hs - ref_h).abs().max().item() < 2e-4 * max(1.0, ref_h.abs().max().item())
     assert (got - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item())
+
+
+def test_tape_image_runs_a_forward_without_the_python_graph_compiler(tmp_path):
+    """The model-level boundary (include/aed.h, tape images): a U-Net engine's tapes are exported ahead of time
+    (image.export_image); then (1) the seven aed_image_* entry points, driven through ctypes the way a C host would, and
+    (2) a plain C program (examples/image_host.c, built by __graft_entry__.build(), no Python / no torch in its process)
+    reproduce the engine's own forward bit for bit -- for the snapshot inputs and for new inputs copied in by name."""
+    import ctypes
+    import os
+    import subprocess
+
+    import numpy as np
+
+    from audioeditingcode_amd import _lib as L
+    from audioeditingcode_amd.image import Image, export_image
+    fam = configs.tiny_family("audioldm2")
+    cfg = fam["unet"]
+    sd = weights.random_state_dict(weights.unet_param_shapes(cfg), seed=0)
+    ts = torch.tensor([501, 301], dtype=torch.int64, device=DEV)
+    state = torch.zeros(4, dtype=torch.int32, device=DEV)
+    eng = UNetEngine(cfg, sd, DEV, 2, 32, 16, ctx_len0=8, ctx_len1=8, timesteps_dev=ts, state_dev=state)
+    g = torch.Generator().manual_seed(1)
+    mk = lambda: (torch.randn(2, 8, 48, generator=g), torch.randn(2, 8, 64, generator=g), torch.zeros(2, 8),   # noqa: E731
+                  torch.randn(2, 32, 16, 8, generator=g))
+
+    def engine_forward(e0, e1, b1, x):
+        eng.set_conditioning(ehs0=e0, ehs1=e1, bias1=b1)
+        eng.x_in.copy_(x)
+        eng.forward()
+        torch.cuda.synchronize()
+        return eng.eps.cpu().clone()
+    first, second = mk(), mk()
+    ref1 = engine_forward(*first)
+    path = str(tmp_path / "unet_tiny.aedimg")
+    info = export_image(path, {"context": eng.ctx_tape, "forward": eng.tape},
+                        dict(x_in=eng.x_in, eps=eng.eps, ehs0=eng.ehs0, ehs1=eng.ehs1, bias1=eng.bias1, timesteps=ts,
+                             state=state), scratch=[eng.eps, eng.h_space])
+    assert info["programs"] == ["context", "forward"]
+    ref2 = engine_forward(*second)                 # the engine moves on; the image keeps the snapshot of `first`
+    # ---- (1) the C ABI through ctypes
+    im = Image(path)
+    st = torch.cuda.Stream()
+    sp = ctypes.c_void_p(st.cuda_stream)
+    im.run("context", sp)
+    im.run("forward", sp)
+    got = im.copy_out("eps", torch.empty_like(ref1), sp)
+    assert torch.equal(got, ref1)
+    for name, t in zip(("ehs0", "ehs1", "bias1", "x_in"), second):
+        im.copy_in(name, t.float(), sp)
+    im.run("context", sp)
+    im.run("forward", sp)
+    assert torch.equal(im.copy_out("eps", torch.empty_like(ref2), sp), ref2)
+    im.close()
+    # ---- (2) a host without Python
+    pkg = os.path.dirname(L.LIB_PATH)
+    host = os.path.join(pkg, "aed_image_host")
+    if not os.path.exists(host):                   # normally built by __graft_entry__.build(); plain gcc, seconds
+        root = os.path.dirname(pkg)
+        subprocess.check_call(["gcc", "-O2", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "image_host.c"),
+                               "-L" + pkg, "-laed", "-Wl,-rpath,$ORIGIN", "-o", host])
+    files = []
+    for name, t in zip(("ehs0", "ehs1", "bias1", "x_in"), second):
+        f = str(tmp_path / f"{name}.bin")
+        t.float().contiguous().numpy().tofile(f)
+        files.append(f"{name}={f}")
+    out = str(tmp_path / "eps.bin")
+    r = subprocess.run([host, path, out, "3", *files], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    eps = torch.from_numpy(np.fromfile(out, dtype=np.float32)).reshape(ref2.shape)
+    assert torch.equal(eps, ref2), float((eps - ref2).abs().max())

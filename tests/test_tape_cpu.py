@@ -297,3 +297,61 @@ def test_edit_latents_batch_equals_per_clip_runs_on_cpu(cpu_loops):
     _, zs_o, xts_o = oloops.invert(ow, x0b[:1], conds["src"], conds["unc"], [3.0], T, eta=1.0, xts=xts0.clone())
     w_o = oloops.edit(ow, xts_o, torch.tensor([tstart]), conds["tgt"], conds["unc"], [12.0], zs_o[:tstart], eta=1.0)
     assert rel(both[:1], w_o) < 2e-3
+
+
+def test_tape_image_round_trip_in_host_memory(tmp_path):
+    """image.export_image -> aed_image_load(flags=1: arena in host memory): the file carries both programs of a U-Net engine
+    (per-prompt context tape + forward tape), every op survives with its pointers relocated into ONE arena at the same
+    relative positions, named buffers hold what the engine held (weights and inputs travel, scratch buffers arrive zeroed),
+    copy_in / copy_out address buffers by name, and an image that lives in host memory refuses to run."""
+    import ctypes
+
+    from audioeditingcode_amd import _lib as L, configs, weights
+    from audioeditingcode_amd.image import Image, export_image
+    from audioeditingcode_amd.unet import UNetEngine
+    fam = configs.tiny_family("audioldm2")
+    sd = weights.random_state_dict(weights.unet_param_shapes(fam["unet"]), seed=0)
+    ts = torch.tensor([501, 301], dtype=torch.int64)
+    state = torch.zeros(4, dtype=torch.int32)
+    eng = UNetEngine(fam["unet"], sd, "cpu", 2, 32, 16, ctx_len0=8, ctx_len1=8, timesteps_dev=ts, state_dev=state)
+    g = torch.Generator().manual_seed(1)
+    eng.x_in.copy_(torch.randn(2, 32, 16, 8, generator=g))
+    eng.ehs0.copy_(torch.randn(eng.ehs0.shape, generator=g))
+    names = dict(x_in=eng.x_in, eps=eng.eps, ehs0=eng.ehs0, ehs1=eng.ehs1, bias1=eng.bias1, timesteps=ts, state=state,
+                 conv_in_w=eng.wd["conv_in.weight"])
+    path = str(tmp_path / "unet_tiny.aedimg")
+    info = export_image(path, {"context": eng.ctx_tape, "forward": eng.tape}, names, scratch=[eng.eps, eng.h_space])
+    assert info["n_ops"] == len(eng.ctx_tape.ops) + len(eng.tape.ops) and info["snapshot_bytes"] < info["arena_bytes"]
+    im = Image(path, host=True)
+    base, _ = im.buffer("x_in")
+    for prog, tp in (("context", eng.ctx_tape), ("forward", eng.tape)):
+        ops, n = im.program(prog)
+        assert n == len(tp.ops)
+        arr = tp.finalize()
+        for k in range(n):
+            a, b = ops[k], arr[k]
+            assert a.code == b.code and a.flags == b.flags and list(a.i) == list(b.i) and list(a.f) == list(b.f)
+            for j in range(10):
+                assert bool(a.p[j]) == bool(b.p[j] and j != 7), (prog, k, j)
+    ops, n = im.program("forward")
+    conv_in = ops[[mt["name"] for mt in eng.tape.meta].index("conv_in")]
+    assert conv_in.code == L.OP_CONV_GEMM and conv_in.p[0] == base         # conv_in reads the image's x_in
+    w_ptr, w_bytes = im.buffer("conv_in_w")
+    assert conv_in.p[1] == w_ptr and w_bytes == eng.wd["conv_in.weight"].numel() * 4
+    read = lambda name, like: im.copy_out(name, torch.empty_like(like))    # noqa: E731
+    assert torch.equal(read("x_in", eng.x_in), eng.x_in) and torch.equal(read("ehs0", eng.ehs0), eng.ehs0)
+    assert torch.equal(read("conv_in_w", eng.wd["conv_in.weight"]), eng.wd["conv_in.weight"])
+    assert torch.equal(read("timesteps", ts), ts)
+    assert float(read("eps", eng.eps).abs().max()) == 0.0                 # scratch: zero after load
+    new_x = torch.randn(2, 32, 16, 8, generator=g)
+    im.copy_in("x_in", new_x)
+    assert torch.equal(read("x_in", new_x), new_x)
+    with pytest.raises(L.AedError, match="host memory"):
+        im.run("forward")
+    with pytest.raises(L.AedError, match="no program"):
+        im.program("nope")
+    with pytest.raises(L.AedError, match="do not fit"):
+        im.copy_in("state", torch.zeros(64))
+    im.close()
+    with pytest.raises(L.AedError):
+        Image(str(tmp_path / "missing.aedimg"))

@@ -147,3 +147,78 @@ class Image:
         if self.h:
             L.check(L.lib().aed_image_free(self.h), "aed_image_free")
             self.h = ctypes.c_void_p()
+
+
+# ------------------------------------------------------------------------------------------------ whole engines / models
+def engine_image_spec(eng):
+    """(programs, names, scratch) of one engine of this package, by its class: the buffers a host fills and reads."""
+    kind = type(eng).__name__
+    if kind == "UNetEngine":
+        names = {k: getattr(eng, k) for k in ("x_in", "eps", "h_space", "ehs0", "ehs1", "bias0", "bias1", "class_labels")
+                 if getattr(eng, k, None) is not None}
+        if eng.timesteps_dev is not None:
+            names["timesteps"] = eng.timesteps_dev          # int64 table read by the time-embedding op at index state[0]
+        if eng.state_dev is not None:
+            names["state"] = eng.state_dev
+        return {"context": eng.ctx_tape, "forward": eng.tape}, names, [eng.eps, eng.h_space]
+    if kind == "STFTEngine":
+        return {"forward": eng.tape}, {"wav": eng.wav, "mel": eng.mel}, [eng.mel, eng.mag]
+    if kind == "VAEEncoder":
+        return {"forward": eng.tape}, {"x_in": eng.x_in, "latent": eng.latent}, [eng.latent]
+    if kind == "VAEDecoder":
+        return {"forward": eng.tape}, {"z_in": eng.z_in, "mel": eng.mel}, [eng.mel]
+    if kind == "VocoderEngine":
+        return {"forward": eng.tape}, {"mel_in": eng.mel_in, "wav": eng.wav}, [eng.wav]
+    raise TypeError(f"no image spec for {kind}")
+
+
+def export_engine(path, eng):
+    programs, names, scratch = engine_image_spec(eng)
+    return export_image(path, programs, names, scratch)
+
+
+def export_model_images(model, out_dir, n_samples=163840, unet_batch=2, ctx_len1=16):
+    """The five engines of one mel-latent wrapper (AudioLDM / AudioLDM2 / TANGO) for a clip of `n_samples` at the model's
+    rate, as tape images: stft.aedimg, vae_encode.aedimg, unet_b<B>.aedimg, vae_decode.aedimg, vocoder.aedimg -- what a
+    host needs besides the loop-level step entry points (aed_get_zs_from_xts, aed_reverse_step_with_custom_noise) to run
+    the whole path of main_run.py:104-185 without Python.  Returns {file: summary}."""
+    import os
+    os.makedirs(out_dir, exist_ok=True)
+    stft = model._stft(1, n_samples)
+    T = stft.frames - 1                                 # utils.pad_spec cuts the STFT's surplus last frame
+    if T % 4:
+        raise ValueError(f"n_samples={n_samples}: {T} mel frames is not a multiple of the VAE's time stride (4)")
+    F = stft.n_mels
+    enc = model._vae_enc(1, T, F)
+    dec = model._vae_dec(1, enc.h, enc.w)
+    voc = model._vocoder(1, T)
+    ed = model.editor(enc.h, enc.w)
+    fam = model.family["ctx"]
+    L0 = fam.get("gpt2_len", 0) if model.kind == "audioldm2" else (ctx_len1 if model.kind == "tango" else 0)
+    unet = ed.unet(unet_batch, L0, ctx_len1 if model.kind == "audioldm2" else 0)
+    out = {}
+    for name, eng in (("stft", stft), ("vae_encode", enc), (f"unet_b{unet_batch}", unet), ("vae_decode", dec),
+                      ("vocoder", voc)):
+        out[name + ".aedimg"] = export_engine(os.path.join(out_dir, name + ".aedimg"), eng)
+    return out
+
+
+def main(argv=None):
+    import argparse
+    p = argparse.ArgumentParser(description="Export the engines of one model as tape images (include/aed.h: aed_image_*)")
+    p.add_argument("--model_id", default="cvssp/audioldm2")
+    p.add_argument("--out", default="images")
+    p.add_argument("--num_diffusion_steps", type=int, default=200)
+    p.add_argument("--seconds", type=float, default=10.24)
+    p.add_argument("--device_num", type=int, default=0)
+    p.add_argument("--allow_synthetic", action="store_true")
+    a = p.parse_args(argv)
+    from .models import load_model
+    m = load_model(a.model_id, f"cuda:{a.device_num}", a.num_diffusion_steps, allow_synthetic=a.allow_synthetic or None)
+    for f, info in export_model_images(m, a.out, n_samples=int(a.seconds * m.get_sr())).items():
+        print(f"{f}: {info['n_ops']} ops, programs {info['programs']}, buffers {info['names']}, "
+              f"{info['snapshot_bytes'] / 1e6:.1f} MB snapshot + {(info['arena_bytes'] - info['snapshot_bytes']) / 1e6:.1f} MB scratch")
+
+
+if __name__ == "__main__":
+    main()

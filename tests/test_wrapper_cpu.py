@@ -424,3 +424,33 @@ def test_clip_pipeline_plans_equal_serial_edit_clip(cpu_stack, monkeypatch):
         assert "sample_xts_from_x0" not in lanes.workers[0].view.__dict__      # the gated draw hook is removed again
     finally:
         torch.set_num_threads(threads)
+
+
+def test_export_model_images_on_cpu(monkeypatch, tmp_path):
+    """image.export_model_images: the five engines of a wrapper (STFT, VAE encode, U-Net, VAE decode, vocoder) become five
+    tape images whose named buffers have the engines' shapes; loaded into host memory, the STFT image's window / basis and
+    the U-Net image's timestep table arrive intact."""
+    from audioeditingcode_amd import _lib as L
+    from audioeditingcode_amd.image import Image, export_model_images
+    from conftest import install_cpu_stack
+    real_lib = L.lib
+    with monkeypatch.context() as mp:                   # engines are built on CPU under the test stack ...
+        install_cpu_stack(mp)
+        m = _model(4)
+        out = export_model_images(m, str(tmp_path), n_samples=5120, unet_batch=2, ctx_len1=8)
+    assert L.lib is real_lib                            # ... the images are loaded by the real libaed.so (host-memory mode)
+    assert sorted(out) == ["stft.aedimg", "unet_b2.aedimg", "vae_decode.aedimg", "vae_encode.aedimg", "vocoder.aedimg"]
+    assert out["unet_b2.aedimg"]["programs"] == ["context", "forward"]
+    assert {"x_in", "eps", "ehs0", "ehs1", "bias1", "timesteps", "state"} <= set(out["unet_b2.aedimg"]["names"])
+    im = Image(str(tmp_path / "unet_b2.aedimg"), host=True)
+    ed = next(iter(m._editors.values()))
+    _, nb = im.buffer("x_in")
+    eng = next(iter(ed._unets.values()))
+    assert nb == eng.x_in.numel() * 4
+    assert torch.equal(im.copy_out("timesteps", torch.empty_like(ed.ts_dev)), ed.ts_dev)
+    ops, n = im.program("forward")
+    assert n == len(eng.tape.ops)
+    im.close()
+    voc = Image(str(tmp_path / "vocoder.aedimg"), host=True)
+    assert voc.buffer("wav")[1] > 0 and voc.buffer("mel_in")[1] > 0
+    voc.close()

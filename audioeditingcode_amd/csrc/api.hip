@@ -43,9 +43,14 @@ static int launch_retired(const aed_op* op, hipStream_t) {
     aed_set_error("opcode %d was retired in ABI v4 (fused into conv_gemm: ln_mode / geglu slots)", op->code);
     return 3;
 }
+// CONV_GEMM, flag bit 2: contraction on split-bf16 MFMAs (conv_gemm_x6.hip; experimental, see include/aed.h)
+int launch_conv_gemm_x6(const aed_op* op, hipStream_t s);
+static int launch_conv_gemm_any(const aed_op* op, hipStream_t s) {
+    return (op->flags & 4) ? launch_conv_gemm_x6(op, s) : launch_conv_gemm(op, s);
+}
 static launcher_t g_table[AED_OP_COUNT] = {
     launch_nop,           // NOP
-    launch_conv_gemm,     // CONV_GEMM
+    launch_conv_gemm_any, // CONV_GEMM
     launch_gn_stats, launch_gn_apply, launch_retired, launch_attention, launch_retired, launch_copy2d,
     launch_time_embed, launch_softmax_rows, launch_transpose, launch_axpby, launch_invert_step,
     launch_reverse_step, launch_ddim_step, launch_advance, launch_reflect_pad, launch_magnitude,

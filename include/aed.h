@@ -38,7 +38,13 @@ extern "C" {
 enum aed_opcode {
     AED_OP_NOP = 0,
     AED_OP_CONV_GEMM = 1,     /* implicit-GEMM conv / linear on fp32 MFMA (K5,K6,K11,K2,K3); optional two-source A
-                                 (skip concat never materialised), fused LayerNorm, fused GEGLU gate (K8)        */
+                                 (skip concat never materialised), fused LayerNorm, fused GEGLU gate (K8).
+                                 flags bit 0: in-kernel timeline into p[7]; bit 1: late epilogue fetch (lin_gemm A/B);
+                                 bit 2 (EXPERIMENTAL, nothing on the product path sets it): contract on split-bf16
+                                 MFMAs -- every fp32 operand is cut exactly into three bf16 pieces in the loader and the
+                                 six piece products of relative size >= 2^-16 are accumulated in fp32
+                                 (csrc/conv_gemm_x6.hip; as close to fp64 as the fp32 chain, tools/bf16_split_study.py);
+                                 bit 3: with bit 2, request the MFMA / VALU interleave (A/B switch)              */
     AED_OP_GN_STATS = 2,      /* GroupNorm partial sums (K4)                                   */
     AED_OP_GN_APPLY = 3,      /* GroupNorm normalise + affine (+SiLU) (K4)                     */
     AED_OP_LAYERNORM = 4,     /* RETIRED in v4 (returns an error): LayerNorm is fused into the consuming GEMM (K8)  */

@@ -1,0 +1,265 @@
+// x6_bench.cpp -- standalone A/B of the split-bf16 contraction (csrc/conv_gemm_x6.hip, op flag bit 2) against the fp32-MFMA
+// kernel on the GEMM shapes of one AudioLDM2 U-Net forward at batch 200 (the inversion's batched forward), through the
+// C ABI only (no Python, no torch: the process starts in milliseconds on a fresh box).
+//
+//   hipcc -O2 -std=c++17 -Iinclude tools/x6_bench.cpp -Laudioeditingcode_amd -laed -Wl,-rpath,'$ORIGIN' \
+//         -o audioeditingcode_amd/x6_bench          (python tools/build_x6_bench.py does this)
+//   audioeditingcode_amd/x6_bench [iters]           -> one JSON line per (shape, variant) on stdout
+//
+// Per shape: the same AED_OP_CONV_GEMM record is launched with flags = 0 (fp32 MFMA, tile 1 = 128x128) and with
+// flags = 4 (| 8) and tile codes 1 / 8 / 9 / 3.  Reported: average launch time over `iters` launches (HIP events on the
+// launch stream), TF/s of the algorithmic flops, rel L2 and max |diff| of the x6 result against the fp32 kernel's over
+// the whole output, and the rel L2 error of BOTH against an fp64 host reference on 512 sampled outputs.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "aed.h"
+
+#define HIPCHECK(e)                                                                      \
+    do {                                                                                 \
+        hipError_t _e = (e);                                                             \
+        if (_e != hipSuccess) {                                                          \
+            fprintf(stderr, "%s:%d %s -> %s\n", __FILE__, __LINE__, #e, hipGetErrorString(_e)); \
+            exit(2);                                                                     \
+        }                                                                                \
+    } while (0)
+
+static uint64_t g_rng = 0x9E3779B97F4A7C15ull;
+static inline float urand() {       // xorshift64*, uniform in [-1, 1)
+    g_rng ^= g_rng >> 12; g_rng ^= g_rng << 25; g_rng ^= g_rng >> 27;
+    return (float)((int32_t)((g_rng * 0x2545F4914F6CDD1Dull) >> 32)) * (1.0f / 2147483648.0f);
+}
+static inline float nrand() { return (urand() + urand() + urand() + urand()) * 0.8660254f; }   // ~N(0,1)
+
+// integer hash -> [-1, 1): the same value on the host and on the device (the residual operand is generated in place)
+__host__ __device__ static inline float hash_unit(uint64_t e) {
+    uint64_t z = e + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (float)((int32_t)(z >> 32)) * (1.0f / 2147483648.0f);
+}
+__global__ void fill_hash(float* p, size_t n) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) p[e] = hash_unit(e);
+}
+// out[0] += sum (a-b)^2, out[1] += sum b^2, *maxbits = max |a-b| (float bits; NaN differences make out[0] NaN)
+__global__ void compare_kernel(const float* a, const float* b, size_t n, double* out, unsigned* maxbits) {
+    double num = 0.0, den = 0.0;
+    float mx = 0.f;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const float dv = a[e] - b[e];
+        num += (double)dv * dv;
+        den += (double)b[e] * b[e];
+        mx = fmaxf(mx, fabsf(dv));
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        num += __shfl_down(num, o, 64);
+        den += __shfl_down(den, o, 64);
+        mx = fmaxf(mx, __shfl_down(mx, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&out[0], num);
+        atomicAdd(&out[1], den);
+        atomicMax(maxbits, __float_as_uint(mx));
+    }
+}
+__global__ void gather_kernel(const float* C, const unsigned long long* idx, float* out, int n) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n) out[q] = C[idx[q]];
+}
+
+struct Shape {
+    const char* name;
+    int B, IH, IW, Cin, N, KH;      // stride 1, "same" padding, KH x KH taps (1 = linear layer)
+    int res;                        // add a residual in the epilogue
+    int lnglu;                      // fused LayerNorm prologue statistics + GEGLU gate (the FF1 form; x6 vs fp32 kernel only)
+};
+
+struct Dev {
+    float *A, *W, *bias, *res, *rowvec, *C0, *C1;
+};
+
+static void fill_op(aed_op& op, const Shape& s, const Dev& d, float* C, int flags, int tile) {
+    memset(&op, 0, sizeof(op));
+    const int M = s.B * s.IH * s.IW, K = s.KH * s.KH * s.Cin;
+    const int ldc = s.lnglu ? s.N / 2 : s.N;
+    op.code = AED_OP_CONV_GEMM;
+    op.flags = flags;
+    int32_t* i = op.i;
+    i[0] = M; i[1] = s.N; i[2] = K; i[3] = s.Cin; i[4] = ldc; i[5] = ldc; i[6] = 0;
+    i[7] = s.IH; i[8] = s.IW; i[9] = s.IH; i[10] = s.IW; i[11] = s.Cin; i[12] = s.KH; i[13] = s.KH;
+    i[14] = 1; i[15] = s.KH / 2; i[16] = s.KH / 2; i[17] = 1; i[18] = 1; i[19] = 0;
+    i[20] = s.IH * s.IW * s.Cin;                       // a_bs
+    i[21] = 1; i[22] = 0; i[23] = s.IH * s.IW; i[24] = s.IH * s.IW;      // o_mul, o_add, o_len, out_bs
+    i[28] = 1; i[29] = tile;
+    i[31] = s.lnglu ? 1 : 0;
+    i[35] = s.lnglu ? 1 : 0;
+    op.f[3] = 1e-5f;
+    op.p[0] = d.A; op.p[1] = d.W; op.p[2] = d.bias; op.p[3] = C;
+    op.p[4] = (s.res && !s.lnglu) ? d.res : nullptr;
+    op.p[5] = s.lnglu ? d.rowvec : nullptr;
+}
+
+static float time_op(const aed_op& op, hipStream_t st, int iters, bool* ok) {
+    hipEvent_t e0, e1;
+    HIPCHECK(hipEventCreate(&e0));
+    HIPCHECK(hipEventCreate(&e1));
+    for (int k = 0; k < 3; ++k)
+        if (aed_launch(&op, st)) { fprintf(stderr, "launch failed: %s\n", aed_last_error()); *ok = false; return 0.f; }
+    HIPCHECK(hipStreamSynchronize(st));
+    HIPCHECK(hipEventRecord(e0, st));
+    for (int k = 0; k < iters; ++k) aed_launch(&op, st);
+    HIPCHECK(hipEventRecord(e1, st));
+    HIPCHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    *ok = true;
+    return ms / iters;
+}
+
+int main(int argc, char** argv) {
+    const int iters = argc > 1 ? atoi(argv[1]) : 10;
+    const Shape shapes[] = {
+        {"conv3x3 200x(64x16) 256->256", 200, 64, 16, 256, 256, 3, 1, 0},
+        {"conv3x3 200x(32x8) 640->640", 200, 32, 8, 640, 640, 3, 0, 0},
+        {"conv3x3 200x(256x16) 128->128", 200, 256, 16, 128, 128, 3, 0, 0},
+        {"linear 204800 x 256 -> 768 (qkv)", 200, 64, 16, 256, 768, 1, 0, 0},
+        {"linear 204800 x 256 -> 2048 LN+GEGLU (FF1)", 200, 64, 16, 256, 2048, 1, 0, 1},
+        {"linear 12800 x 640 -> 5120 LN+GEGLU (FF1)", 200, 8, 8, 640, 5120, 1, 0, 1},
+        {"linear 51200 x 384 -> 384 (to_out)", 200, 32, 8, 384, 384, 1, 1, 0},
+    };
+    int cus = 0, lds = 0;
+    char arch[64] = "";
+    aed_device_info(&cus, &lds, arch, sizeof(arch));
+    fprintf(stderr, "device %s, %d CUs, ABI v%d\n", arch, cus, aed_version());
+    hipStream_t st;
+    HIPCHECK(hipStreamCreate(&st));
+
+    for (const Shape& s : shapes) {
+        const int M = s.B * s.IH * s.IW, K = s.KH * s.KH * s.Cin, N = s.N;
+        const int ldc = s.lnglu ? N / 2 : N;
+        const size_t nA = (size_t)M * s.Cin, nW = (size_t)N * K, nC = (size_t)M * ldc;
+        std::vector<float> hA(nA), hW(nW), hb(N), hrv(N);
+        std::vector<float> cs(s.Cin);
+        for (int c = 0; c < s.Cin; ++c) cs[c] = expf(1.2f * nrand());          // per-channel scales: mixed magnitudes
+        for (size_t e = 0; e < nA; ++e) hA[e] = nrand() * cs[e % s.Cin];
+        const float wsc = 1.0f / sqrtf((float)K);
+        for (size_t e = 0; e < nW; ++e) hW[e] = nrand() * wsc;
+        for (int n = 0; n < N; ++n) {
+            hb[n] = 0.1f * nrand();
+            double sum = 0.0;
+            for (int k = 0; k < K; ++k) sum += hW[(size_t)n * K + k];
+            hrv[n] = (float)sum;
+        }
+        Dev d;
+        HIPCHECK(hipMalloc(&d.A, nA * 4));
+        HIPCHECK(hipMalloc(&d.W, nW * 4));
+        HIPCHECK(hipMalloc(&d.bias, N * 4));
+        HIPCHECK(hipMalloc(&d.rowvec, N * 4));
+        HIPCHECK(hipMalloc(&d.res, nC * 4));
+        HIPCHECK(hipMalloc(&d.C0, nC * 4));
+        HIPCHECK(hipMalloc(&d.C1, nC * 4));
+        HIPCHECK(hipMemcpy(d.A, hA.data(), nA * 4, hipMemcpyHostToDevice));
+        HIPCHECK(hipMemcpy(d.W, hW.data(), nW * 4, hipMemcpyHostToDevice));
+        HIPCHECK(hipMemcpy(d.bias, hb.data(), N * 4, hipMemcpyHostToDevice));
+        HIPCHECK(hipMemcpy(d.rowvec, hrv.data(), N * 4, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(fill_hash, dim3(2048), dim3(256), 0, st, d.res, nC);
+        HIPCHECK(hipStreamSynchronize(st));
+
+        // fp64 host reference on sampled outputs (plain epilogue shapes only)
+        const int NS = 512;
+        std::vector<int> sm(NS), sn(NS);
+        std::vector<double> sref(NS);
+        if (!s.lnglu) {
+            for (int q = 0; q < NS; ++q) {
+                const int m = (int)((urand() * 0.5f + 0.5f) * (M - 1)), n = (int)((urand() * 0.5f + 0.5f) * (N - 1));
+                sm[q] = m; sn[q] = n;
+                const int b = m / (s.IH * s.IW), r = m % (s.IH * s.IW), oy = r / s.IW, ox = r % s.IW;
+                double acc = 0.0;
+                for (int ty = 0; ty < s.KH; ++ty)
+                    for (int tx = 0; tx < s.KH; ++tx) {
+                        const int iy = oy + ty - s.KH / 2, ix = ox + tx - s.KH / 2;
+                        if (iy < 0 || iy >= s.IH || ix < 0 || ix >= s.IW) continue;
+                        const float* a = &hA[((size_t)(b * s.IH + iy) * s.IW + ix) * s.Cin];
+                        const float* w = &hW[(size_t)n * K + (size_t)(ty * s.KH + tx) * s.Cin];
+                        for (int c = 0; c < s.Cin; ++c) acc += (double)a[c] * (double)w[c];
+                    }
+                acc += hb[n];
+                if (s.res) acc += hash_unit((uint64_t)m * ldc + n);
+                sref[q] = acc;
+            }
+        }
+        std::vector<unsigned long long> hidx(NS);
+        for (int q = 0; q < NS; ++q) hidx[q] = (unsigned long long)sm[q] * ldc + sn[q];
+        unsigned long long* d_idx;
+        float* d_smp;
+        double* d_acc;
+        unsigned* d_max;
+        HIPCHECK(hipMalloc(&d_idx, NS * 8));
+        HIPCHECK(hipMalloc(&d_smp, NS * 4));
+        HIPCHECK(hipMalloc(&d_acc, 16));
+        HIPCHECK(hipMalloc(&d_max, 4));
+        HIPCHECK(hipMemcpy(d_idx, hidx.data(), NS * 8, hipMemcpyHostToDevice));
+        auto sample_err = [&](const float* C) {
+            std::vector<float> got(NS);
+            hipLaunchKernelGGL(gather_kernel, dim3((NS + 255) / 256), dim3(256), 0, st, C, d_idx, d_smp, NS);
+            HIPCHECK(hipStreamSynchronize(st));
+            HIPCHECK(hipMemcpy(got.data(), d_smp, NS * 4, hipMemcpyDeviceToHost));
+            double num = 0.0, den = 0.0;
+            for (int q = 0; q < NS; ++q) {
+                const double dv = (double)got[q] - sref[q];
+                num += dv * dv; den += sref[q] * sref[q];
+            }
+            return sqrt(num / den);
+        };
+
+        const double flops = 2.0 * M * (double)N * K;
+        aed_op op;
+        bool ok = false;
+        fill_op(op, s, d, d.C0, 0, 1);
+        const float ms0 = time_op(op, st, iters, &ok);
+        const double e0 = s.lnglu ? -1.0 : sample_err(d.C0);
+        printf("{\"shape\": \"%s\", \"M\": %d, \"N\": %d, \"K\": %d, \"variant\": \"fp32 mfma tile 1\", \"ok\": %s, \"us\": %.1f, "
+               "\"tflops\": %.1f, \"rel_l2_vs_fp64_sample\": %.3e}\n",
+               s.name, M, N, K, ok ? "true" : "false", ms0 * 1e3, flops / (ms0 * 1e-3) * 1e-12, e0);
+        fflush(stdout);
+        const int variants[][2] = {{1, 4}, {1, 12}, {8, 4}, {8, 12}, {9, 4}, {3, 4}, {1, 20}, {8, 20}};      // {tile, flags}
+        for (const auto& v : variants) {
+            if (s.lnglu && v[1] != 4) continue;         // the non-PLAIN kernels exist in the product form only
+            HIPCHECK(hipMemset(d.C1, 0xff, nC * 4));
+            fill_op(op, s, d, d.C1, v[1], v[0]);
+            const float ms1 = time_op(op, st, iters, &ok);
+            double num = 0.0, den = 1.0, mx = 0.0, e1 = -1.0;
+            if (ok) {
+                HIPCHECK(hipMemsetAsync(d_acc, 0, 16, st));
+                HIPCHECK(hipMemsetAsync(d_max, 0, 4, st));
+                hipLaunchKernelGGL(compare_kernel, dim3(2048), dim3(256), 0, st, d.C1, d.C0, nC, d_acc, d_max);
+                HIPCHECK(hipStreamSynchronize(st));
+                double acc2[2];
+                unsigned mb = 0;
+                HIPCHECK(hipMemcpy(acc2, d_acc, 16, hipMemcpyDeviceToHost));
+                HIPCHECK(hipMemcpy(&mb, d_max, 4, hipMemcpyDeviceToHost));
+                num = acc2[0]; den = acc2[1];
+                float mf;
+                memcpy(&mf, &mb, 4);
+                mx = mf;
+                if (!s.lnglu) e1 = sample_err(d.C1);
+            }
+            printf("{\"shape\": \"%s\", \"M\": %d, \"N\": %d, \"K\": %d, \"variant\": \"x6 tile %d%s\", \"ok\": %s, \"us\": %.1f, "
+                   "\"tflops\": %.1f, \"speedup_vs_fp32\": %.2f, \"rel_l2_vs_fp32_kernel\": %.3e, \"max_abs_diff\": %.3e, "
+                   "\"rel_l2_vs_fp64_sample\": %.3e}\n",
+                   s.name, M, N, K, v[0], v[1] == 12 ? " sched" : (v[1] == 20 ? " x3-diagnostic" : ""), ok ? "true" : "false", ms1 * 1e3,
+                   ok ? flops / (ms1 * 1e-3) * 1e-12 : 0.0, ok ? ms0 / ms1 : 0.0, ok ? sqrt(num / den) : -1.0, mx, e1);
+            fflush(stdout);
+        }
+        hipFree(d_idx); hipFree(d_smp); hipFree(d_acc); hipFree(d_max);
+        hipFree(d.A); hipFree(d.W); hipFree(d.bias); hipFree(d.rowvec); hipFree(d.res); hipFree(d.C0); hipFree(d.C1);
+    }
+    return 0;
+}

@@ -1,26 +1,37 @@
 // conv_gemm_x6.hip -- the implicit-GEMM convolution / linear layer of conv_gemm.hip with SPLIT-BF16 arithmetic.
 //
-// EXPERIMENTAL (round 3): selected per op by flag bit 2 of an AED_OP_CONV_GEMM record (include/aed.h); nothing on the
-// product path sets it yet.  Same record, same operands, same epilogue -- only the contraction differs.
+// EXPERIMENTAL (round 3): selected per op by flag bit 2 of an AED_OP_CONV_GEMM record (include/aed.h); only tapes built under
+// tape.arith_mode("bf16x6") set it, no default path does.  Same record, same operands, same epilogue -- only the
+// contraction differs.
 //
 // Why: the fp32-input MFMA (v_mfma_f32_32x32x2_f32) runs at the fp32 VECTOR rate, 1/16 of the bf16 MFMA
 // (MI355X_MICROARCH.md: 157 TF vs 2.5 PF).  An fp32 value is exactly the sum of three bf16 values (24 significand bits
 // = 3 x 8): a = a0 + a1 + a2, |a1| <= 2^-8 |a|, |a2| <= 2^-16 |a|.  A product a*b is then the sum of nine piece products
 // a_i*b_j, each EXACT in fp32 (8 x 8 bits), of relative size 2^-8(i+j).  Keeping the six with i+j <= 2 drops terms below
-// 2^-23 |a||b| -- under the rounding of the fp32 accumulation itself (tools/bf16_split_study.py: vs fp64 the six-term sum
-// is as close as a plain fp32 GEMM, 1.3e-7 .. 3.5e-7 rel L2 at K = 320 .. 5760; x9 brings nothing over x6).  Six
-// v_mfma_f32_32x32x16_bf16 (32 cycles each per SIMD) replace eight v_mfma_f32_32x32x2_f32 (64 cycles each) per 16 k:
-// 192 vs 512 matrix-pipe cycles, a 2.67x higher roof (419 TF/s fp32-equivalent) for the same fp32 operands in HBM.
+// 2^-23 |a||b| -- under the rounding of the fp32 accumulation itself (tools/bf16_split_study.py on the CPU and
+// profiles/r03_x6_gemm.md on the GPU: vs fp64 the six-term result is as close as -- in fact slightly closer than -- the
+// fp32-MFMA kernel's).  Six v_mfma_f32_32x32x16_bf16 (32 cycles each per SIMD) replace eight v_mfma_f32_32x32x2_f32 (64
+// cycles each) per 16 k: 192 vs 512 matrix-pipe cycles, a 2.67x higher roof (419 TF/s fp32-equivalent) for the same fp32
+// operands in HBM.  Measured at the U-Net's batch-200 shapes: 1.45-1.8x over conv_gemm.hip (180-210 TF/s, above the fp32
+// MFMA peak); the kernel is then at ~44 % of the bf16 MFMA rate, the range of HIP-level bf16 GEMMs on this chip.
 //
-// Data path: operands stay fp32 in HBM (no second copy of weights or activations).  The loader threads split each
-// float4 they fetched into three packed-bf16 pieces (v_cvt_pk_bf16_f32, RNE; 4.5 VALU per element) while writing the
-// LDS stage.  LDS row = [hi 16 k | mid 16 k | lo 16 k | 16 B pad] = 112 B: the fragment read of one piece is one
-// ds_read_b128 per lane (8 consecutive k), conflict-free with this stride (28 dwords: the 16 rows of a b128 lane group
-// land on 16 distinct 4-bank windows).  A and W use the same k -> (lane half, element) map, so the result does not depend
-// on the instruction's internal k order; the C/D map is the one of the fp32 32x32 MFMA (conv_gemm.hip's epilogue).
+// Data path: operands stay fp32 in HBM (no second copy of weights or activations).  Loads are buffer loads: a lane whose
+// element does not exist (conv zero padding, rows past M / N, a chunk past the block's k range) gets offset X6_OOB and
+// the hardware returns 0 -- no masks or selects on the data.  The loader threads split each float4 into three packed-bf16
+// pieces (v_cvt_pk_bf16_f32 RNE + scalar subtractions: 5.5 VALU per element; v_pk_add_f32 issues badly beside MFMAs) while
+// writing the LDS stage.  LDS row = [hi 16 k | mid 16 k | lo 16 k | 16 B pad] = 112 B: the fragment read of one piece is
+// one ds_read_b128 per lane (8 consecutive k), conflict-free with this stride (28 dwords: the 16 rows of a b128 lane
+// group land on 16 distinct 4-bank windows).  A and W use the same k -> (lane half, element) map, so the result does not
+// depend on the instruction's internal k order; the C/D map is the one of the fp32 32x32 MFMA (conv_gemm.hip's epilogue).
 //
 // Pipeline (as conv_gemm.hip): two LDS stages, chunk k+1 is split + written to the other stage while the MFMAs of
 // chunk k run, one barrier per chunk, DEPTH further chunks in flight in registers.  A chunk is 16 k = one bf16 k-block.
+// The chunk body is ONE basic block (branch-free address arithmetic, trip count rounded up to DEPTH with zero chunks), and
+// VALU-only sched_group_barrier hints spread the split between the MFMAs (+3-4 % measured).
+//
+// Tried and dropped (profiles/r03_x6_gemm.md): 256x256 / 256x128 tiles with ONE wave per SIMD and the accumulators in
+// AGPRs (4x slower as compiled), a row-permuted loader for conflict-free ds_write_b64 (-4 %), LDS-write / VMEM groups in
+// the hints (the solver gives up), packed subtractions (-10 %), flat loads with LDS-side zero masking (-3 %).
 #include "cg_params.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -32,14 +43,33 @@ int launch_conv_gemm_x6(const aed_op* op, hipStream_t s);
 constexpr int X6_BK = 16;           // fp32 k per chunk
 constexpr int X6_ROWQ = 7;          // uint4 (16 B) per LDS row: 3 pieces x 2 + 1 pad
 
-// (x0, x1) -> packed bf16 pieces {hi, mid, lo}; x == hi + mid + lo exactly (element 0 in the low half)
+// (x0, x1) -> packed bf16 pieces {hi, mid, lo}; x == hi + mid + lo exactly (element 0 in the low half).  Scalar subtractions:
+// v_pk_add_f32 issues badly next to MFMAs (MI355X_MICROARCH.md, filler prices; measured -10 %)
 __device__ __forceinline__ void x6_split_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
-    const f32x2 x = {x0, x1};
-    h = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));
-    const f32x2 r = {x0 - __uint_as_float(h << 16), x1 - __uint_as_float(h & 0xffff0000u)};
-    m = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
-    const f32x2 q = {r[0] - __uint_as_float(m << 16), r[1] - __uint_as_float(m & 0xffff0000u)};
-    l = __builtin_bit_cast(unsigned, __builtin_convertvector(q, bf16x2));
+    h = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){x0, x1}, bf16x2));
+    float r0 = x0 - __uint_as_float(h << 16);
+    float r1 = x1 - __uint_as_float(h & 0xffff0000u);
+    asm volatile("" : "+v"(r0), "+v"(r1));              // keep the two subtractions scalar (no SLP packing)
+    m = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){r0, r1}, bf16x2));
+    float q0 = r0 - __uint_as_float(m << 16);
+    float q1 = r1 - __uint_as_float(m & 0xffff0000u);
+    asm volatile("" : "+v"(q0), "+v"(q1));
+    l = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){q0, q1}, bf16x2));
+}
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned X6_OOB = 0x80000000u;        // byte offset past every buffer (num_records 0x7ffffff0): the load returns 0
+
+// Compile-time interleave request for one chunk body: NM MFMAs with NV VALU instructions spread evenly between them
+// (sched_group_barrier wants immediates, hence the recursion).
+template <int G, int NM, int NV>
+__device__ __forceinline__ void x6_hints() {
+    if constexpr (G < NM) {
+        constexpr int v = (NV * (G + 1)) / NM - (NV * G) / NM;
+        if constexpr (v > 0) __builtin_amdgcn_sched_group_barrier(0x002, v, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        x6_hints<G + 1, NM, NV>();
+    }
 }
 
 // SCHED: 0 = leave the instruction order to the compiler; 1 = ask for MFMA / VALU / DS interleave in the main loop
@@ -124,15 +154,21 @@ __global__ __launch_bounds__(64 * WROWS * WCOLS, 2) void conv_gemm_x6_kernel(CGP
     }
 
     float4 rbuf_a[DEPTH][PA], rbuf_b[DEPTH][PB];
-    unsigned rmask[DEPTH];
     float ln_s1[PA], ln_s2[PA];
 #pragma unroll
     for (int q = 0; q < PA; ++q) { ln_s1[q] = 0.f; ln_s2[q] = 0.f; }
 
-    // Branch-free on purpose: the whole chunk body (split of chunk k+1, loads of chunk k+1+DEPTH, MFMAs of chunk k) is ONE basic
-    // block, so the scheduler may put VALU / LDS / VMEM work into the shadow of the MFMAs.
-    auto prefetch = [&](int kc, float4 (&ra)[PA], float4 (&rb)[PB], unsigned& mask) {
-        const int k0 = min(kc, p.nchunks - 1) * X6_BK;      // dead prefetches past the end stay in bounds
+    // Buffer descriptors over "everything below 2 GB" (the launcher checks the operands fit): an offset of X6_OOB is out of
+    // range and reads 0.  Branch-free on purpose: the whole chunk body (split of chunk k+1, loads of chunk k+1+DEPTH, MFMAs
+    // of chunk k) is ONE basic block, so VALU / LDS / VMEM work can sit in the shadow of the MFMAs.
+    const __amdgpu_buffer_rsrc_t srd_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7ffffff0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_a2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A2 ? p.A2 : p.A), 0, 0x7ffffff0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7ffffff0, 0x00020000);
+    auto as_f4 = [](u32x4 v) {
+        return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    };
+    auto prefetch = [&](int kc, float4 (&ra)[PA], float4 (&rb)[PB]) {
+        const int k0 = kc * X6_BK;
         int c0 = pf_c0;
         const int dy = pf_ty * p.dil_h, dx = pf_tx * p.dil_w;
         pf_c0 += X6_BK;
@@ -143,24 +179,22 @@ __global__ __launch_bounds__(64 * WROWS * WCOLS, 2) void conv_gemm_x6_kernel(CGP
         pf_tx = wrap2 ? 0 : pf_tx;
         pf_ty += wrap2 ? 1 : 0;
         const bool second = p.C1 > 0 && c0 >= p.C1;         // two-source A: block-uniform select per chunk
-        const float* src = second ? p.A2 : p.A;
-        const unsigned ld = second ? (unsigned)p.lda2 : (unsigned)p.lda;
         c0 -= second ? p.C1 : 0;
-        unsigned mk = 0;
+        const unsigned ld = second ? (unsigned)p.lda2 : (unsigned)p.lda;
+        // a chunk past this block's k range, an out-of-image tap, a row past M or N: the lane's offset is X6_OOB
+        const bool dead = kc >= kc_end;
 #pragma unroll
         for (int q = 0; q < PA; ++q) {
             const int iy = ay0[q] + dy, ix = ax0[q] + dx;
-            const bool ok = avalid[q] & ((unsigned)iy < (unsigned)vIH) & ((unsigned)ix < (unsigned)vIW);
-            const unsigned okm = ok ? 0xffffffffu : 0u;
-            // out-of-image taps read element lcol of the tensor (always valid); the zero padding is applied at the LDS write
+            const bool ok = avalid[q] & ((unsigned)iy < (unsigned)vIH) & ((unsigned)ix < (unsigned)vIW) & !dead;
             const unsigned base = second ? abase2[q] : abase[q];
-            const unsigned off = base + (unsigned)((iy >> p.up) * p.IW + (ix >> p.up)) * ld + (unsigned)c0;
-            ra[q] = *reinterpret_cast<const float4*>(src + ((off & okm) | ((unsigned)lcol & ~okm)));
-            mk |= okm & (1u << q);
+            const unsigned off = (base + (unsigned)((iy >> p.up) * p.IW + (ix >> p.up)) * ld + (unsigned)c0) * 4u;
+            ra[q] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(second ? srd_a2 : srd_a, ok ? off : X6_OOB, 0, 0));
         }
-        mask = mk;
 #pragma unroll
-        for (int q = 0; q < PB; ++q) rb[q] = *reinterpret_cast<const float4*>(p.W + wbase[q] + k0);
+        for (int q = 0; q < PB; ++q)
+            rb[q] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(
+                srd_w, (wvalid[q] & !dead) ? (wbase[q] + (unsigned)k0) * 4u : X6_OOB, 0, 0));
     };
 
     // one fetched float4 -> three 8-byte piece groups of its LDS row
@@ -174,19 +208,16 @@ __global__ __launch_bounds__(64 * WROWS * WCOLS, 2) void conv_gemm_x6_kernel(CGP
         dst[8] = make_uint2(l0, l1);
     };
 
-    // live == false: the chunk does not exist (past the end of this block's k range) -> the stage is written as zeros
-    auto stage_write = [&](uint4* st, const float4 (&ra)[PA], const float4 (&rb)[PB], unsigned mask, bool live) {
-        mask = live ? mask : 0u;
+    auto stage_write = [&](uint4* st, const float4 (&ra)[PA], const float4 (&rb)[PB]) {
 #pragma unroll
         for (int q = 0; q < PA; ++q) {
             float4 v = ra[q];
-            if (!((mask >> q) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
             if constexpr (!PLAIN) {
                 if (p.ln_mode) {
                     ln_s1[q] += (v.x + v.y) + (v.z + v.w);
                     ln_s2[q] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
                 }
-                if (p.in_act) {
+                if (p.in_act) {         // SiLU / LeakyReLU of the A operand; f(0) = 0 keeps the zero padding
                     v.x = in_transform(v.x, p.in_act, p.in_slope);
                     v.y = in_transform(v.y, p.in_act, p.in_slope);
                     v.z = in_transform(v.z, p.in_act, p.in_slope);
@@ -196,8 +227,7 @@ __global__ __launch_bounds__(64 * WROWS * WCOLS, 2) void conv_gemm_x6_kernel(CGP
             put_row(st, lrow + RPP * q, v);
         }
 #pragma unroll
-        for (int q = 0; q < PB; ++q)
-            put_row(st, BM + lrow + RPP * q, (wvalid[q] && live) ? rb[q] : make_float4(0.f, 0.f, 0.f, 0.f));
+        for (int q = 0; q < PB; ++q) put_row(st, BM + lrow + RPP * q, rb[q]);
     };
 
     f32x16 acc[TM][TN];
@@ -240,13 +270,13 @@ __global__ __launch_bounds__(64 * WROWS * WCOLS, 2) void conv_gemm_x6_kernel(CGP
     };
 
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) prefetch(kc_begin + d, rbuf_a[d], rbuf_b[d], rmask[d]);
-    stage_write(lds, rbuf_a[0], rbuf_b[0], rmask[0], true);
-    prefetch(kc_begin + DEPTH, rbuf_a[0], rbuf_b[0], rmask[0]);
+    for (int d = 0; d < DEPTH; ++d) prefetch(kc_begin + d, rbuf_a[d], rbuf_b[d]);
+    stage_write(lds, rbuf_a[0], rbuf_b[0]);
+    prefetch(kc_begin + DEPTH, rbuf_a[0], rbuf_b[0]);
     __syncthreads();
     int cur = 0;
     // The trip count is rounded up to a multiple of DEPTH (static register slots, no exit inside the unrolled body): a chunk
-    // past kc_end is staged as zeros and its MFMAs add nothing.  Per iteration, in program order: fragment reads of chunk kc
+    // past kc_end was loaded as zeros and its MFMAs add nothing.  Per iteration, in program order: fragment reads of chunk kc
     // (stage cur) -> split + LDS write of chunk kc+1 (other stage) -> loads of chunk kc+1+DEPTH -> MFMAs of chunk kc -> barrier.
     for (int kc0 = kc_begin; kc0 < kc_end; kc0 += DEPTH) {
 #pragma unroll
@@ -254,20 +284,15 @@ __global__ __launch_bounds__(64 * WROWS * WCOLS, 2) void conv_gemm_x6_kernel(CGP
             const int kc = kc0 + d;
             const int sl = (d + 1) % DEPTH;     // chunk kc+1 sits in this register slot
             load_frags(lds + cur * STAGE);
-            stage_write(lds + (cur ^ 1) * STAGE, rbuf_a[sl], rbuf_b[sl], rmask[sl], kc + 1 < kc_end);
-            prefetch(kc + 1 + DEPTH, rbuf_a[sl], rbuf_b[sl], rmask[sl]);
+            stage_write(lds + (cur ^ 1) * STAGE, rbuf_a[sl], rbuf_b[sl]);
+            prefetch(kc + 1 + DEPTH, rbuf_a[sl], rbuf_b[sl]);
             do_mfmas();
             if constexpr (SCHED == 1) {
-                // one wave per SIMD hides ~5 single-issue instructions per 32-cycle MFMA: spread the split of chunk kc+1
-                // (4.5 VALU per element), its LDS writes and the next loads between the MFMAs of chunk kc
+                // a wave hides ~5 single-issue instructions per 32-cycle MFMA: spread the split of chunk kc+1 (5.5 VALU per
+                // element + addresses) between the MFMAs of chunk kc.  VALU groups only: asking for LDS-write / load groups as
+                // well makes the solver give up and emit all VALU first.
                 constexpr int NM = TM * TN * NTERMS;
-#pragma unroll
-                for (int g = 0; g < NM; ++g) {
-                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                      // 4 VALU
-                    if (g % 3 == 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // 1 DS write
-                    if (g % 6 == 5) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 1 VMEM read
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                      // 1 MFMA
-                }
+                x6_hints<0, NM, NM * (((PA + PB) * 22 + 40 + NM - 1) / NM)>();
             }
             __syncthreads();
             cur ^= 1;
@@ -416,31 +441,41 @@ __global__ __launch_bounds__(64 * WROWS * WCOLS, 2) void conv_gemm_x6_kernel(CGP
         }
 }
 
-template <int BM, int BN, int WR, int WC, int DEPTH>
-static void x6_launch(const CGParams& p, bool plain, int sched, int terms, hipStream_t s) {
+template <int BM, int BN, int WR, int WC, int DEPTH, bool DIAG>
+static int x6_launch(const CGParams& p, bool plain, int sched, int terms, hipStream_t s) {
     dim3 grid(aed_cdiv(p.N, BN), aed_cdiv(p.M, BM), p.ksplit);
     dim3 block(64 * WR * WC);
-    if (plain) {
-        if (terms == 3) hipLaunchKernelGGL((conv_gemm_x6_kernel<BM, BN, WR, WC, DEPTH, true, 0, 3>), grid, block, 0, s, p);
-        else if (sched) hipLaunchKernelGGL((conv_gemm_x6_kernel<BM, BN, WR, WC, DEPTH, true, 1, 6>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((conv_gemm_x6_kernel<BM, BN, WR, WC, DEPTH, true, 0, 6>), grid, block, 0, s, p);
-    } else {
-        hipLaunchKernelGGL((conv_gemm_x6_kernel<BM, BN, WR, WC, DEPTH, false, 0, 6>), grid, block, 0, s, p);
+#define X6_GO(PL, SC, NT_) hipLaunchKernelGGL((conv_gemm_x6_kernel<BM, BN, WR, WC, DEPTH, PL, SC, NT_>), grid, block, 0, s, p)
+    if (terms == 3) {
+        if constexpr (DIAG) {
+            if (plain) { X6_GO(true, 1, 3); return 0; }
+        }
+        AED_REQUIRE(false, "conv_gemm_x6: the three-term diagnostic exists for tiles 1 and 8 with a plain A operand");
     }
+    if (!plain) X6_GO(false, 1, 6);
+    else if (sched) X6_GO(true, 1, 6);
+    else X6_GO(true, 0, 6);
+#undef X6_GO
+    return 0;
 }
 
-// Tile codes (i[29]): 1 = 128x128, 2 = 128x64, 3 = 64x128, 4 = 64x64 (256 threads); 8 = 256x128, 9 = 128x256 (512 threads:
-// one workgroup per CU, two waves per SIMD).  0 = pick.  Shapes this kernel does not take (channel counts that are not a
-// multiple of 16, unaligned operands, the latency-regime tiles >= 10, per-batch weights / grouped softmax) run the fp32 path.
-// Flag bit 3 (8): ask the compiler for the MFMA / VALU / DS-write interleave (A/B switch of the experiment).
-// Flag bit 4 (16): DIAGNOSTIC three-term arithmetic (plain epilogue shapes only).
+// Tile codes (i[29]): 1 = 128x128, 2 = 128x64, 3 = 64x128, 4 = 64x64 (256 threads, two workgroups per CU); 8 = 256x128,
+// 9 = 128x256 (512 threads: one workgroup per CU, two waves per SIMD).  0 = pick.  Shapes this kernel does not take (channel
+// counts that are not a multiple of 16, unaligned or > 2 GB operands, the skinny tiles 5 / 6, the latency-regime tiles >= 10,
+// per-batch weights / grouped softmax) run the fp32 path.
+// Flag bit 3 (8): WITHOUT it the compiler orders the chunk body itself (A/B switch; tapes set it).
+// Flag bit 4 (16): DIAGNOSTIC three-term arithmetic (~4e-6 rel error; tells how much of the kernel time is matrix-pipe time).
 int launch_conv_gemm_x6(const aed_op* op, hipStream_t s) {
     const int32_t* i = op->i;
     const int Cin = i[11];
     int cfg = i[29];
+    const long long batch = i[0] / (i[9] * i[10] > 0 ? i[9] * i[10] : 1);
     const bool fits = (Cin % X6_BK == 0) && (i[3] % 4 == 0) && ((uintptr_t)op->p[0] % 16 == 0) &&
-                      ((uintptr_t)op->p[1] % 16 == 0) && cfg < 10 && cfg != 5 && cfg != 6 && i[36] == 0 && i[37] == 0 &&
-                      i[39] == 0;
+                      ((uintptr_t)op->p[1] % 16 == 0) && cfg < 10 && cfg != 5 && cfg != 6 && cfg != 7 && i[36] == 0 &&
+                      i[37] == 0 && i[39] == 0 &&
+                      // buffer loads address bytes below 2 GB of every operand
+                      batch * i[20] + (long long)i[7] * i[8] * i[3] < (1LL << 29) && (long long)i[1] * i[2] < (1LL << 29) &&
+                      (i[32] == 0 || batch * i[34] + (long long)i[7] * i[8] * i[33] < (1LL << 29));
     if (!fits) return launch_conv_gemm(op, s);
     CGParams p;
     int rc = cg_fill_params(op, p, X6_BK);
@@ -459,14 +494,15 @@ int launch_conv_gemm_x6(const aed_op* op, hipStream_t s) {
     const int terms = (op->flags & 16) ? 3 : 6;
     if (p.geglu) AED_REQUIRE(cfg == 1 || cfg == 3 || cfg == 8 || cfg == 9, "conv_gemm_x6: the GEGLU epilogue needs 64-wide wave tiles (cfg %d)", cfg);
     switch (cfg) {
-        case 1: x6_launch<128, 128, 2, 2, 2>(p, plain, sched, terms, s); break;
-        case 2: x6_launch<128, 64, 2, 2, 2>(p, plain, sched, terms, s); break;
-        case 3: x6_launch<64, 128, 2, 2, 2>(p, plain, sched, terms, s); break;
-        case 4: x6_launch<64, 64, 2, 2, 2>(p, plain, sched, terms, s); break;
-        case 8: x6_launch<256, 128, 4, 2, 2>(p, plain, sched, terms, s); break;
-        case 9: x6_launch<128, 256, 2, 4, 2>(p, plain, sched, terms, s); break;
+        case 1: rc = x6_launch<128, 128, 2, 2, 2, true>(p, plain, sched, terms, s); break;
+        case 2: rc = x6_launch<128, 64, 2, 2, 2, false>(p, plain, sched, terms, s); break;
+        case 3: rc = x6_launch<64, 128, 2, 2, 2, false>(p, plain, sched, terms, s); break;
+        case 4: rc = x6_launch<64, 64, 2, 2, 2, false>(p, plain, sched, terms, s); break;
+        case 8: rc = x6_launch<256, 128, 4, 2, 2, true>(p, plain, sched, terms, s); break;
+        case 9: rc = x6_launch<128, 256, 2, 4, 2, false>(p, plain, sched, terms, s); break;
         default: AED_REQUIRE(false, "conv_gemm_x6: bad tile cfg %d", cfg);
     }
+    if (rc) return rc;
     AED_CHECK_HIP(hipGetLastError());
     if (p.ksplit > 1) return launch_splitk_reduce(op, s);
     return 0;

@@ -40,11 +40,13 @@ enum aed_opcode {
     AED_OP_CONV_GEMM = 1,     /* implicit-GEMM conv / linear on fp32 MFMA (K5,K6,K11,K2,K3); optional two-source A
                                  (skip concat never materialised), fused LayerNorm, fused GEGLU gate (K8).
                                  flags bit 0: in-kernel timeline into p[7]; bit 1: late epilogue fetch (lin_gemm A/B);
-                                 bit 2 (EXPERIMENTAL, nothing on the product path sets it): contract on split-bf16
-                                 MFMAs -- every fp32 operand is cut exactly into three bf16 pieces in the loader and the
-                                 six piece products of relative size >= 2^-16 are accumulated in fp32
-                                 (csrc/conv_gemm_x6.hip; as close to fp64 as the fp32 chain, tools/bf16_split_study.py);
-                                 bit 3: with bit 2, request the MFMA / VALU interleave (A/B switch)              */
+                                 bit 2 (EXPERIMENTAL; set only by tapes built under tape.arith_mode("bf16x6")): contract on
+                                 split-bf16 MFMAs -- every fp32 operand is cut exactly into three bf16 pieces in the
+                                 loader and the six piece products of relative size >= 2^-16 are accumulated in fp32
+                                 (csrc/conv_gemm_x6.hip; as close to fp64 as the fp32 chain: tools/bf16_split_study.py,
+                                 profiles/r03_x6_gemm.md; shapes that kernel does not take run the fp32 path);
+                                 bit 3: with bit 2, interleave hints in the main loop (tapes set it; off = A/B);
+                                 bit 4: with bit 2, three-term DIAGNOSTIC arithmetic (~4e-6 rel error)            */
     AED_OP_GN_STATS = 2,      /* GroupNorm partial sums (K4)                                   */
     AED_OP_GN_APPLY = 3,      /* GroupNorm normalise + affine (+SiLU) (K4)                     */
     AED_OP_LAYERNORM = 4,     /* RETIRED in v4 (returns an error): LayerNorm is fused into the consuming GEMM (K8)  */

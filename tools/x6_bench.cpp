@@ -7,7 +7,7 @@
 //   audioeditingcode_amd/x6_bench [iters]           -> one JSON line per (shape, variant) on stdout
 //
 // Per shape: the same AED_OP_CONV_GEMM record is launched with flags = 0 (fp32 MFMA, tile 1 = 128x128) and with
-// flags = 4 (| 8) and tile codes 1 / 8 / 9 / 3.  Reported: average launch time over `iters` launches (HIP events on the
+// flags = 4 | 8 and tile codes 1 / 8 / 9 / 2 / 3 / 4 / 0 (launcher's pick).  Reported: average launch time over `iters` launches (HIP events on the
 // launch stream), TF/s of the algorithmic flops, rel L2 and max |diff| of the x6 result against the fp32 kernel's over
 // the whole output, and the rel L2 error of BOTH against an fp64 host reference on 512 sampled outputs.
 #include <hip/hip_runtime.h>
@@ -43,8 +43,9 @@ __host__ __device__ static inline float hash_unit(uint64_t e) {
     z ^= z >> 31;
     return (float)((int32_t)(z >> 32)) * (1.0f / 2147483648.0f);
 }
-__global__ void fill_hash(float* p, size_t n) {
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) p[e] = hash_unit(e);
+__global__ void fill_hash(float* p, size_t n, uint64_t seed = 0, float scale = 1.0f) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x)
+        p[e] = hash_unit(e + seed) * scale;
 }
 // out[0] += sum (a-b)^2, out[1] += sum b^2, *maxbits = max |a-b| (float bits; NaN differences make out[0] NaN)
 __global__ void compare_kernel(const float* a, const float* b, size_t n, double* out, unsigned* maxbits) {
@@ -123,6 +124,106 @@ static float time_op(const aed_op& op, hipStream_t st, int iters, bool* ok) {
     return ms / iters;
 }
 
+// ---- feature matrix: every loader / epilogue mode of the op record on small shapes, x6 against the fp32 kernel ------------
+struct Case {
+    const char* name;
+    int B, IH, IW, Cin, N, KH, KW, stride, pad_h, pad_w, dil_h, dil_w, up, OH, OW;
+    int C1;                 // two-source A: channels [0, C1) from A, the rest from A2
+    int in_act, out_act, res, rowvec, accumulate, ksplit, o_mul, o_add, tile;
+};
+
+static int run_case(const Case& c, hipStream_t st) {
+    const int M = c.B * c.OH * c.OW, K = c.KH * c.KW * c.Cin, N = c.N;
+    const int lda = c.C1 ? c.C1 : c.Cin, lda2 = c.Cin - c.C1;
+    const int o_len = c.OH * c.OW * c.o_mul, rows_out = c.B * o_len, ldc = N;
+    const size_t nA = (size_t)c.B * c.IH * c.IW * lda, nA2 = c.C1 ? (size_t)c.B * c.IH * c.IW * lda2 : 4, nW = (size_t)N * K;
+    const size_t nC = (size_t)rows_out * ldc, nws = (size_t)(c.ksplit > 1 ? c.ksplit : 1) * M * N;
+    float *A, *A2, *W, *bias, *res, *rv, *ws, *C0, *C1;
+    HIPCHECK(hipMalloc(&A, nA * 4)); HIPCHECK(hipMalloc(&A2, nA2 * 4)); HIPCHECK(hipMalloc(&W, nW * 4));
+    HIPCHECK(hipMalloc(&bias, N * 4)); HIPCHECK(hipMalloc(&res, nC * 4)); HIPCHECK(hipMalloc(&rv, (size_t)c.B * N * 4));
+    HIPCHECK(hipMalloc(&ws, nws * 4)); HIPCHECK(hipMalloc(&C0, nC * 4)); HIPCHECK(hipMalloc(&C1, nC * 4));
+    auto fill = [&](float* p, size_t n, uint64_t seed, float scale) {
+        hipLaunchKernelGGL(fill_hash, dim3(512), dim3(256), 0, st, p, n, seed, scale);
+    };
+    fill(A, nA, 1ull << 32, 2.0f); fill(A2, nA2, 2ull << 32, 2.0f); fill(W, nW, 3ull << 32, 1.7f / sqrtf((float)K));
+    fill(bias, N, 4ull << 32, 0.3f); fill(res, nC, 5ull << 32, 1.0f); fill(rv, (size_t)c.B * N, 6ull << 32, 0.5f);
+    fill(C0, nC, 7ull << 32, 1.0f); fill(C1, nC, 7ull << 32, 1.0f);       // identical previous contents (accumulate / scatter)
+    HIPCHECK(hipStreamSynchronize(st));
+    aed_op op;
+    memset(&op, 0, sizeof(op));
+    op.code = AED_OP_CONV_GEMM;
+    int32_t* i = op.i;
+    i[0] = M; i[1] = N; i[2] = K; i[3] = lda; i[4] = ldc; i[5] = ldc; i[6] = c.rowvec ? N : 0;
+    i[7] = c.IH; i[8] = c.IW; i[9] = c.OH; i[10] = c.OW; i[11] = c.Cin; i[12] = c.KH; i[13] = c.KW;
+    i[14] = c.stride; i[15] = c.pad_h; i[16] = c.pad_w; i[17] = c.dil_h; i[18] = c.dil_w; i[19] = c.up;
+    i[20] = c.IH * c.IW * lda; i[21] = c.o_mul; i[22] = c.o_add; i[23] = o_len; i[24] = o_len;
+    i[25] = c.in_act; i[26] = c.out_act; i[27] = c.accumulate; i[28] = c.ksplit;
+    i[32] = c.C1; i[33] = c.C1 ? lda2 : 0; i[34] = c.C1 ? c.IH * c.IW * lda2 : 0;
+    op.f[0] = 0.1f; op.f[1] = 0.1f; op.f[2] = 1.4142135f; op.f[3] = 1e-5f;
+    op.p[0] = A; op.p[1] = W; op.p[2] = bias; op.p[4] = c.res ? res : nullptr; op.p[5] = c.rowvec ? rv : nullptr;
+    op.p[6] = ws; op.p[8] = c.C1 ? A2 : nullptr;
+    // reference: the fp32 kernel with its own tile choice
+    op.flags = 0; i[29] = 0; op.p[3] = C0;
+    int rc0 = aed_launch(&op, st);
+    HIPCHECK(hipStreamSynchronize(st));
+    if (rc0) fprintf(stderr, "case %s fp32: %s\n", c.name, aed_last_error());
+    op.flags = 12; i[29] = c.tile; op.p[3] = C1;
+    int rc1 = aed_launch(&op, st);
+    hipError_t e = hipStreamSynchronize(st);
+    if (rc1) fprintf(stderr, "case %s x6: %s\n", c.name, aed_last_error());
+    double acc2[2] = {0, 1};
+    unsigned mb = 0;
+    if (!rc0 && !rc1 && e == hipSuccess) {
+        double* d_acc; unsigned* d_max;
+        HIPCHECK(hipMalloc(&d_acc, 16)); HIPCHECK(hipMalloc(&d_max, 4));
+        HIPCHECK(hipMemsetAsync(d_acc, 0, 16, st)); HIPCHECK(hipMemsetAsync(d_max, 0, 4, st));
+        hipLaunchKernelGGL(compare_kernel, dim3(256), dim3(256), 0, st, C1, C0, nC, d_acc, d_max);
+        HIPCHECK(hipStreamSynchronize(st));
+        HIPCHECK(hipMemcpy(acc2, d_acc, 16, hipMemcpyDeviceToHost));
+        HIPCHECK(hipMemcpy(&mb, d_max, 4, hipMemcpyDeviceToHost));
+        hipFree(d_acc); hipFree(d_max);
+    }
+    float mf; memcpy(&mf, &mb, 4);
+    const double rel = sqrt(acc2[0] / acc2[1]);
+    const bool pass = !rc0 && !rc1 && e == hipSuccess && rel < 5e-6;        // also false for NaN
+    printf("{\"case\": \"%s\", \"M\": %d, \"N\": %d, \"K\": %d, \"tile\": %d, \"rc_fp32\": %d, \"rc_x6\": %d, "
+           "\"rel_l2_vs_fp32_kernel\": %.3e, \"max_abs_diff\": %.3e, \"pass\": %s}\n",
+           c.name, M, N, K, c.tile, rc0, rc1, rel, (double)mf, pass ? "true" : "false");
+    fflush(stdout);
+    hipFree(A); hipFree(A2); hipFree(W); hipFree(bias); hipFree(res); hipFree(rv); hipFree(ws); hipFree(C0); hipFree(C1);
+    return pass ? 0 : 1;
+}
+
+static int run_feature_cases(hipStream_t st) {
+    //            name                               B  IH  IW  Cin   N KH KW st ph pw dh dw up  OH  OW  C1 ia oa res rv acc ks om oa tile
+    const Case cases[] = {
+        {"3x3 same, bias only",                      4, 32, 16,  64,  64, 3, 3, 1, 1, 1, 1, 1, 0, 32, 16,  0, 0, 0, 0, 0, 0, 1, 1, 0, 0},
+        {"3x3 stride 2 (downsample)",                4, 32, 16,  64, 128, 3, 3, 2, 1, 1, 1, 1, 0, 16,  8,  0, 0, 0, 0, 0, 0, 1, 1, 0, 0},
+        {"3x3 on a nearest-upsampled grid",          4, 16,  8,  64,  64, 3, 3, 1, 1, 1, 1, 1, 1, 32, 16,  0, 0, 0, 0, 0, 0, 1, 1, 0, 0},
+        {"3x3 two-source A (skip concat)",           4, 32, 16, 192, 128, 3, 3, 1, 1, 1, 1, 1, 0, 32, 16, 64, 0, 0, 0, 0, 0, 1, 1, 0, 0},
+        {"1x1 two-source A + residual",              4, 32, 16, 128, 128, 1, 1, 1, 0, 0, 1, 1, 0, 32, 16, 64, 0, 0, 1, 0, 0, 1, 1, 0, 1},
+        {"3x3 SiLU(A), + time row vector + res",     4, 32, 16,  64,  64, 3, 3, 1, 1, 1, 1, 1, 0, 32, 16,  0, 1, 0, 1, 1, 0, 1, 1, 0, 0},
+        {"linear, SiLU out",                         1, 2048, 1, 256, 256, 1, 1, 1, 0, 0, 1, 1, 0, 2048, 1, 0, 0, 1, 0, 0, 0, 1, 1, 0, 0},
+        {"linear, tanh out, tile 4",                 1, 1024, 1, 128, 192, 1, 1, 1, 0, 0, 1, 1, 0, 1024, 1, 0, 0, 3, 0, 0, 0, 1, 1, 0, 4},
+        {"3x3 split-K 4 (workspace + reduce)",       2, 16, 16, 256, 128, 3, 3, 1, 1, 1, 1, 1, 0, 16, 16,  0, 0, 0, 1, 0, 0, 4, 1, 0, 4},
+        {"3x3 split-K 3, odd chunk count",           2, 16, 16,  48, 128, 3, 3, 1, 1, 1, 1, 1, 0, 16, 16,  0, 0, 0, 0, 0, 0, 3, 1, 0, 2},
+        {"accumulate += (vocoder MRF)",              2,  1, 512, 64,  64, 1, 7, 1, 0, 9, 1, 3, 0,  1, 512, 0, 2, 0, 0, 0, 1, 1, 1, 0, 0},
+        {"accumulate (prev + v) / div",              2,  1, 512, 64,  64, 1, 3, 1, 0, 1, 1, 1, 0,  1, 512, 0, 2, 0, 0, 0, 2, 1, 1, 0, 0},
+        {"row scatter o_mul 2 o_add 1 (transposed)", 2,  1, 256, 64,  64, 1, 2, 1, 0, 1, 1, 1, 0,  1, 256, 0, 0, 0, 0, 0, 0, 1, 2, 1, 0},
+        {"ragged M = 1000, N = 72",                  5, 20, 10,  32,  72, 3, 3, 1, 1, 1, 1, 1, 0, 20, 10,  0, 0, 0, 1, 0, 0, 1, 1, 0, 0},
+        {"ragged, tile 1",                           5, 20, 10,  32, 136, 3, 3, 1, 1, 1, 1, 1, 0, 20, 10,  0, 0, 0, 0, 0, 0, 1, 1, 0, 1},
+        {"ragged, tile 8",                           5, 20, 10,  32, 136, 3, 3, 1, 1, 1, 1, 1, 0, 20, 10,  0, 0, 0, 0, 0, 0, 1, 1, 0, 8},
+        {"ragged, tile 9",                           5, 20, 10,  32, 136, 3, 3, 1, 1, 1, 1, 1, 0, 20, 10,  0, 0, 0, 0, 0, 0, 1, 1, 0, 9},
+        {"Cin = 16 (one chunk per tap)",             2, 16, 16,  16,  64, 3, 3, 1, 1, 1, 1, 1, 0, 16, 16,  0, 0, 0, 0, 0, 0, 1, 1, 0, 4},
+        {"Cin = 8 (falls back to the fp32 path)",    2, 16, 16,   8,  64, 3, 3, 1, 1, 1, 1, 1, 0, 16, 16,  0, 0, 0, 0, 0, 0, 1, 1, 0, 4},
+        {"dilated 3x3 (2,2), LeakyReLU(A)",          2, 24, 24,  64,  64, 3, 3, 1, 2, 2, 2, 2, 0, 24, 24,  0, 2, 0, 0, 0, 0, 1, 1, 0, 0},
+    };
+    int bad = 0;
+    for (const Case& c : cases) bad += run_case(c, st);
+    fprintf(stderr, "feature cases: %d of %d failed\n", bad, (int)(sizeof(cases) / sizeof(cases[0])));
+    return bad;
+}
+
 int main(int argc, char** argv) {
     const int iters = argc > 1 ? atoi(argv[1]) : 10;
     const Shape shapes[] = {
@@ -140,6 +241,8 @@ int main(int argc, char** argv) {
     fprintf(stderr, "device %s, %d CUs, ABI v%d\n", arch, cus, aed_version());
     hipStream_t st;
     HIPCHECK(hipStreamCreate(&st));
+    const int bad_cases = run_feature_cases(st);
+    if (argc > 2 && !strcmp(argv[2], "cases")) return bad_cases ? 1 : 0;
 
     for (const Shape& s : shapes) {
         const int M = s.B * s.IH * s.IW, K = s.KH * s.KH * s.Cin, N = s.N;
@@ -229,9 +332,11 @@ int main(int argc, char** argv) {
                "\"tflops\": %.1f, \"rel_l2_vs_fp64_sample\": %.3e}\n",
                s.name, M, N, K, ok ? "true" : "false", ms0 * 1e3, flops / (ms0 * 1e-3) * 1e-12, e0);
         fflush(stdout);
-        const int variants[][2] = {{1, 4}, {1, 12}, {8, 4}, {8, 12}, {9, 4}, {3, 4}, {1, 20}, {8, 20}};      // {tile, flags}
+        // {tile, flags}: 4 = split-bf16 contraction; | 8 = interleave hints (what tapes set); | 16 = three-term diagnostic
+        const int variants[][2] = {{1, 12}, {8, 12}, {9, 12}, {2, 12}, {3, 12}, {4, 12}, {0, 12}, {1, 4}, {8, 4}, {1, 28}, {8, 28}};
+        auto vname = [](int fl) { return fl == 12 ? "" : (fl == 4 ? " no-hints" : (fl == 28 ? " x3-diagnostic" : " ?")); };
         for (const auto& v : variants) {
-            if (s.lnglu && v[1] != 4) continue;         // the non-PLAIN kernels exist in the product form only
+            if (s.lnglu && (v[1] != 12 || v[0] == 2 || v[0] == 4)) continue;      // GEGLU needs 64-wide wave tiles       // the non-PLAIN kernels exist in the product forms only
             HIPCHECK(hipMemset(d.C1, 0xff, nC * 4));
             fill_op(op, s, d, d.C1, v[1], v[0]);
             const float ms1 = time_op(op, st, iters, &ok);
@@ -254,12 +359,12 @@ int main(int argc, char** argv) {
             printf("{\"shape\": \"%s\", \"M\": %d, \"N\": %d, \"K\": %d, \"variant\": \"x6 tile %d%s\", \"ok\": %s, \"us\": %.1f, "
                    "\"tflops\": %.1f, \"speedup_vs_fp32\": %.2f, \"rel_l2_vs_fp32_kernel\": %.3e, \"max_abs_diff\": %.3e, "
                    "\"rel_l2_vs_fp64_sample\": %.3e}\n",
-                   s.name, M, N, K, v[0], v[1] == 12 ? " sched" : (v[1] == 20 ? " x3-diagnostic" : ""), ok ? "true" : "false", ms1 * 1e3,
+                   s.name, M, N, K, v[0], vname(v[1]), ok ? "true" : "false", ms1 * 1e3,
                    ok ? flops / (ms1 * 1e-3) * 1e-12 : 0.0, ok ? ms0 / ms1 : 0.0, ok ? sqrt(num / den) : -1.0, mx, e1);
             fflush(stdout);
         }
         hipFree(d_idx); hipFree(d_smp); hipFree(d_acc); hipFree(d_max);
         hipFree(d.A); hipFree(d.W); hipFree(d.bias); hipFree(d.rowvec); hipFree(d.res); hipFree(d.C0); hipFree(d.C1);
     }
-    return 0;
+    return bad_cases ? 1 : 0;
 }

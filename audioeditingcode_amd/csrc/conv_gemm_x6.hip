@@ -29,7 +29,8 @@
 // The chunk body is ONE basic block (branch-free address arithmetic, trip count rounded up to DEPTH with zero chunks), and
 // VALU-only sched_group_barrier hints spread the split between the MFMAs (+3-4 % measured).
 //
-// Tried and dropped (profiles/r03_x6_gemm.md): 256x256 / 256x128 tiles with ONE wave per SIMD and the accumulators in
+// Tried and dropped (profiles/r03_x6_gemm.md): reading the fragments of chunk k+1 while the MFMAs of chunk k run from a
+// second register set (-2 %: LDS latency behind the barrier is not what is exposed), 256x256 / 256x128 tiles with ONE wave per SIMD and the accumulators in
 // AGPRs (4x slower as compiled), a row-permuted loader for conflict-free ds_write_b64 (-4 %), LDS-write / VMEM groups in
 // the hints (the solver gives up), packed subtractions (-10 %), flat loads with LDS-side zero masking (-3 %).
 #include "cg_params.h"
@@ -244,20 +245,20 @@ __global__ __launch_bounds__(64 * WROWS * WCOLS, 2) void conv_gemm_x6_kernel(CGP
     const int b_frag = (BM + wc * WN + fi) * X6_ROWQ + fh;
 
     bf16x8 af[TM][3], bw[TN][3];
-    auto load_frags = [&](const uint4* st) {
+    auto load_frags = [&](const uint4* st, bf16x8 (&fa)[TM][3], bf16x8 (&fb)[TN][3]) {
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl)
-                af[a][pl] = __builtin_bit_cast(bf16x8, st[a_frag + a * 32 * X6_ROWQ + 2 * pl]);
+                fa[a][pl] = __builtin_bit_cast(bf16x8, st[a_frag + a * 32 * X6_ROWQ + 2 * pl]);
 #pragma unroll
         for (int b = 0; b < TN; ++b)
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl)
-                bw[b][pl] = __builtin_bit_cast(bf16x8, st[b_frag + b * 32 * X6_ROWQ + 2 * pl]);
+                fb[b][pl] = __builtin_bit_cast(bf16x8, st[b_frag + b * 32 * X6_ROWQ + 2 * pl]);
     };
     // the six piece products with i + j <= 2, smallest first
-    auto do_mfmas = [&]() {
+    auto do_mfmas = [&](const bf16x8 (&fa)[TM][3], const bf16x8 (&fb)[TN][3]) {
         constexpr int TA[6] = {0, 2, 1, 0, 1, 0};
         constexpr int TB[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll
@@ -266,7 +267,16 @@ __global__ __launch_bounds__(64 * WROWS * WCOLS, 2) void conv_gemm_x6_kernel(CGP
             for (int a = 0; a < TM; ++a)
 #pragma unroll
                 for (int b = 0; b < TN; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][TA[t]], bw[b][TB[t]], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][TA[t]], fb[b][TB[t]], acc[a][b], 0, 0, 0);
+    };
+    auto hints = [&]() {
+        if constexpr (SCHED == 1) {
+            // a wave hides ~5 single-issue instructions per 32-cycle MFMA: spread the split of the chunk being staged (5.5 VALU
+            // per element + addresses) between the MFMAs.  VALU groups only: asking for LDS-write / load groups as well makes
+            // the solver give up and emit all VALU first.
+            constexpr int NM = TM * TN * NTERMS;
+            x6_hints<0, NM, NM * (((PA + PB) * 22 + 40 + NM - 1) / NM)>();
+        }
     };
 
 #pragma unroll
@@ -283,17 +293,11 @@ __global__ __launch_bounds__(64 * WROWS * WCOLS, 2) void conv_gemm_x6_kernel(CGP
         for (int d = 0; d < DEPTH; ++d) {
             const int kc = kc0 + d;
             const int sl = (d + 1) % DEPTH;     // chunk kc+1 sits in this register slot
-            load_frags(lds + cur * STAGE);
+            load_frags(lds + cur * STAGE, af, bw);
             stage_write(lds + (cur ^ 1) * STAGE, rbuf_a[sl], rbuf_b[sl]);
             prefetch(kc + 1 + DEPTH, rbuf_a[sl], rbuf_b[sl]);
-            do_mfmas();
-            if constexpr (SCHED == 1) {
-                // a wave hides ~5 single-issue instructions per 32-cycle MFMA: spread the split of chunk kc+1 (5.5 VALU per
-                // element + addresses) between the MFMAs of chunk kc.  VALU groups only: asking for LDS-write / load groups as
-                // well makes the solver give up and emit all VALU first.
-                constexpr int NM = TM * TN * NTERMS;
-                x6_hints<0, NM, NM * (((PA + PB) * 22 + 40 + NM - 1) / NM)>();
-            }
+            do_mfmas(af, bw);
+            hints();
             __syncthreads();
             cur ^= 1;
         }

@@ -25,6 +25,7 @@ import torch
 
 from . import _lib as L
 from .scheduler import coefficient_table
+from . import tape as tape_mod
 from .tape import Tape
 from .unet import PackedUNetWeights, UNetEngine
 
@@ -171,12 +172,22 @@ class EditEngine(LoopPlumbing):
         self.ts_dev[:n] = ts.to(self.device)
         self._ts_host = ts
 
+    # EXPERIMENTAL (round 3): arithmetic of the LDS-staged GEMMs of the BATCHED engines (tape.arith_mode); the latency-regime
+    # engines of the edit loop (batch < ARITH_MIN_BATCH) always stay fp32.  Set by PipelineWrapper.editor from `model.arith`.
+    arith = "f32"
+    ARITH_MIN_BATCH = 8
+
+    def _arith_for(self, B):
+        return self.arith if B >= self.ARITH_MIN_BATCH else "f32"
+
     def unet(self, B, L0=0, L1=0):
-        key = (B, L0, L1)
+        arith = self._arith_for(B)
+        key = (B, L0, L1) if arith == "f32" else (B, L0, L1, arith)
         if key not in self._unets:
-            self._unets[key] = UNetEngine(self.cfg, self.weights, self.device, B, self.H, self.W, ctx_len0=L0,
-                                          ctx_len1=L1, use_ehs=self.kind != "audioldm",
-                                          timesteps_dev=self.ts_dev, state_dev=self.state)
+            with tape_mod.arith_mode(arith):
+                self._unets[key] = UNetEngine(self.cfg, self.weights, self.device, B, self.H, self.W, ctx_len0=L0,
+                                              ctx_len1=L1, use_ehs=self.kind != "audioldm",
+                                              timesteps_dev=self.ts_dev, state_dev=self.state)
         return self._unets[key]
 
     def _set_cond(self, eng, groups, repeat=1):
@@ -312,7 +323,8 @@ class EditEngine(LoopPlumbing):
         rows_per_t = n * (1 + P)
         L0, L1 = self._ctx_lens(groups)
         scalar = float(cfg_src[0]) if (cfg_tensor is None and P) else 1.0
-        key = ("invert", n, P, T, G, L0, L1, bool(numerical_fix), v_pred, cfg_tensor is not None, scalar)
+        key = ("invert", n, P, T, G, L0, L1, bool(numerical_fix), v_pred, cfg_tensor is not None, scalar,
+               self._arith_for(G * rows_per_t))
         plan = self._get_plan(key)
         if plan is None:
             plan = self._plans[key] = dict(
@@ -397,7 +409,8 @@ class EditEngine(LoopPlumbing):
         eta_rows = self._etas_in_loop_order(eta, Z)
         any_noise = (eta_rows > 0) if isinstance(eta_rows, float) else any(e > 0 for e in eta_rows)
         has_noise = int(any_noise and zs is not None)
-        key = ("edit", n, P, T, Z, L0, L1, v_pred, cfg_tensor is not None, scalar, has_noise, table_kind)
+        key = ("edit", n, P, T, Z, L0, L1, v_pred, cfg_tensor is not None, scalar, has_noise, table_kind,
+               self._arith_for(n * (1 + P)))
         plan = self._get_plan(key)
         if plan is None:
             plan = self._plans[key] = dict(

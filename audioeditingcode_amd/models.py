@@ -192,6 +192,7 @@ class PipelineWrapper(torch.nn.Module):
         # inside a clip pipeline (pipeline.ClipPipeline) the loops replay on the caller's CU-partition lane
         ed.lane_stream = self.__dict__.get("_lane_stream")
         ed.eager_steps = bool(self.__dict__.get("_lane_eager"))       # lanes issue their steps launch by launch
+        ed.arith = getattr(self, "arith", "f32")       # EXPERIMENTAL: "bf16x6" = split-bf16 GEMMs in the batched engines
         return ed
 
     def lane_view(self):

@@ -64,6 +64,37 @@ def tile_regime(name):
         _regime.name = prev
 
 
+# ---- arithmetic of the LDS-staged GEMMs (EXPERIMENTAL, round 3) ------------------------------------------------------------
+# "f32": v_mfma_f32_32x32x2_f32 on fp32 operands (the product's arithmetic, conv_gemm.hip).
+# "bf16x6": every fp32 operand is cut exactly into three bf16 pieces in the kernel's loader and the six piece products of
+#   relative size >= 2^-16 are accumulated in fp32 (conv_gemm_x6.hip): as close to fp64 as the fp32 chain
+#   (tools/bf16_split_study.py, profiles/r03_x6_gemm.md), 1.5-1.8x faster at the inversion's batch-200 shapes.  Ops the
+#   split kernel does not take (latency-regime tiles >= 10, skinny tiles 5 / 6, scalar-gather shapes) stay fp32.
+ARITH_FLAGS = {"f32": 0, "bf16x6": 4 | 8}
+
+
+@contextlib.contextmanager
+def arith_mode(name):
+    """Engines built inside this context (on this thread) mark their eligible AED_OP_CONV_GEMM records with ARITH_FLAGS[name]."""
+    if name not in ARITH_FLAGS:
+        raise KeyError(f"unknown arithmetic {name!r} (have {sorted(ARITH_FLAGS)})")
+    prev = getattr(_regime, "arith", "f32")
+    _regime.arith = name
+    try:
+        yield
+    finally:
+        _regime.arith = prev
+
+
+def x6_tile(M, N, tile, ksplit, cus=None):
+    """Tile code for the split-bf16 kernel given the fp32 choice: the 512-thread 256x128 tile where two of them per CU still
+    fill the chip (profiles/r03_x6_gemm.md: +2-8 % over 128x128 at the batch-200 shapes), otherwise the fp32 table's tile."""
+    cus = cus or CU_COUNT
+    if tile == 1 and N >= 128 and math.ceil(M / 256) * math.ceil(N / 128) * max(ksplit, 1) >= 2 * cus:
+        return 8
+    return tile
+
+
 class Tape:
     def __init__(self, device):
         self.device = torch.device(device)
@@ -224,10 +255,16 @@ class Tape:
              a_bs, o_mul, o_add, o_len, out_bs, in_act, out_act, accumulate, ksplit, tile, FORCE_BK, ln_mode,
              C1 if x2 is not None else 0, lda2 or 0, a_bs2 or 0, int(geglu), sm_group, w_bs, vec_ld, vec_bs]
         n_out = N // 2 if geglu else N
+        flags = 2 if LATE_EPILOGUE else 0
+        arith = ARITH_FLAGS[getattr(_regime, "arith", "f32")]
+        if arith and vec_ok and tile in (1, 2, 3, 4) and B * a_bs + IH * IW * lda < (1 << 29) and N * K < (1 << 29) and \
+                (x2 is None or B * a_bs2 + IH * IW * lda2 < (1 << 29)):
+            flags |= arith
+            i[29] = x6_tile(M, N, tile, ksplit)
         idx = self._add(L.OP_CONV_GEMM, i, [in_slope, out_p, out_div, ln_eps, sm_scale],
                         [x, w, bias, out, res, rowvec, None, None, x2, kbias], name=name,
                         flops=2 * M * N * K if alg_flops is None else alg_flops, exec_flops=2 * M * N * K,
-                        nbytes=4 * (B * IH * IW * Cin + N * K + M * n_out), flags=2 if LATE_EPILOGUE else 0)
+                        nbytes=4 * (B * IH * IW * Cin + N * K + M * n_out), flags=flags)
         if ksplit > 1:
             self._ws_need = max(self._ws_need, ksplit * M * N)
             self._ws_ops.append(idx)

@@ -661,7 +661,10 @@ def sub_benchmarks(elapsed_s):
                                   "1", "--lanes", "1", "--no-extras", "--no-cpu-baseline", "--no-batched"], 240),
             ("config4_pc_extract_apply", [py, os.path.join(ROOT, "tools", "bench_config4.py")], 300),
             ("config5_stable_audio_fp32", [py, os.path.join(ROOT, "tools", "bench_stable_audio.py"), "--steps", "1",
-                                           "--warmup", "1"], 300)]
+                                           "--warmup", "1"], 300),
+            # EXPERIMENTAL (first run on hardware is the driver's): the same clip with the batched engines' GEMMs on
+            # split-bf16 MFMAs next to the product's fp32 arithmetic -- reported only, never part of `value`
+            ("x6_inversion", [py, os.path.join(ROOT, "tools", "bench_x6_inversion.py")], 240)]
     out = {}
     for key, cmd, limit in jobs:
         if elapsed_s > 600:                     # keep the whole default run bounded
@@ -675,6 +678,8 @@ def sub_benchmarks(elapsed_s):
                 d = json.loads(line[-1])
                 keep = {k: d[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "config", "checks",
                                           "phases_s_one_clip", "seconds") if k in d}
+                if key == "x6_inversion":
+                    keep = d
                 if isinstance(d.get("roofline"), dict):
                     keep["roofline"] = {k: v for k, v in d["roofline"].items() if not isinstance(v, (dict, list))}
                 out[key] = keep

@@ -355,3 +355,45 @@ def test_tape_image_round_trip_in_host_memory(tmp_path):
     im.close()
     with pytest.raises(L.AedError):
         Image(str(tmp_path / "missing.aedimg"))
+
+
+def test_arith_mode_marks_only_the_lds_staged_gemms():
+    """tape.arith_mode("bf16x6"): AED_OP_CONV_GEMM records built inside the context carry flag bits 2|3 exactly where the
+    split-bf16 kernel applies (LDS-staged tiles 1-4, 32-wide channel chunks), get tile 8 where two 256x128 workgroups per CU
+    still fill the chip, and nothing else about the record changes; outside the context (and after it) tapes are unflagged;
+    an engine built by EditEngine below ARITH_MIN_BATCH never is.  The CPU interpreter ignores the bits (fp32 semantics)."""
+    from audioeditingcode_amd import _lib as L, tape as tape_mod
+    from audioeditingcode_amd.tape import Tape
+
+    def build():
+        tp = Tape("cpu")
+        big = tp.alloc(64, 32, 16, 128)                       # M = 32768
+        w3 = tp.alloc(128, 9 * 128)
+        tp.conv(big, w3, None, tp.alloc(64, 32, 16, 128), B=64, IH=32, IW=16, Cin=128, OH=32, OW=16, N=128, KH=3, KW=3,
+                pad_h=1, pad_w=1, name="big3x3")              # fp32 tile 1, enough 256x128 blocks? 128 x 1 = 128 < 512 -> stays 1
+        huge = tp.alloc(512, 32, 16, 128)                     # M = 262144 -> 1024 blocks of 256x128
+        tp.conv(huge, w3, None, tp.alloc(512, 32, 16, 128), B=512, IH=32, IW=16, Cin=128, OH=32, OW=16, N=128, KH=3, KW=3,
+                pad_h=1, pad_w=1, name="huge3x3")
+        tp.linear(tp.alloc(64, 128), tp.alloc(128, 128), None, tp.alloc(64, 128), M=64, K=128, N=128, name="small")   # lin tile
+        odd = tp.alloc(64, 32, 16, 8)
+        tp.conv(odd, tp.alloc(128, 72), None, tp.alloc(64, 32, 16, 128), B=64, IH=32, IW=16, Cin=8, OH=32, OW=16, N=128,
+                KH=3, KW=3, pad_h=1, pad_w=1, name="cin8")    # scalar-gather shape
+        return tp
+    plain = build()
+    with tape_mod.arith_mode("bf16x6"):
+        x6 = build()
+        assert tape_mod.ARITH_FLAGS["bf16x6"] == 12
+    after = build()
+    by_name = {}
+    for a, b, c, mt in zip(plain.ops, x6.ops, after.ops, plain.meta):
+        assert a.code == b.code == c.code == L.OP_CONV_GEMM and a.flags == c.flags == 0 and list(a.i) == list(c.i)
+        assert list(a.i[:29]) == list(b.i[:29]) and list(a.i[30:]) == list(b.i[30:])
+        by_name[mt["name"]] = (a.i[29], b.i[29], b.flags)
+    assert by_name["big3x3"] == (1, 1, 12) and by_name["huge3x3"] == (1, 8, 12)
+    assert by_name["small"][0] >= 10 and by_name["small"][1:] == (by_name["small"][0], 0)
+    assert by_name["cin8"][2] == 0 and by_name["cin8"][0] == by_name["cin8"][1]
+    assert tape_mod.x6_tile(204800, 256, 1, 1) == 8 and tape_mod.x6_tile(2048, 256, 1, 1) == 1
+    assert tape_mod.x6_tile(204800, 64, 2, 1) == 2
+    with pytest.raises(KeyError):
+        with tape_mod.arith_mode("fp8"):
+            pass

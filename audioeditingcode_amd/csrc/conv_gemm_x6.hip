@@ -488,7 +488,8 @@ int launch_conv_gemm_x6(const aed_op* op, hipStream_t s) {
     if (cfg == 0) {
         const int cus = aed_num_cus();
         auto blocks = [&](int bm, int bn) { return (long)aed_cdiv(p.M, bm) * aed_cdiv(p.N, bn) * p.ksplit; };
-        if (blocks(256, 128) >= 2L * cus && p.N >= 128) cfg = 8;
+        if (p.N >= 512 && p.N % 256 == 0 && blocks(128, 256) >= 2L * cus) cfg = 9;      // wide Linears (qkv, FF1)
+        else if (blocks(256, 128) >= 2L * cus && p.N >= 128) cfg = 8;
         else if (blocks(128, 128) >= (long)cus && p.N >= 128) cfg = 1;
         else if (blocks(128, 64) >= 2L * cus) cfg = 2;
         else cfg = 4;

@@ -130,9 +130,17 @@ class ClipPipeline:
                              self.full, prep=Lane(dev, index=17) if overlap_prep else None)]
             # the edit loop's batch-2 kernels on half the chip are no longer purely latency-bound: their tiles come from
             # the sweep taken on a 128-CU stream (tile_table_cus128.py) when the partition is about that size
-            regime = "cus128" if (96 <= self.edit_cus <= 160 and "cus128" in tape_mod.REGIME_TABLES) else None
-            back = [_Worker("back", k, self._view(), Lane(dev, cus=range(self.edit_cus), total=self.total, index=k),
-                            Lane(dev, index=1 + k), regime=regime) for k in range(self.edit_lanes)]
+            # Several edit lanes get DISJOINT slices of the edit partition when it splits into multiples of 32 CUs (a mask must
+            # give every shader engine of every XCD the same number of CUs; 64 consecutive mask bits = 8 CUs on each XCD):
+            # lane k runs on CUs [k * edit_cus / n, (k + 1) * edit_cus / n).  Otherwise the lanes SHARE the partition's CUs --
+            # measured in round 3 (128 CUs, 2 lanes): CU-time bound, 2 x 2.87 s per clip per lane = the one-lane rate.
+            n = self.edit_lanes
+            per = self.edit_cus // n if (n > 1 and self.edit_cus % n == 0 and (self.edit_cus // n) % 32 == 0) else None
+            self.edit_lane_cus = per or self.edit_cus
+            lane_cus = (lambda k: range(k * per, (k + 1) * per)) if per else (lambda k: range(self.edit_cus))
+            regime = "cus128" if (96 <= self.edit_lane_cus <= 160 and "cus128" in tape_mod.REGIME_TABLES) else None
+            back = [_Worker("back", k, self._view(), Lane(dev, cus=lane_cus(k), total=self.total, index=k),
+                            Lane(dev, index=1 + k), regime=regime) for k in range(n)]
             self.stages = [("front", ("front",), front), ("back", ("back",), back)]
         else:
             n = DEFAULT_LANES if lanes is None else int(lanes)
@@ -451,7 +459,7 @@ class ClipPipeline:
             d[0], d[1] = min(d[0], t["start"]), max(d[1], t["end"])
         lats = [1e3 * (b - a) for a, b in lat.values()]
         return dict(plan=self.plan, launch=self.launch, clips_in_flight=self.clips_in_flight, total_cus=self.total,
-                    edit_cus=self.edit_cus, edit_lanes=self.edit_lanes,
+                    edit_cus=self.edit_cus, edit_lanes=self.edit_lanes, edit_lane_cus=getattr(self, "edit_lane_cus", None),
                     inversion_cus=None if self.edit_cus is None else self.total - self.edit_cus,
                     device_ms={k: dict(n=len(v), avg=sum(v) / len(v)) for k, v in acc.items()},
                     clip_latency_ms_avg=(sum(lats) / len(lats)) if lats else None,

@@ -87,11 +87,16 @@ def arith_mode(name):
 
 
 def x6_tile(M, N, tile, ksplit, cus=None):
-    """Tile code for the split-bf16 kernel given the fp32 choice: the 512-thread 256x128 tile where two of them per CU still
-    fill the chip (profiles/r03_x6_gemm.md: +2-8 % over 128x128 at the batch-200 shapes), otherwise the fp32 table's tile."""
+    """Tile code for the split-bf16 kernel given the fp32 choice (profiles/r03_x6_gemm.md, batch-200 shapes): the 512-thread
+    tiles where two of them per CU still fill the chip -- 128x256 when N is a whole number of 256-wide tiles (wide Linears:
+    qkv, FF1; +3-6 % over 256x128), else 256x128 (+2-8 % over 128x128) -- otherwise the fp32 table's tile."""
     cus = cus or CU_COUNT
-    if tile == 1 and N >= 128 and math.ceil(M / 256) * math.ceil(N / 128) * max(ksplit, 1) >= 2 * cus:
-        return 8
+    if tile == 1 and N >= 128:
+        ks = max(ksplit, 1)
+        if N >= 512 and N % 256 == 0 and math.ceil(M / 128) * (N // 256) * ks >= 2 * cus:
+            return 9
+        if math.ceil(M / 256) * math.ceil(N / 128) * ks >= 2 * cus:
+            return 8
     return tile
 
 

@@ -201,7 +201,13 @@ def main():
                          "inversion on disjoint CU partitions; 'lanes' = --lanes whole clips at once in the reference's "
                          "step order; 'serial' = one clip at a time")
     ap.add_argument("--edit-cus", type=int, default=128, help="partition plan: CUs of the edit-loop partition")
-    ap.add_argument("--edit-lanes", type=int, default=1, help="partition plan: edit loops sharing the edit partition")
+    ap.add_argument("--edit-lanes", type=int, default=1,
+                    help="partition plan: concurrent edit loops (disjoint CU slices of the edit partition where they are "
+                         "multiples of 32 CUs, shared otherwise)")
+    ap.add_argument("--arith", default="f32", choices=["f32", "bf16x6"],
+                    help="EXPERIMENTAL: arithmetic of the LDS-staged GEMMs of the batched (inversion) engines: fp32 MFMA "
+                         "(default, the product) or split-bf16 MFMAs (csrc/conv_gemm_x6.hip; same fp32 operands, as close "
+                         "to fp64 -- profiles/r03_x6_gemm.md)")
     ap.add_argument("--lanes", type=int, default=3, help="lanes plan: clips in flight")
     ap.add_argument("--lane-launch", default="graph", choices=["eager", "graph"],
                     help="how a pipeline worker issues one diffusion step: one hipGraphLaunch (default) or launch by launch")
@@ -240,6 +246,7 @@ def main():
         torch.cuda.synchronize()
     t_bcast = time.time() - t0
     m = models.load_model(args.model_id, dev, args.T, state_dicts=sds, allow_synthetic=True)   # no checkpoint exists offline
+    m.arith = args.arith        # lane views of the pipeline copy it; "f32" unless --arith asks for the experiment
 
     # ---- synthetic inputs, resident in HBM before the timed region
     src, tgt, neg = ["a recording of a piano melody"], ["a recording of an electric guitar melody"], [""]
@@ -474,6 +481,7 @@ def main():
                           "clips_per_gpu_per_step": NC,
                           "clips_in_flight_per_gpu": NC if pipe_info is None else pipe_info["clips_in_flight"],
                           "parallelism": f"clip-dp{world}" + ("" if pipe_info is None else f" x {PLAN} pipeline"),
+                          "arith": args.arith,
                           "weights_broadcast_s": t_bcast if world > 1 else 0.0,
                           "gathered_latents": None if gathered is None else [list(g.shape) for g in gathered][:2]},
                "roofline": roof, "cpu_baseline": base, "parity": parity, "phases_ms_one_clip_alone": phases}

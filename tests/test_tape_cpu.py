@@ -394,6 +394,7 @@ def test_arith_mode_marks_only_the_lds_staged_gemms():
     assert by_name["cin8"][2] == 0 and by_name["cin8"][0] == by_name["cin8"][1]
     assert tape_mod.x6_tile(204800, 256, 1, 1) == 8 and tape_mod.x6_tile(2048, 256, 1, 1) == 1
     assert tape_mod.x6_tile(204800, 64, 2, 1) == 2
+    assert tape_mod.x6_tile(204800, 768, 1, 1) == 9 and tape_mod.x6_tile(51200, 640, 1, 1) == 8     # whole 256-wide tiles only
     with pytest.raises(KeyError):
         with tape_mod.arith_mode("fp8"):
             pass

@@ -382,6 +382,10 @@ def test_clip_pipeline_plans_equal_serial_edit_clip(cpu_stack, monkeypatch):
         pipe = ClipPipeline(m, plan="partition", edit_cus=96, edit_lanes=2, timestep_group=3)
         assert [w.stage for w in pipe.workers] == ["front", "back", "back"] and pipe.clips_in_flight == 3
         assert pipe.workers[0].lane.cus == list(range(96, 256)) and pipe.workers[1].lane.cus == list(range(96))
+        assert pipe.workers[2].lane.cus == list(range(96))              # 48 CUs per lane is not a legal mask: the lanes share
+        split = ClipPipeline(m, plan="partition", edit_cus=128, edit_lanes=2, timestep_group=3)
+        assert [w.lane.cus for w in split.workers] == [list(range(128, 256)), list(range(64)), list(range(64, 128))]
+        assert split.edit_lane_cus == 64 and split.workers[1].regime is None
         v0, v1 = pipe.workers[0].view, pipe.workers[1].view
         assert v0.unet_weights is m.unet_weights and v0.state_dicts is m.state_dicts and v0.model is m.model
         assert v0._engines is not m._engines and v0._editors is not v1._editors

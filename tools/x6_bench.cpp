@@ -17,6 +17,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#include <string>
+#include <fstream>
+#include <sstream>
 #include "aed.h"
 
 #define HIPCHECK(e)                                                                      \
@@ -224,6 +227,123 @@ static int run_feature_cases(hipStream_t st) {
     return bad;
 }
 
+// ---- replay: the AED_OP_CONV_GEMM records of a whole U-Net forward (tools/dump_gemm_ops.py), each in both arithmetics ------
+struct Rec {
+    std::string name;
+    int flags, tile_f32, have[4];
+    int32_t i[40];
+    float f[5];
+};
+
+static int run_replay(const char* path, int iters, hipStream_t st) {
+    std::ifstream in(path);
+    if (!in) { fprintf(stderr, "cannot open %s\n", path); return 2; }
+    std::vector<Rec> recs;
+    std::string line;
+    while (std::getline(in, line)) {
+        Rec r;
+        std::vector<std::string> part;
+        std::stringstream ss(line);
+        std::string tok;
+        while (std::getline(ss, tok, '|')) part.push_back(tok);
+        if (part.size() != 6) continue;
+        r.name = part[0]; r.flags = atoi(part[1].c_str()); r.tile_f32 = atoi(part[2].c_str());
+        std::stringstream h(part[3]); for (int k = 0; k < 4; ++k) h >> r.have[k];
+        std::stringstream iv(part[4]); for (int k = 0; k < 40; ++k) iv >> r.i[k];
+        std::stringstream fv(part[5]); for (int k = 0; k < 5; ++k) fv >> r.f[k];
+        recs.push_back(r);
+    }
+    size_t mA = 4, mA2 = 4, mW = 4, mC = 4, mRes = 4, mRv = 4, mWs = 4, mB = 4;
+    auto dims = [](const Rec& r, size_t& nA, size_t& nA2, size_t& nW, size_t& nC, size_t& nRes, size_t& nRv, size_t& nWs) {
+        const int32_t* i = r.i;
+        const size_t batch = (size_t)i[0] / ((size_t)i[9] * i[10]);
+        nA = batch * i[20] + (size_t)i[7] * i[8] * i[3] + 16;
+        nA2 = i[32] ? batch * i[34] + (size_t)i[7] * i[8] * i[33] + 16 : 4;
+        nW = (size_t)i[1] * i[2];
+        nC = (batch * i[24] + 1) * (size_t)i[4];
+        nRes = (batch * i[24] + 1) * (size_t)(i[5] > 0 ? i[5] : 1);
+        nRv = i[31] ? (size_t)i[1] : batch * (size_t)(i[6] > i[1] ? i[6] : i[1]);
+        nWs = (size_t)(i[28] > 1 ? i[28] : 1) * i[0] * i[1];
+    };
+    for (const Rec& r : recs) {
+        size_t a, a2, w, c, rs, rv, ws;
+        dims(r, a, a2, w, c, rs, rv, ws);
+        if (a > mA) mA = a; if (a2 > mA2) mA2 = a2; if (w > mW) mW = w; if (c > mC) mC = c;
+        if (rs > mRes) mRes = rs; if (rv > mRv) mRv = rv; if (ws > mWs) mWs = ws; if ((size_t)r.i[1] > mB) mB = r.i[1];
+    }
+    float *A, *A2, *W, *bias, *res, *rv, *ws, *C0, *C1;
+    HIPCHECK(hipMalloc(&A, mA * 4)); HIPCHECK(hipMalloc(&A2, mA2 * 4)); HIPCHECK(hipMalloc(&W, mW * 4));
+    HIPCHECK(hipMalloc(&bias, mB * 4)); HIPCHECK(hipMalloc(&res, mRes * 4)); HIPCHECK(hipMalloc(&rv, mRv * 4));
+    HIPCHECK(hipMalloc(&ws, mWs * 4)); HIPCHECK(hipMalloc(&C0, mC * 4)); HIPCHECK(hipMalloc(&C1, mC * 4));
+    auto fill = [&](float* p, size_t n, uint64_t seed, float scale) {
+        hipLaunchKernelGGL(fill_hash, dim3(2048), dim3(256), 0, st, p, n, seed, scale);
+    };
+    fill(A, mA, 1ull << 40, 1.5f); fill(A2, mA2, 2ull << 40, 1.5f); fill(W, mW, 3ull << 40, 0.04f); fill(bias, mB, 4ull << 40, 0.2f);
+    fill(res, mRes, 5ull << 40, 1.0f); fill(rv, mRv, 6ull << 40, 0.3f); fill(C0, mC, 7ull << 40, 1.0f); fill(C1, mC, 7ull << 40, 1.0f);
+    HIPCHECK(hipStreamSynchronize(st));
+    double *d_acc; unsigned* d_max;
+    HIPCHECK(hipMalloc(&d_acc, 16)); HIPCHECK(hipMalloc(&d_max, 4));
+    hipEvent_t e0, e1;
+    HIPCHECK(hipEventCreate(&e0)); HIPCHECK(hipEventCreate(&e1));
+    double tot32 = 0, tot6 = 0, tot32_flagged = 0, flops = 0, worst = 0;
+    int n_flagged = 0, n_bad = 0;
+    for (const Rec& r : recs) {
+        aed_op op;
+        memset(&op, 0, sizeof(op));
+        op.code = AED_OP_CONV_GEMM;
+        memcpy(op.i, r.i, sizeof(op.i));
+        memcpy(op.f, r.f, sizeof(r.f));
+        op.p[0] = A; op.p[1] = W; op.p[2] = r.have[0] ? bias : nullptr; op.p[4] = r.have[1] ? res : nullptr;
+        op.p[5] = r.have[2] ? rv : nullptr; op.p[6] = ws; op.p[8] = r.have[3] ? A2 : nullptr;
+        size_t a, a2, w, c, rs, rvn, wsn;
+        dims(r, a, a2, w, c, rs, rvn, wsn);
+        auto timed = [&](int flags, int tile, float* C, int* rc) {
+            op.flags = flags; op.i[29] = tile; op.p[3] = C;
+            *rc = 0;
+            for (int k = 0; k < 2 && !*rc; ++k) *rc = aed_launch(&op, st);
+            if (*rc) { fprintf(stderr, "%s: %s\n", r.name.c_str(), aed_last_error()); return 0.f; }
+            HIPCHECK(hipEventRecord(e0, st));
+            for (int k = 0; k < iters; ++k) aed_launch(&op, st);
+            HIPCHECK(hipEventRecord(e1, st));
+            HIPCHECK(hipEventSynchronize(e1));
+            float ms = 0.f;
+            HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
+            return ms / iters;
+        };
+        int rc0 = 0, rc1 = 0;
+        const bool flagged = r.flags & 4;
+        const float ms0 = timed(r.flags & ~28, r.tile_f32, C0, &rc0);
+        float ms1 = ms0;
+        double rel = 0.0;
+        if (flagged) {
+            ms1 = timed(r.flags, r.i[29], C1, &rc1);
+            HIPCHECK(hipMemsetAsync(d_acc, 0, 16, st)); HIPCHECK(hipMemsetAsync(d_max, 0, 4, st));
+            hipLaunchKernelGGL(compare_kernel, dim3(1024), dim3(256), 0, st, C1, C0, c, d_acc, d_max);
+            double acc2[2];
+            HIPCHECK(hipStreamSynchronize(st));
+            HIPCHECK(hipMemcpy(acc2, d_acc, 16, hipMemcpyDeviceToHost));
+            rel = sqrt(acc2[0] / acc2[1]);
+            ++n_flagged;
+            tot32_flagged += ms0;
+            if (!(rel < 1e-5) || rc0 || rc1) ++n_bad;
+            if (rel > worst) worst = rel;
+        }
+        tot32 += ms0; tot6 += ms1;
+        const double fl = 2.0 * r.i[0] * (double)r.i[1] * r.i[2];
+        flops += fl;
+        printf("{\"op\": \"%s\", \"M\": %d, \"N\": %d, \"K\": %d, \"split\": %s, \"tile_f32\": %d, \"tile_x6\": %d, \"us_f32\": %.1f, "
+               "\"us_x6\": %.1f, \"rel_l2\": %.2e}\n", r.name.c_str(), r.i[0], r.i[1], r.i[2], flagged ? "true" : "false",
+               r.tile_f32, r.i[29], ms0 * 1e3, ms1 * 1e3, rel);
+    }
+    printf("{\"replay\": \"%s\", \"records\": %d, \"split_records\": %d, \"gemm_ms_f32\": %.2f, \"gemm_ms_bf16x6\": %.2f, "
+           "\"speedup\": %.3f, \"gemm_ms_f32_of_split_records\": %.2f, \"tflops_f32\": %.1f, \"tflops_bf16x6\": %.1f, "
+           "\"worst_rel_l2_vs_fp32_kernel\": %.2e, \"records_over_1e-5_or_failed\": %d}\n",
+           path, (int)recs.size(), n_flagged, tot32, tot6, tot32 / tot6, tot32_flagged, flops / (tot32 * 1e-3) * 1e-12,
+           flops / (tot6 * 1e-3) * 1e-12, worst, n_bad);
+    fflush(stdout);
+    return n_bad ? 1 : 0;
+}
+
 int main(int argc, char** argv) {
     const int iters = argc > 1 ? atoi(argv[1]) : 10;
     const Shape shapes[] = {
@@ -241,6 +361,7 @@ int main(int argc, char** argv) {
     fprintf(stderr, "device %s, %d CUs, ABI v%d\n", arch, cus, aed_version());
     hipStream_t st;
     HIPCHECK(hipStreamCreate(&st));
+    if (argc > 3 && !strcmp(argv[2], "replay")) return run_replay(argv[3], iters, st);
     const bool pmc = argc > 2 && !strcmp(argv[2], "pmc");       // counter passes: two shapes, three variants, no feature matrix
     const int bad_cases = pmc ? 0 : run_feature_cases(st);
     if (argc > 2 && !strcmp(argv[2], "cases")) return bad_cases ? 1 : 0;

@@ -193,6 +193,8 @@ class PipelineWrapper(torch.nn.Module):
         ed.lane_stream = self.__dict__.get("_lane_stream")
         ed.eager_steps = bool(self.__dict__.get("_lane_eager"))       # lanes issue their steps launch by launch
         ed.arith = getattr(self, "arith", "f32")       # EXPERIMENTAL: "bf16x6" = split-bf16 GEMMs in the batched engines
+        if hasattr(self, "arith_min_batch"):           # ... and, with a swept tape.X6_TABLES regime, in smaller ones too
+            ed.ARITH_MIN_BATCH = int(self.arith_min_batch)
         return ed
 
     def lane_view(self):

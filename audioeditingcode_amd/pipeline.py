@@ -138,7 +138,10 @@ class ClipPipeline:
             per = self.edit_cus // n if (n > 1 and self.edit_cus % n == 0 and (self.edit_cus // n) % 32 == 0) else None
             self.edit_lane_cus = per or self.edit_cus
             lane_cus = (lambda k: range(k * per, (k + 1) * per)) if per else (lambda k: range(self.edit_cus))
-            regime = "cus128" if (96 <= self.edit_lane_cus <= 160 and "cus128" in tape_mod.REGIME_TABLES) else None
+            regime = None
+            for name, lo, hi in (("cus128", 96, 160), ("cus64", 48, 80)):       # tables swept on a stream of about that size
+                if lo <= self.edit_lane_cus <= hi and name in tape_mod.REGIME_TABLES:
+                    regime = name
             back = [_Worker("back", k, self._view(), Lane(dev, cus=lane_cus(k), total=self.total, index=k),
                             Lane(dev, index=1 + k), regime=regime) for k in range(n)]
             self.stages = [("front", ("front",), front), ("back", ("back",), back)]

@@ -48,6 +48,21 @@ try:
     REGIME_TABLES["cus128"] = dict(_CUS128)
 except ImportError:                                              # pragma: no cover
     pass
+try:                                   # lanes of 64 CUs (several edit loops side by side); not swept yet
+    from .tile_table_cus64 import TILE_TABLE as _CUS64
+    REGIME_TABLES["cus64"] = dict(_CUS64)
+except ImportError:
+    pass
+# Tables for engines built under arith_mode("bf16x6"), per regime (None = whole chip): (M, N, K, geglu) -> (tile, ksplit) with
+# tile >= 100 meaning "split-bf16 kernel, tile code - 100" and tile < 100 "stay on the fp32 kernel with this tile" (the sweep
+# of tools/tile_sweep.py with AED_SWEEP_ARITH=bf16x6 decides per shape).  Shapes without an entry follow the rule in
+# Tape.conv: fp32 choice, flagged + x6_tile() when that choice is an LDS-staged tile.  No table has been swept yet.
+X6_TABLES = {}
+for _reg, _mod in ((None, "tile_table_x6"), ("cus128", "tile_table_x6_cus128"), ("cus64", "tile_table_x6_cus64")):
+    try:
+        X6_TABLES[_reg] = dict(__import__(f"{__package__}.{_mod}", fromlist=["TILE_TABLE"]).TILE_TABLE)
+    except ImportError:
+        pass
 _regime = threading.local()
 
 
@@ -242,6 +257,7 @@ class Tape:
         # lin_gemm needs an unsplit epilogue without the accumulate modes (vocoder MRF) and 32-wide channel chunks
         lin_ok = vec_ok and accumulate == 0 and (x2 is None or C1 % 32 == 0)
         auto_tile, auto_split = self.pick_tile(M, N, K, vector_ok=vec_ok, geglu=bool(geglu), lin_ok=lin_ok)
+        tile_forced = bool(tile)
         tile = tile or auto_tile
         ksplit = ksplit or auto_split
         if w_bs or vec_bs or sm_group or vec_ld != 1:
@@ -262,8 +278,18 @@ class Tape:
         n_out = N // 2 if geglu else N
         flags = 2 if LATE_EPILOGUE else 0
         arith = ARITH_FLAGS[getattr(_regime, "arith", "f32")]
-        if arith and vec_ok and tile in (1, 2, 3, 4) and B * a_bs + IH * IW * lda < (1 << 29) and N * K < (1 << 29) and \
-                (x2 is None or B * a_bs2 + IH * IW * lda2 < (1 << 29)):
+        x6_ok = arith and vec_ok and B * a_bs + IH * IW * lda < (1 << 29) and N * K < (1 << 29) and \
+            (x2 is None or B * a_bs2 + IH * IW * lda2 < (1 << 29)) and not (w_bs or vec_bs or sm_group or vec_ld != 1)
+        swept = X6_TABLES.get(getattr(_regime, "name", None), {}).get((M, N, K, int(bool(geglu)))) if x6_ok else None
+        if swept is not None and not tile_forced and (swept[0] >= 100 or lin_ok):
+            # measured per shape: tile >= 100 = split-bf16 kernel with tile - 100, else the fp32 kernel with that tile
+            t, ks = swept
+            if t >= 100:
+                flags |= arith
+                t -= 100
+            ksplit = 1 if (t >= 10 or ln_mode) else max(ks, 1)
+            i[28], i[29] = ksplit, t
+        elif x6_ok and tile in (1, 2, 3, 4):
             flags |= arith
             i[29] = x6_tile(M, N, tile, ksplit)
         idx = self._add(L.OP_CONV_GEMM, i, [in_slope, out_p, out_div, ln_eps, sm_scale],

@@ -398,3 +398,25 @@ def test_arith_mode_marks_only_the_lds_staged_gemms():
     with pytest.raises(KeyError):
         with tape_mod.arith_mode("fp8"):
             pass
+
+
+def test_swept_x6_table_decides_kernel_and_tile_per_shape(monkeypatch):
+    """tape.X6_TABLES (filled by tools/tile_table_from_sweep.py --x6): under arith_mode("bf16x6") an entry with tile >= 100 puts
+    the shape on the split-bf16 kernel with that tile, an entry with tile < 100 keeps it on the fp32 kernel even though the
+    default rule would have flagged it; without the mode the table is never consulted; a forced tile wins over the table."""
+    from audioeditingcode_amd import tape as tape_mod
+    from audioeditingcode_amd.tape import Tape
+    M, N, K = 64 * 512, 128, 9 * 128
+    monkeypatch.setitem(tape_mod.X6_TABLES, None, {(M, N, K, 0): (103, 1), (M, 256, K, 0): (2, 1)})
+
+    def build(forced=0):
+        tp = Tape("cpu")
+        x = tp.alloc(64, 32, 16, 128)
+        for n in (128, 256):
+            tp.conv(x, tp.alloc(n, K), None, tp.alloc(64, 32, 16, n), B=64, IH=32, IW=16, Cin=128, OH=32, OW=16, N=n, KH=3,
+                    KW=3, pad_h=1, pad_w=1, tile=forced)
+        return [(o.flags, o.i[29]) for o in tp.ops]
+    assert [f for f, _ in build()] == [0, 0]
+    with tape_mod.arith_mode("bf16x6"):
+        assert build() == [(12, 3), (0, 2)]
+        assert build(forced=1) == [(12, 1), (12, 1)]

@@ -9,7 +9,12 @@ served from the 256 MB Infinity Cache -- a forward streams 1.39 GB of weights, i
     PYTHONPATH=. python tools/tile_sweep.py <B> [R] dit  -> the contractions of the Stable Audio DiT forward instead
                                                             (gpurun_out/tile_sweep_dit_B<B>.json)
 
-The winners are pasted into audioeditingcode_amd/tile_table.py (tools/tile_table_from_sweep.py does it)."""
+    AED_SWEEP_CUS=64 ...                                 -> the same on a stream masked to 64 CUs (one lane of a pipeline)
+    AED_SWEEP_ARITH=bf16x6 ...                           -> the split-bf16 kernel's tiles compete too (tile codes 100 + tile:
+                                                            101, 102, 103, 104, 108, 109; csrc/conv_gemm_x6.hip)
+
+The winners are pasted into audioeditingcode_amd/tile_table.py (tools/tile_table_from_sweep.py does it; `--x6` writes the
+per-shape arithmetic + tile table of engines built under tape.arith_mode("bf16x6"))."""
 import collections
 import ctypes
 import json
@@ -47,6 +52,7 @@ else:
     eng.x_in.copy_(torch.randn(B, 256, 16, 8, generator=g))
     eng.set_timestep(500)
 # AED_SWEEP_CUS=n: run the sweep on a stream masked to n CUs (tile choices for one partition of the clip pipeline)
+SWEEP_ARITH = os.environ.get("AED_SWEEP_ARITH", "f32")
 SWEEP_CUS = int(os.environ.get("AED_SWEEP_CUS", "0"))
 if SWEEP_CUS:
     from audioeditingcode_amd.streams import PartitionStream
@@ -87,6 +93,8 @@ def candidates(M, N, K, taps, geglu, generic):
     big = M * N >= 4096 * 1024
     if big:                                 # throughput regime: the 32x32 lin tiles only add L2 traffic
         c = [x for x in c if x[0] in (1, 2, 3, 4, 15, 17)]
+    if SWEEP_ARITH == "bf16x6":             # the split-bf16 kernel (flags 4|8), unsplit K
+        c += [(100 + t, 1) for t in ((1, 3, 8, 9) if geglu else (1, 2, 3, 4, 8, 9))]
     return c
 
 
@@ -98,8 +106,10 @@ def time_cfg(op, tile, ksplit):
     for r in range(R):
         o = L.aed_op()
         ctypes.memmove(ctypes.byref(o), ctypes.byref(op), ctypes.sizeof(L.aed_op))
-        o.i[29] = tile
+        o.i[29] = tile % 100
         o.i[28] = ksplit
+        if tile >= 100:
+            o.flags |= 12
         o.p[1] = pool.data_ptr() + (r * step) % span
         if ksplit > 1:
             o.p[6] = ws.data_ptr()
@@ -154,4 +164,5 @@ for key, (op, count, name, flops) in reps.items():
           + " ".join(f"{k}={v:.1f}" for k, v in sorted(res.items(), key=lambda kv: kv[1])[:6]), flush=True)
 print(f"B={B}: conv_gemm per forward with the current rule {tot_auto / 1e3:.3f} ms, with per-shape best {tot_best / 1e3:.3f} ms")
 os.makedirs("gpurun_out", exist_ok=True)
-json.dump(rows, open(f"gpurun_out/tile_sweep_{'dit_' if DIT else ''}B{B}{f'_cus{SWEEP_CUS}' if SWEEP_CUS else ''}.json", "w"), indent=1)
+json.dump(rows, open(f"gpurun_out/tile_sweep_{'dit_' if DIT else ''}B{B}{f'_cus{SWEEP_CUS}' if SWEEP_CUS else ''}"
+                     f"{'_x6' if SWEEP_ARITH == 'bf16x6' else ''}.json", "w"), indent=1)

@@ -235,7 +235,7 @@ struct Rec {
     float f[5];
 };
 
-static int run_replay(const char* path, int iters, hipStream_t st) {
+static int run_replay(const char* path, int iters, hipStream_t st, bool x6only) {
     std::ifstream in(path);
     if (!in) { fprintf(stderr, "cannot open %s\n", path); return 2; }
     std::vector<Rec> recs;
@@ -312,11 +312,13 @@ static int run_replay(const char* path, int iters, hipStream_t st) {
         };
         int rc0 = 0, rc1 = 0;
         const bool flagged = r.flags & 4;
-        const float ms0 = timed(r.flags & ~28, r.tile_f32, C0, &rc0);
+        // x6only: the fp32 launch of an eligible record is skipped (timing a partition where only the split kernel matters)
+        const float ms0 = (x6only && flagged) ? 0.f : timed(r.flags & ~28, r.tile_f32, C0, &rc0);
         float ms1 = ms0;
         double rel = 0.0;
         if (flagged) {
             ms1 = timed(r.flags, r.i[29], C1, &rc1);
+            if (x6only) { tot6 += ms1; tot32 += ms0; flops += 2.0 * r.i[0] * (double)r.i[1] * r.i[2]; ++n_flagged; continue; }
             HIPCHECK(hipMemsetAsync(d_acc, 0, 16, st)); HIPCHECK(hipMemsetAsync(d_max, 0, 4, st));
             hipLaunchKernelGGL(compare_kernel, dim3(1024), dim3(256), 0, st, C1, C0, c, d_acc, d_max);
             double acc2[2];
@@ -361,7 +363,24 @@ int main(int argc, char** argv) {
     fprintf(stderr, "device %s, %d CUs, ABI v%d\n", arch, cus, aed_version());
     hipStream_t st;
     HIPCHECK(hipStreamCreate(&st));
-    if (argc > 3 && !strcmp(argv[2], "replay")) return run_replay(argv[3], iters, st);
+    if (argc > 3 && !strcmp(argv[2], "replay")) {
+        // replay <file> [cus=N] [x6only]: on a stream masked to CUs [0, N) (a pipeline partition) when asked
+        bool x6only = false;
+        hipStream_t rs = st;
+        for (int k = 4; k < argc; ++k) {
+            if (!strcmp(argv[k], "x6only")) x6only = true;
+            if (!strncmp(argv[k], "cus=", 4)) {
+                const int n = atoi(argv[k] + 4);
+                uint32_t words[8] = {0};
+                for (int b = 0; b < n && b < 256; ++b) words[b / 32] |= 1u << (b % 32);
+                void* h = nullptr;
+                if (aed_stream_create_cu_mask(&h, words, 8, 0)) { fprintf(stderr, "%s\n", aed_last_error()); return 2; }
+                rs = (hipStream_t)h;
+                fprintf(stderr, "replay on a stream masked to CUs [0, %d)\n", n);
+            }
+        }
+        return run_replay(argv[3], iters, rs, x6only);
+    }
     const bool pmc = argc > 2 && !strcmp(argv[2], "pmc");       // counter passes: two shapes, three variants, no feature matrix
     const int bad_cases = pmc ? 0 : run_feature_cases(st);
     if (argc > 2 && !strcmp(argv[2], "cases")) return bad_cases ? 1 : 0;

@@ -672,10 +672,16 @@ def sub_benchmarks(elapsed_s):
                                            "--warmup", "1"], 300),
             # EXPERIMENTAL (first run on hardware is the driver's): the same clip with the batched engines' GEMMs on
             # split-bf16 MFMAs next to the product's fp32 arithmetic -- reported only, never part of `value`
-            ("x6_inversion", [py, os.path.join(ROOT, "tools", "bench_x6_inversion.py")], 240)]
+            ("x6_inversion", [py, os.path.join(ROOT, "tools", "bench_x6_inversion.py")], 240),
+            # ... and the configuration the next round aims at: split-bf16 inversion on CUs [128, 256), two edit loops on the
+            # disjoint 64-CU slices [0, 64) and [64, 128) (NOTES.md); started only if the run is still short
+            ("pipeline_bf16x6_two_edit_lanes", [py, os.path.join(ROOT, "bench.py"), "--arith", "bf16x6", "--edit-lanes", "2",
+                                                "--steps", "8", "--warmup", "2", "--no-extras", "--no-cpu-baseline",
+                                                "--no-batched"], 200)]
+    start_by = {"pipeline_bf16x6_two_edit_lanes": 540}
     out = {}
     for key, cmd, limit in jobs:
-        if elapsed_s > 600:                     # keep the whole default run bounded
+        if elapsed_s > start_by.get(key, 600):  # keep the whole default run bounded
             out[key] = dict(skipped=f"bench already ran {elapsed_s:.0f} s")
             continue
         t0 = time.time()
@@ -685,7 +691,8 @@ def sub_benchmarks(elapsed_s):
             if r.returncode == 0 and line:
                 d = json.loads(line[-1])
                 keep = {k: d[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "config", "checks",
-                                          "phases_s_one_clip", "seconds") if k in d}
+                                          "phases_s_one_clip", "seconds", "pipeline", "pipeline_vs_one_clip_at_a_time")
+                        if k in d}
                 if key == "x6_inversion":
                     keep = d
                 if isinstance(d.get("roofline"), dict):

@@ -94,3 +94,22 @@ def test_full_audioldm2_unet_in_split_bf16_matches_the_fp32_engine_and_the_oracl
     ref, _, _ = ounet.unet_forward(cfg, sd, x[:2], torch.tensor(601), encoder_hidden_states=e0[:2],
                                    encoder_hidden_states_1=e1[:2], encoder_attention_mask_1=m1[:2])
     assert rel(eps["bf16x6"][:2], ref) < 1e-4 and rel(eps["f32"][:2], ref) < 1e-4
+
+
+def test_c_abi_harness_feature_matrix():
+    """tools/x6_bench.cpp `cases`: a plain C++ host (no Python, no torch) launches 20 records covering every loader / epilogue
+    mode of AED_OP_CONV_GEMM (stride, upsample, two-source A, SiLU / LeakyReLU of A, row vector, residual, activations, split-K,
+    accumulate modes, row scatter, ragged edges, Cin = 16, the fp32 fallback) through aed_launch with and without the
+    interleave hints and compares the split-bf16 result with the fp32 kernel's on the device (rel L2 < 5e-6 each)."""
+    import json
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "audioeditingcode_amd", "x6_bench")
+    if not os.path.exists(exe):
+        pytest.skip("audioeditingcode_amd/x6_bench is built by __graft_entry__.build()")
+    r = subprocess.run([exe, "1", "cases"], capture_output=True, text=True, timeout=300)
+    rows = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith('{"case"')]
+    assert len(rows) == 40, (r.returncode, r.stderr[-400:])
+    bad = [row for row in rows if not row["pass"]]
+    assert r.returncode == 0 and not bad, (bad[:3], r.stderr[-400:])
+    assert max(row["rel_l2_vs_fp32_kernel"] for row in rows) < 5e-6

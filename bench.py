@@ -672,13 +672,14 @@ def sub_benchmarks(elapsed_s):
                                            "--warmup", "1"], 300),
             # EXPERIMENTAL (first run on hardware is the driver's): the same clip with the batched engines' GEMMs on
             # split-bf16 MFMAs next to the product's fp32 arithmetic -- reported only, never part of `value`
-            ("x6_inversion", [py, os.path.join(ROOT, "tools", "bench_x6_inversion.py")], 240),
+            ("x6_inversion", [py, os.path.join(ROOT, "tools", "bench_x6_inversion.py"), "--clips", "1"], 150),
             # ... and the configuration the next round aims at: split-bf16 inversion on CUs [128, 256), two edit loops on the
             # disjoint 64-CU slices [0, 64) and [64, 128) (NOTES.md); started only if the run is still short
             ("pipeline_bf16x6_two_edit_lanes", [py, os.path.join(ROOT, "bench.py"), "--arith", "bf16x6", "--edit-lanes", "2",
                                                 "--steps", "8", "--warmup", "2", "--no-extras", "--no-cpu-baseline",
-                                                "--no-batched"], 200)]
-    start_by = {"pipeline_bf16x6_two_edit_lanes": 540}
+                                                "--no-batched"], 150)]
+    # the experimental legs only start while the whole run is still short (the default run stays within ~8 minutes)
+    start_by = {"x6_inversion": 470, "pipeline_bf16x6_two_edit_lanes": 420}
     out = {}
     for key, cmd, limit in jobs:
         if elapsed_s > start_by.get(key, 600):  # keep the whole default run bounded

@@ -9,8 +9,18 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def pytest_addoption(parser):
+    parser.addoption("--arith", default="f32", choices=["f32", "bf16x6"],
+                     help="EXPERIMENTAL: run the suite with the batched U-Net engines of every wrapper built under "
+                          "tape.arith_mode(<this>) (default f32 = the product); `-m gpu --arith bf16x6` is the acceptance run "
+                          "of the split-bf16 GEMMs: every parity tolerance of the suite must hold unchanged")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    if config.getoption("--arith") != "f32":
+        from audioeditingcode_amd import models
+        models.PipelineWrapper.arith = config.getoption("--arith")      # editor() reads it with getattr(self, "arith", "f32")
 
 
 @pytest.fixture(scope="session")

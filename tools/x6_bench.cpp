@@ -5,6 +5,11 @@
 //   hipcc -O2 -std=c++17 -Iinclude tools/x6_bench.cpp -Laudioeditingcode_amd -laed -Wl,-rpath,'$ORIGIN' \
 //         -o audioeditingcode_amd/x6_bench          (python tools/build_x6_bench.py does this)
 //   audioeditingcode_amd/x6_bench [iters]           -> one JSON line per (shape, variant) on stdout
+//   audioeditingcode_amd/x6_bench 1 cases           -> only the feature matrix (rc 1 if a case fails)
+//   audioeditingcode_amd/x6_bench 4 replay <records> [cus=N] [x6only]   -> every GEMM record of a forward, both arithmetics
+//   audioeditingcode_amd/x6_bench 60 sweep <records> [cus=N] [x6] > sweep.json   -> tile sweep (tools/tile_sweep.py without
+//                                                      Python; the JSON feeds tools/tile_table_from_sweep.py)
+//   (records: PYTHONPATH=. python tools/dump_gemm_ops.py <unet batch> > file)
 //
 // Per shape: the same AED_OP_CONV_GEMM record is launched with flags = 0 (fp32 MFMA, tile 1 = 128x128) and with
 // flags = 4 | 8 and tile codes 1 / 8 / 9 / 2 / 3 / 4 / 0 (launcher's pick).  Reported: average launch time over `iters` launches (HIP events on the
@@ -235,10 +240,18 @@ struct Rec {
     float f[5];
 };
 
+static bool read_records(const char* path, std::vector<Rec>& recs);
+static int run_replay_records(const char* path, const std::vector<Rec>& recs, int iters, hipStream_t st, bool x6only);
+
 static int run_replay(const char* path, int iters, hipStream_t st, bool x6only) {
-    std::ifstream in(path);
-    if (!in) { fprintf(stderr, "cannot open %s\n", path); return 2; }
     std::vector<Rec> recs;
+    if (!read_records(path, recs)) return 2;
+    return run_replay_records(path, recs, iters, st, x6only);
+}
+
+static bool read_records(const char* path, std::vector<Rec>& recs) {
+    std::ifstream in(path);
+    if (!in) { fprintf(stderr, "cannot open %s\n", path); return false; }
     std::string line;
     while (std::getline(in, line)) {
         Rec r;
@@ -253,6 +266,10 @@ static int run_replay(const char* path, int iters, hipStream_t st, bool x6only) 
         std::stringstream fv(part[5]); for (int k = 0; k < 5; ++k) fv >> r.f[k];
         recs.push_back(r);
     }
+    return true;
+}
+
+static int run_replay_records(const char* path, const std::vector<Rec>& recs, int iters, hipStream_t st, bool x6only) {
     size_t mA = 4, mA2 = 4, mW = 4, mC = 4, mRes = 4, mRv = 4, mWs = 4, mB = 4;
     auto dims = [](const Rec& r, size_t& nA, size_t& nA2, size_t& nW, size_t& nC, size_t& nRes, size_t& nRv, size_t& nWs) {
         const int32_t* i = r.i;
@@ -346,6 +363,130 @@ static int run_replay(const char* path, int iters, hipStream_t st, bool x6only) 
     return n_bad ? 1 : 0;
 }
 
+// ---- sweep: tools/tile_sweep.py without Python ---------------------------------------------------------------------------
+// For every distinct contraction of the records file: each candidate tile (fp32 LDS-staged tiles, the lin_gemm tiles, the
+// split-bf16 tiles as 100 + tile), timed the way the op runs inside the loops: R dependent launches in ONE hipGraph on the
+// (optionally CU-masked) stream, weights cold (every launch reads its W from a different slice of a 768 MB pool).  Prints the
+// JSON rows tools/tile_table_from_sweep.py reads (one array).  Records with per-batch weights / grouped softmax are skipped.
+static int run_sweep(const char* path, int R, hipStream_t st, bool with_x6) {
+    std::vector<Rec> recs;
+    if (!read_records(path, recs)) return 2;
+    struct Key { int v[10]; bool operator<(const Key& o) const { return memcmp(v, o.v, sizeof(v)) < 0; } };
+    std::vector<Key> order;
+    std::vector<int> first, count;
+    for (size_t k = 0; k < recs.size(); ++k) {
+        const int32_t* i = recs[k].i;
+        if (i[36] || i[37] || i[39]) continue;
+        Key key = {{i[0], i[1], i[2], i[12] * i[13], i[35], i[31], i[32] > 0, i[14], i[19], i[25]}};
+        size_t q = 0;
+        for (; q < order.size(); ++q) if (!(order[q] < key) && !(key < order[q])) break;
+        if (q == order.size()) { order.push_back(key); first.push_back((int)k); count.push_back(0); }
+        ++count[q];
+    }
+    const size_t POOL = (size_t)768 << 20;
+    size_t mA = 4, mA2 = 4, mC = 4, mRes = 4, mRv = 4, mWs = 4, mB = 4;
+    for (int f : first) {
+        const int32_t* i = recs[f].i;
+        const size_t batch = (size_t)i[0] / ((size_t)i[9] * i[10]);
+        size_t a = batch * i[20] + (size_t)i[7] * i[8] * i[3] + 16, a2 = i[32] ? batch * i[34] + (size_t)i[7] * i[8] * i[33] + 16 : 4;
+        size_t c = (batch * i[24] + 1) * (size_t)i[4], rs = (batch * i[24] + 1) * (size_t)(i[5] > 0 ? i[5] : 1);
+        size_t rv = i[31] ? (size_t)i[1] : batch * (size_t)(i[6] > i[1] ? i[6] : i[1]), ws = (size_t)32 * i[0] * i[1];
+        if (a > mA) mA = a; if (a2 > mA2) mA2 = a2; if (c > mC) mC = c; if (rs > mRes) mRes = rs; if (rv > mRv) mRv = rv;
+        if (ws > mWs) mWs = ws; if ((size_t)i[1] > mB) mB = i[1];
+    }
+    if (mWs > ((size_t)1 << 28)) mWs = (size_t)1 << 28;
+    float *A, *A2, *pool, *bias, *res, *rv, *ws, *C;
+    HIPCHECK(hipMalloc(&A, mA * 4)); HIPCHECK(hipMalloc(&A2, mA2 * 4)); HIPCHECK(hipMalloc(&pool, POOL));
+    HIPCHECK(hipMalloc(&bias, mB * 4)); HIPCHECK(hipMalloc(&res, mRes * 4)); HIPCHECK(hipMalloc(&rv, mRv * 4));
+    HIPCHECK(hipMalloc(&ws, mWs * 4)); HIPCHECK(hipMalloc(&C, mC * 4));
+    auto fill = [&](float* p, size_t n, uint64_t seed, float scale) {
+        hipLaunchKernelGGL(fill_hash, dim3(2048), dim3(256), 0, st, p, n, seed, scale);
+    };
+    fill(A, mA, 1ull << 40, 1.5f); fill(A2, mA2, 2ull << 40, 1.5f); fill(pool, POOL / 4, 3ull << 40, 0.04f);
+    fill(bias, mB, 4ull << 40, 0.2f); fill(res, mRes, 5ull << 40, 1.0f); fill(rv, mRv, 6ull << 40, 0.3f);
+    HIPCHECK(hipStreamSynchronize(st));
+    hipEvent_t e0, e1;
+    HIPCHECK(hipEventCreate(&e0)); HIPCHECK(hipEventCreate(&e1));
+    printf("[\n");
+    double tot_auto = 0, tot_best = 0;
+    for (size_t q = 0; q < order.size(); ++q) {
+        const Rec& r = recs[first[q]];
+        const int32_t* i = r.i;
+        const int M = i[0], N = i[1], K = i[2], geglu = i[35];
+        const bool generic = (i[11] % 32 != 0) || (i[3] % 4 != 0);
+        std::vector<int> cand;
+        if (generic) cand = {r.tile_f32};
+        else if (geglu) cand = {13, 14, 15, 17, 1, 3};
+        else cand = {10, 11, 12, 18, 19, 13, 15, 16, 17, 4, 1, 2, 3};
+        if (!generic && (size_t)M * N >= (size_t)4096 * 1024) {
+            std::vector<int> keep;
+            for (int t : cand) if (t == 1 || t == 2 || t == 3 || t == 4 || t == 15 || t == 17) keep.push_back(t);
+            cand = keep;
+        }
+        if (!generic && with_x6) for (int t : (geglu ? std::vector<int>{1, 3, 8, 9} : std::vector<int>{1, 2, 3, 4, 8, 9})) cand.push_back(100 + t);
+        bool has_auto = false;
+        for (int t : cand) has_auto |= t == r.tile_f32;
+        if (!has_auto) cand.push_back(r.tile_f32);
+        const size_t wbytes = (size_t)N * K * 4, step = (wbytes + 4095) / 4096 * 4096, span = POOL - wbytes - 4096;
+        std::string all;
+        double best_us = 1e30, auto_us = -1;
+        int best_t = -1;
+        for (int t : cand) {
+            aed_op op;
+            memset(&op, 0, sizeof(op));
+            op.code = AED_OP_CONV_GEMM;
+            memcpy(op.i, r.i, sizeof(op.i));
+            memcpy(op.f, r.f, sizeof(r.f));
+            op.flags = t >= 100 ? 12 : 0;
+            op.i[29] = t % 100;
+            op.i[28] = 1;
+            op.p[0] = A; op.p[2] = r.have[0] ? bias : nullptr; op.p[3] = C; op.p[4] = r.have[1] ? res : nullptr;
+            op.p[5] = r.have[2] ? rv : nullptr; op.p[6] = ws; op.p[8] = r.have[3] ? A2 : nullptr;
+            op.p[1] = pool;
+            if (aed_launch(&op, st) || hipStreamSynchronize(st) != hipSuccess) { (void)hipGetLastError(); continue; }
+            if (aed_graph_begin(st)) { fprintf(stderr, "%s\n", aed_last_error()); return 2; }
+            for (int k = 0; k < R; ++k) {
+                op.p[1] = (char*)pool + ((size_t)k * step) % span;
+                aed_launch(&op, st);
+            }
+            void* g = nullptr;
+            if (aed_graph_end(st, &g)) { fprintf(stderr, "%s\n", aed_last_error()); return 2; }
+            aed_graph_launch(g, st);
+            HIPCHECK(hipStreamSynchronize(st));
+            double us = 1e30;
+            for (int rep = 0; rep < 3; ++rep) {
+                HIPCHECK(hipEventRecord(e0, st));
+                aed_graph_launch(g, st);
+                HIPCHECK(hipEventRecord(e1, st));
+                HIPCHECK(hipEventSynchronize(e1));
+                float ms = 0.f;
+                HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
+                if (ms * 1e3 / R < us) us = ms * 1e3 / R;
+            }
+            aed_graph_destroy(g);
+            char buf[64];
+            snprintf(buf, sizeof(buf), "%s\"%d:1\": %.2f", all.empty() ? "" : ", ", t, us);
+            all += buf;
+            if (us < best_us) { best_us = us; best_t = t; }
+            if (t == r.tile_f32) auto_us = us;
+        }
+        if (best_t < 0) continue;
+        tot_auto += count[q] * (auto_us > 0 ? auto_us : best_us);
+        tot_best += count[q] * best_us;
+        printf("%s {\"M\": %d, \"N\": %d, \"K\": %d, \"taps\": %d, \"geglu\": %d, \"ln\": %d, \"two_source\": %d, \"stride\": %d, "
+               "\"up\": %d, \"count\": %d, \"name\": \"%s\", \"flops\": %.0f, \"auto\": \"%d:1\", \"auto_us\": %.2f, \"best\": \"%d:1\", "
+               "\"best_us\": %.2f, \"all\": {%s}}",
+               q ? ",\n" : "", M, N, K, i[12] * i[13], geglu, i[31], i[32] > 0, i[14], i[19], count[q], r.name.c_str(),
+               2.0 * M * (double)N * K, r.tile_f32, auto_us, best_t, best_us, all.c_str());
+        fflush(stdout);
+        fprintf(stderr, "%7d %5d %6d t%d g%d l%d x%3d  auto %3d %8.1f us | best %3d %8.1f us\n", M, N, K, i[12] * i[13], geglu, i[31],
+                count[q], r.tile_f32, auto_us, best_t, best_us);
+    }
+    printf("\n]\n");
+    fprintf(stderr, "conv_gemm per forward: current tiles %.3f ms, per-shape best %.3f ms\n", tot_auto / 1e3, tot_best / 1e3);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     const int iters = argc > 1 ? atoi(argv[1]) : 10;
     const Shape shapes[] = {
@@ -363,12 +504,13 @@ int main(int argc, char** argv) {
     fprintf(stderr, "device %s, %d CUs, ABI v%d\n", arch, cus, aed_version());
     hipStream_t st;
     HIPCHECK(hipStreamCreate(&st));
-    if (argc > 3 && !strcmp(argv[2], "replay")) {
-        // replay <file> [cus=N] [x6only]: on a stream masked to CUs [0, N) (a pipeline partition) when asked
-        bool x6only = false;
+    if (argc > 3 && (!strcmp(argv[2], "replay") || !strcmp(argv[2], "sweep"))) {
+        // replay | sweep <file> [cus=N] [x6only | x6]: on a stream masked to CUs [0, N) (a pipeline partition) when asked
+        bool x6only = false, with_x6 = false;
         hipStream_t rs = st;
         for (int k = 4; k < argc; ++k) {
             if (!strcmp(argv[k], "x6only")) x6only = true;
+            if (!strcmp(argv[k], "x6")) with_x6 = true;
             if (!strncmp(argv[k], "cus=", 4)) {
                 const int n = atoi(argv[k] + 4);
                 uint32_t words[8] = {0};
@@ -379,6 +521,7 @@ int main(int argc, char** argv) {
                 fprintf(stderr, "replay on a stream masked to CUs [0, %d)\n", n);
             }
         }
+        if (!strcmp(argv[2], "sweep")) return run_sweep(argv[3], iters, rs, with_x6);       // iters = launches per graph
         return run_replay(argv[3], iters, rs, x6only);
     }
     const bool pmc = argc > 2 && !strcmp(argv[2], "pmc");       // counter passes: two shapes, three variants, no feature matrix

@@ -95,7 +95,7 @@ class ClipPipeline:
     event_type = torch.cuda.Event
 
     def __init__(self, model, plan="partition", edit_cus=None, edit_lanes=1, lanes=None, launch="graph",
-                 timestep_group=100, overlap_prep=True):
+                 timestep_group=100, overlap_prep=True, lane_cus=None):
         if getattr(model, "kind", None) == "stable_audio":
             raise NotImplementedError("ClipPipeline drives the mel-latent families (AudioLDM / AudioLDM2 / TANGO)")
         if plan not in ("partition", "lanes"):
@@ -150,8 +150,26 @@ class ClipPipeline:
             if n < 1:
                 raise ValueError("lanes must be >= 1")
             self.edit_cus, self.edit_lanes = None, n
-            self.stages = [("clip", ("front", "back"), [_Worker("clip", k, self._view(), Lane(dev, index=1 + k), None)
-                                                        for k in range(n)])]
+            # lane_cus: every lane is a mini-chip of its own -- lane k owns CUs [k * lane_cus, (k + 1) * lane_cus) and runs whole
+            # clips there with the timestep-batched inversion (the inversion's CU-time does not depend on the partition size, the
+            # edit loop's falls with it: NOTES.md).  None: unmasked streams and the reference's step order (round 3's
+            # measurement: saturates at 1.6x of one chain).
+            self.lane_cus = None if lane_cus is None else int(lane_cus)
+            if self.lane_cus is not None:
+                if self.lane_cus % 32 or self.lane_cus < 32 or n * self.lane_cus > self.total:
+                    raise ValueError(f"{n} lanes of {self.lane_cus} CUs: a lane must be a multiple of 32 CUs and all of them "
+                                     f"fit the {self.total} CUs of the chip")
+                if self.timestep_group < 2:
+                    raise ValueError("masked lanes run the timestep-batched inversion (timestep_group >= 2)")
+            regime = None
+            for name, lo, hi in (("cus128", 96, 160), ("cus64", 48, 80)):
+                if self.lane_cus is not None and lo <= self.lane_cus <= hi and name in tape_mod.REGIME_TABLES:
+                    regime = name
+            cus_of = (lambda k: None) if self.lane_cus is None else \
+                (lambda k: range(k * self.lane_cus, (k + 1) * self.lane_cus))
+            self.stages = [("clip", ("front", "back"),
+                            [_Worker("clip", k, self._view(), Lane(dev, cus=cus_of(k), total=self.total, index=1 + k), None,
+                                     regime=regime) for k in range(n)])]
         self._build_lock = threading.Lock()     # an un-warmed worker builds engines (and lazily folds shared weights)
         self.stats = []
 
@@ -398,7 +416,7 @@ class ClipPipeline:
             raise ValueError("ClipPipeline edits with one source and one target prompt")
         if isinstance(tstart, (list, tuple)):
             tstart = tstart[0]
-        batched = self.plan == "partition"
+        batched = self.plan == "partition" or getattr(self, "lane_cus", None) is not None
         return dict(src=source_prompt, tgt=target_prompt, neg=target_neg_prompt, cfg_src=cfg_src, cfg_tar=cfg_tar, T=T,
                     tstart=int(tstart), eta=eta, schedule="batched" if batched else "sequential",
                     group=self.timestep_group if batched else 1)
@@ -462,7 +480,7 @@ class ClipPipeline:
             d[0], d[1] = min(d[0], t["start"]), max(d[1], t["end"])
         lats = [1e3 * (b - a) for a, b in lat.values()]
         return dict(plan=self.plan, launch=self.launch, clips_in_flight=self.clips_in_flight, total_cus=self.total,
-                    edit_cus=self.edit_cus, edit_lanes=self.edit_lanes, edit_lane_cus=getattr(self, "edit_lane_cus", None),
+                    edit_cus=self.edit_cus, edit_lanes=self.edit_lanes, edit_lane_cus=getattr(self, "edit_lane_cus", None), lane_cus=getattr(self, "lane_cus", None),
                     inversion_cus=None if self.edit_cus is None else self.total - self.edit_cus,
                     device_ms={k: dict(n=len(v), avg=sum(v) / len(v)) for k, v in acc.items()},
                     clip_latency_ms_avg=(sum(lats) / len(lats)) if lats else None,

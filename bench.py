@@ -209,6 +209,9 @@ def main():
                          "(default, the product) or split-bf16 MFMAs (csrc/conv_gemm_x6.hip; same fp32 operands, as close "
                          "to fp64 -- profiles/r03_x6_gemm.md)")
     ap.add_argument("--lanes", type=int, default=3, help="lanes plan: clips in flight")
+    ap.add_argument("--lane-cus", type=int, default=0,
+                    help="lanes plan: every lane on its own slice of this many CUs (a multiple of 32), whole clips with the "
+                         "timestep-batched inversion there; 0 = unmasked streams and the reference's step order")
     ap.add_argument("--lane-launch", default="graph", choices=["eager", "graph"],
                     help="how a pipeline worker issues one diffusion step: one hipGraphLaunch (default) or launch by launch")
     ap.add_argument("--no-overlap-prep", action="store_true",
@@ -355,13 +358,17 @@ def main():
     if PLAN != "serial":
         from audioeditingcode_amd.pipeline import ClipPipeline
         pipe = ClipPipeline(m, plan=PLAN, edit_cus=args.edit_cus, edit_lanes=args.edit_lanes, lanes=args.lanes,
-                            launch=args.lane_launch, timestep_group=args.group, overlap_prep=not args.no_overlap_prep)
+                            launch=args.lane_launch, timestep_group=args.group, overlap_prep=not args.no_overlap_prep,
+                            **({"lane_cus": args.lane_cus} if args.lane_cus else {}))
         dt, gathered = timed_pipeline(args.steps, args.warmup)
         extra["pipeline"] = pipe.report()
         if PLAN == "partition":
             headline = (f"{pipe.clips_in_flight} clips in flight per GPU: clip i+1's forward inversion ({args.group} timesteps "
                         f"per U-Net call) on {pipe.total - pipe.edit_cus} CUs beside clip i's edit loop "
                         f"({pipe.edit_lanes} lane(s)) on {pipe.edit_cus} CUs")
+        elif args.lane_cus:
+            headline = (f"{pipe.clips_in_flight} whole clips in flight per GPU, each on its own {args.lane_cus}-CU slice of the chip "
+                        f"(timestep-batched inversion, {args.group} timesteps per U-Net call, then the edit loop)")
         else:
             headline = f"reference step order, {pipe.clips_in_flight} whole clips in flight per GPU on as many HIP streams"
         log(f"{PLAN} pipeline: {dt / args.steps:.3f} s/clip  {json.dumps(extra['pipeline'])}")

@@ -386,6 +386,17 @@ def test_clip_pipeline_plans_equal_serial_edit_clip(cpu_stack, monkeypatch):
         split = ClipPipeline(m, plan="partition", edit_cus=128, edit_lanes=2, timestep_group=3)
         assert [w.lane.cus for w in split.workers] == [list(range(128, 256)), list(range(64)), list(range(64, 128))]
         assert split.edit_lane_cus == 64 and split.workers[1].regime is None
+        quad = ClipPipeline(m, plan="lanes", lanes=4, lane_cus=64, timestep_group=3)       # four mini-chips, whole clips each
+        assert [w.lane.cus for w in quad.workers] == [list(range(64 * k, 64 * k + 64)) for k in range(4)]
+        assert quad._args(["a"], ["b"], [""], [3.0], [12.0], 6, 4, 1.0)["schedule"] == "batched"
+        quad.warm_up(mels[0], *args)
+        for (a, o, w), (a2, o2, w2) in zip(quad.edit_clips(mels, *args, seeds=[40, 41, 42]), serial_b):
+            assert torch.equal(a, a2) and torch.equal(o, o2) and torch.equal(w, w2)
+        quad.close()
+        with pytest.raises(ValueError):
+            ClipPipeline(m, plan="lanes", lanes=5, lane_cus=64)
+        with pytest.raises(ValueError):
+            ClipPipeline(m, plan="lanes", lanes=2, lane_cus=48)
         v0, v1 = pipe.workers[0].view, pipe.workers[1].view
         assert v0.unet_weights is m.unet_weights and v0.state_dicts is m.state_dicts and v0.model is m.model
         assert v0._engines is not m._engines and v0._editors is not v1._editors

@@ -503,7 +503,8 @@ def roofline_leg(m, pipe, args, NC, dt):
     it, the streams (CU partitions) they run on, and the fraction of the chip those streams may use."""
     dev = m.device
     if pipe is None or pipe.plan == "lanes":
-        sequential = pipe is not None or args.schedule == "sequential"
+        masked = pipe is not None and getattr(pipe, "lane_cus", None)        # whole-clip lanes on disjoint CU slices: batched inversion
+        sequential = (pipe is not None and not masked) or (pipe is None and args.schedule == "sequential")
         G = 1
         if not sequential:
             G = max(1, min(args.group // NC if NC > 1 else args.group, args.T))
@@ -514,7 +515,8 @@ def roofline_leg(m, pipe, args, NC, dt):
             st = torch.cuda.Stream(device=dev)
             groups = {B: dict(n=n, members=[(m, st)], cu_frac=1.0) for B, n in calls.items()}
         else:
-            groups = {B: dict(n=n, members=[(w.view, w.lane.stream) for w in pipe.workers], cu_frac=1.0)
+            groups = {B: dict(n=n, members=[(w.view, w.lane.stream) for w in pipe.workers],
+                              cu_frac=(len(pipe.workers) * pipe.lane_cus / pipe.total) if masked else 1.0)
                       for B, n in calls.items()}
     else:
         G = max(1, min(args.group, args.T))
@@ -531,9 +533,10 @@ def roofline_leg(m, pipe, args, NC, dt):
         engs = []
         for v, st in g["members"]:
             ed = v.editor(256, 16)
-            cand = [e for (b, _, _), e in ed._unets.items() if b == B]
+            # engine keys are (B, L0, L1) for fp32 engines and (B, L0, L1, arith) for the others: take the one this run used
+            cand = sorted(((len(key), e) for key, e in ed._unets.items() if key[0] == B), key=lambda t: -t[0])
             if cand:
-                engs.append((ed, cand[0], st))
+                engs.append((ed, cand[0][1], st))
         if not engs:
             continue
         with torch.inference_mode():
@@ -602,7 +605,11 @@ def roofline_leg(m, pipe, args, NC, dt):
         except (OSError, KeyError, ValueError) as e:
             log(f"PMC summary unreadable: {e!r}")
     s_clip = dt / args.steps / NC
-    return dict(bound="mfma", achieved=achieved, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
+    arith_note = {} if args.arith == "f32" else dict(
+        arith=args.arith, peak_note="`peak` stays the fp32-MFMA rate (the arithmetic the results are equivalent to); the batched "
+        "engines' GEMMs run on split-bf16 MFMAs whose own nominal roof is 2500 / 6 = 416.7 TFLOP/s fp32-equivalent (measured "
+        "clocks under that stream put it at ~280: profiles/r03_x6_gemm.md)")
+    return dict(**arith_note, bound="mfma", achieved=achieved, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
                 frac=achieved / PEAK_FP32_MFMA_TFLOPS, traffic=traffic, traffic_note=traffic_note,
                 kernel="conv_gemm_kernel + lin_gemm_kernel (every conv / Linear of the U-Net forwards of one clip)",
                 method="executed flops (2MNK per launch) / [chip-equivalent time per forward x GEMM share].  Chip-equivalent "

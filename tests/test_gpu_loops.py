@@ -259,7 +259,7 @@ def test_eight_clips_per_engine_full_size_audioldm2():
     w8 = eng.edit_latents(x0s, src, unc, tgt, unc, [3.0], [12.0], tstart, schedule="batched", group=2, noise=noise)
     torch.cuda.synchronize()
     assert w8.shape == (n, 8, 256, 16) and torch.isfinite(w8).all()
-    assert {b for (b, _, _) in eng._unets} >= {16, 32}
+    assert {key[0] for key in eng._unets} >= {16, 32}
     for i in (0, 5):
         w1 = eng.edit_latents(x0s[i:i + 1], src, unc, tgt, unc, [3.0], [12.0], tstart, schedule="sequential",
                               noise=noise[:, i:i + 1])

@@ -73,7 +73,7 @@ __device__ __forceinline__ void x6_hints() {
     }
 }
 
-// SCHED: 0 = leave the instruction order to the compiler; 1 = ask for MFMA / VALU / DS interleave in the main loop
+// SCHED: 0 = leave the instruction order to the compiler; 1 = VALU-between-MFMA interleave hints in the main loop (x6_hints)
 // NTERMS: 6 = the product arithmetic; 3 = only the terms of relative size >= 2^-8 (DIAGNOSTIC: tells how much of the kernel time
 // is matrix-pipe time; ~4e-6 rel error, never used by a product path)
 template <int BM, int BN, int WROWS, int WCOLS, int DEPTH, bool PLAIN, int SCHED, int NTERMS>

@@ -588,6 +588,7 @@ class StableAudWrapper(PipelineWrapper):
         if self._editor is None:
             self._editor = StableAudioEditEngine(self.family["dit"], self.dit_weights, self.model.scheduler, self.device)
         self._editor.sched = self.model.scheduler
+        self._editor.arith = getattr(self, "arith", "f32")        # EXPERIMENTAL: "bf16x6" = split-bf16 GEMMs (tape.arith_mode)
         return self._editor
 
     def load_scheduler(self) -> None:

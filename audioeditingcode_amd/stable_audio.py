@@ -25,6 +25,7 @@ import torch
 from . import _lib as L
 from .editing import LoopPlumbing
 from .scheduler import sa_coefficient_table
+from . import tape as tape_mod
 from .tape import Tape
 from .unet import geglu_pack_index
 
@@ -433,9 +434,14 @@ class StableAudioEditEngine(LoopPlumbing):
                 "aed_sample_xts_from_x0")
         return xts
 
+    # EXPERIMENTAL (round 3): arithmetic of the DiT engines' LDS-staged GEMMs (tape.arith_mode); set by
+    # StableAudWrapper.editor from `model.arith`.  Not measured on hardware yet for this model.
+    arith = "f32"
+
     def _dit(self, B, S, tt, tgroup, rows_per_t):
-        return DiTEngine(self.cfg, self.weights, self.device, B, S, time_dev=tt, state_dev=self.state, tgroup=tgroup,
-                         rows_per_t=rows_per_t)
+        with tape_mod.arith_mode(self.arith):
+            return DiTEngine(self.cfg, self.weights, self.device, B, S, time_dev=tt, state_dev=self.state, tgroup=tgroup,
+                             rows_per_t=rows_per_t)
 
     # ------------------------------------------------------------------ forward inversion
     @torch.inference_mode()
@@ -456,7 +462,7 @@ class StableAudioEditEngine(LoopPlumbing):
         while T % G:
             G -= 1
         S = ctx_uncond.shape[1]
-        key = ("invert", P, T, G, S, bool(numerical_fix), bool(first_order), float(cfg_src))
+        key = ("invert", P, T, G, S, bool(numerical_fix), bool(first_order), float(cfg_src), self.arith)
         plan = self._get_plan(key)
         if plan is None:
             plan = self._plans[key] = dict(
@@ -515,7 +521,7 @@ class StableAudioEditEngine(LoopPlumbing):
         Z = int(tstart)
         numel = self.C * self.Lz
         S = ctx_tgt.shape[1]
-        key = ("edit", T, Z, S, bool(first_order), float(cfg_tar))
+        key = ("edit", T, Z, S, bool(first_order), float(cfg_tar), self.arith)
         plan = self._get_plan(key)
         if plan is None:
             plan = self._plans[key] = dict(

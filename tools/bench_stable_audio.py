@@ -19,6 +19,8 @@ ap.add_argument("--tstart", type=int, default=100)
 ap.add_argument("--group", type=int, default=20)
 ap.add_argument("--schedule", default="batched", choices=["batched", "sequential"])
 ap.add_argument("--model_id", default="stabilityai/stable-audio-open-1.0")
+ap.add_argument("--arith", default="f32", choices=["f32", "bf16x6"],
+                help="EXPERIMENTAL: arithmetic of the DiT engines' LDS-staged GEMMs (tape.arith_mode; csrc/conv_gemm_x6.hip)")
 args = ap.parse_args()
 
 from audioeditingcode_amd import models                     # noqa: E402
@@ -28,6 +30,7 @@ from audioeditingcode_amd.utils import load_audio            # noqa: E402
 dev = torch.device("cuda:0")
 t0 = time.time()
 m = models.load_model(args.model_id, dev, args.T, allow_synthetic=True)
+m.arith = args.arith
 print(f"weights ({m.weights_source}) ready in {time.time() - t0:.1f} s", file=sys.stderr, flush=True)
 sr = m.get_sr()
 n = m.model.transformer.config.sample_size * m.model.vae.hop_length

@@ -19,6 +19,7 @@ import torch
 
 from . import _lib as L
 from . import configs, weights
+from . import tape as tape_mod
 from .codec import STFTEngine, VAEDecoder, VAEEncoder, VocoderEngine
 from .editing import Conditioning, EditEngine
 from .scheduler import (CosineDPMSolverMultistepScheduler, DDIMScheduler, sa_step_coefficients, sa_step_orders,
@@ -163,8 +164,13 @@ class PipelineWrapper(torch.nn.Module):
 
     # ------------------------------------------------------------------ engine caches
     def _cached(self, key, make):
+        # EXPERIMENTAL: `codec_arith = "bf16x6"` builds the codec engines (STFT-as-DFT, VAE, vocoder) under tape.arith_mode
+        # (split-bf16 GEMMs, csrc/conv_gemm_x6.hip); default "f32".  Independent of `arith` (the U-Net / DiT engines).
+        arith = getattr(self, "codec_arith", "f32")
+        key = key if arith == "f32" else key + (arith,)
         if key not in self._engines:
-            self._engines[key] = make()
+            with tape_mod.arith_mode(arith):
+                self._engines[key] = make()
         return self._engines[key]
 
     def _stft(self, B, N):

@@ -20,7 +20,7 @@ ap.add_argument("--tstart", type=int, default=100)
 ap.add_argument("--group", type=int, default=100)
 ap.add_argument("--clips", type=int, default=2)
 ap.add_argument("--model_id", default="cvssp/audioldm2")
-ap.add_argument("--seconds", type=float, default=10.24)
+ap.add_argument("--seconds", type=float, default=10.0)       # 1024 mel frames -> 256x16 latent: the benched shapes (tile tables)
 a = ap.parse_args()
 
 from audioeditingcode_amd import _lib as L, models                                        # noqa: E402

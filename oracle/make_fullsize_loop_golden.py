@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE: one run of the CPU oracle's DDPM inversion + edit at the BENCHED size and length (AudioLDM2 U-Net
 346.9 M, latent 8x256x16, T=200, tstart=100, cfg 3 / 12, eta 1) on seeded inputs, stored as a fixture so that the GPU suite can
 compare the HIP loops with the oracle at full length without paying ~6 minutes of CPU per run
-(tests/test_gpu_zz_split_bf16.py::test_full_size_headline_length_loops_vs_the_oracle_fixture).
+(tests/test_gpu_zzz_fullsize_oracle_fixture.py).
 
 Everything the test needs besides the outputs is regenerated from seeds (weights: weights.random_state_dict seed 0, the
 seeded-random U-Net of every full-size test; conditioning and x0: generator seed 11; the x_t draws: oracle

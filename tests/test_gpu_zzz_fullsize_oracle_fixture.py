@@ -59,3 +59,35 @@ def test_full_size_headline_length_loops_vs_the_oracle_fixture(golden_dir):
     print("HIP vs oracle at T=200, full size:", errs)
     for mode, e in errs.items():            # the north star's tolerance (5e-3 on the latent); observed values are printed above
         assert e["w_edit"] < 5e-3 and e["xT"] < 5e-3 and e["zs"] < 5e-3 and e["zs_norms"] < 5e-3 and e["xts_norms"] < 5e-3, (mode, e)
+
+
+def test_stable_audio_dit_at_full_depth_vs_the_oracle_fixture(golden_dir):
+    """Stable Audio Open 1.0 DiT, all 24 layers (1.06 B seeded-random parameters, 1025-token sequence, batch 2 = [zero context
+    | prompt]): the compiled tape against the CPU oracle's forward stored in tests/golden/dit_full_depth.npz
+    (oracle/make_fullsize_dit_golden.py).  The live oracle comparison of test_gpu_stable_audio.py stops at 4 layers."""
+    from audioeditingcode_amd.scheduler import CosineDPMSolverMultistepScheduler
+    from audioeditingcode_amd.stable_audio import DiTEngine
+    from oracle.make_fullsize_dit_golden import S, STEP, case
+    path = os.path.join(golden_dir, "dit_full_depth.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/dit_full_depth.npz: run oracle/make_fullsize_dit_golden.py")
+    fx = np.load(path)
+    cfg = dict(configs.FAMILIES["stable_audio"]["dit"])
+    assert int(fx["num_layers"]) == cfg["num_layers"] == 24
+    sd = weights.random_state_dict(weights.dit_param_shapes(cfg), seed=3)
+    x, ctx, glob = case(cfg)
+    s = CosineDPMSolverMultistepScheduler()
+    s.set_timesteps(200)
+    t = s.timesteps[STEP]
+    assert abs(float(t) - float(fx["t"])) <= 1e-6 * abs(float(fx["t"]))
+    eng = DiTEngine(cfg, sd, DEV, 2, S)
+    eng.set_conditioning(ctx, glob)
+    eng.set_timestep(t)
+    eng.x_in.copy_(x.transpose(1, 2))
+    v = eng.forward().transpose(1, 2).cpu()
+    torch.cuda.synchronize()
+    ref = torch.from_numpy(fx["v"])
+    r = float((v.double() - ref.double()).norm() / ref.double().norm())
+    print("DiT at full depth, HIP vs oracle: rel L2", r)
+    assert torch.isfinite(v).all() and r < 5e-3, r
+    assert float((v[0] - v[1]).abs().max()) > 1e-3

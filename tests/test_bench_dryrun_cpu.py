@@ -229,8 +229,9 @@ def test_extras_are_reported_and_never_fatal():
                                                           '{"frac": 0.5, "by_batch": {}}}\n', stderr="")
     out = _run(["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--group", "20"], [2, 40],
                extra_patches=[mock.patch.object(bench, "parity_leg", lambda *a, **k: dict(latent_rel_l2=1e-4)),
+                              mock.patch.object(bench, "parity_fixture_leg", lambda *a, **k: dict(latent_rel_l2=2e-5)),
                               mock.patch.object(bench.subprocess, "run", fake_run)])
-    assert out["parity"] == dict(latent_rel_l2=1e-4)
+    assert out["parity"] == dict(latent_rel_l2=1e-4, parity_T200=dict(latent_rel_l2=2e-5))      # live T=8 leg + fixture leg
     assert out["config3_per_rank"]["value"] == 2.5 and out["config3_per_rank"]["roofline"] == {"frac": 0.5}
     assert out["config4_pc_extract_apply"]["failed"] == "rc=3"
     assert out["config5_stable_audio_fp32"]["value"] == 2.5

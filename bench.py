@@ -739,7 +739,7 @@ def sub_benchmarks(elapsed_s):
             if r.returncode == 0 and line:
                 d = json.loads(line[-1])
                 keep = {k: d[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "config", "checks",
-                                          "phases_s_one_clip", "seconds", "pipeline", "pipeline_vs_one_clip_at_a_time")
+                                          "phases_s_one_clip", "seconds", "pipeline", "pipeline_vs_one_clip_at_a_time", "parity_T200")
                         if k in d}
                 if key == "x6_inversion":
                     keep = d

@@ -82,7 +82,48 @@ for plan in ed._plans.values():
 edit_tf = 2 * fwd_flops * args.tstart / (edit_loop_ms * 1e-3) / 1e12
 inv_tf = 2 * fwd_flops * args.T / (inv_loop_ms * 1e-3) / 1e12
 clip_tflop = fwd_flops * 2 * (args.T + args.tstart) / 1e12
+
+
+def parity_T200():
+    """Reported only: the HIP loops (reference step order) from the fixture's latent against the CPU oracle's run of the same
+    schedule (tests/golden/sa_parity_T200.npz, oracle/make_sa_parity_golden.py: ~45 min of CPU at full depth)."""
+    import os
+    import numpy as np
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "sa_parity_T200.npz")
+    if not os.path.exists(path):
+        return dict(skipped="tests/golden/sa_parity_T200.npz is missing")
+    fx = np.load(path)
+    if int(fx["T"]) != args.T or int(fx["tstart"]) != args.tstart or args.arith != "f32":
+        return dict(skipped="the fixture is for T=200, tstart=100, fp32")
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())         # noqa: E731
+    psrc, ptgt, pneg = (str(p) for p in fx["prompts"])
+    dur, (cs, ct) = float(fx["duration"]), (float(v) for v in fx["cfg"])
+    t = time.time()
+    torch.manual_seed(int(fx["seed"]))
+    w_in = torch.from_numpy(fx["w0"]).to(dev)
+    _, zs_, wts_, extra_ = inversion_forward_process(m, w_in, etas=1.0, prompts=[psrc], cfg_scales=[cs],
+                                                     num_inference_steps=args.T, numerical_fix=True, schedule="sequential",
+                                                     duration=dur)
+    w_e, _ = inversion_reverse_process(m, xT=wts_, tstart=torch.tensor([args.tstart]), etas=1.0, prompts=[ptgt],
+                                       neg_prompts=[pneg], cfg_scales=[ct], zs=zs_[:args.tstart], duration=dur,
+                                       extra_info=extra_)
+    torch.cuda.synchronize()
+    keep = [int(k) for k in fx["keep"]]
+    return dict(workload="Stable Audio Open 1.0 at full depth, seeded latent, T=200, tstart=100, cfg 1 / 7, reference step order: "
+                         "HIP loops vs the CPU oracle's run (committed fixture)",
+                latent_rel_l2=rel(w_e.cpu().reshape(fx["w_edit"].shape), torch.from_numpy(fx["w_edit"])),
+                xT_rel_l2=rel(wts_[-1].cpu().reshape(fx["xT"].shape), torch.from_numpy(fx["xT"])),
+                zs_rel_l2_max=max(rel(zs_[k].cpu(), torch.from_numpy(fx["zs_keep"][j])) for j, k in enumerate(keep)),
+                seconds=round(time.time() - t, 1))
+
+
+try:
+    par = parity_T200()
+except Exception as e:          # noqa: BLE001 -- reported only
+    par = dict(failed=repr(e))
+print(f"parity at full size / full length vs the oracle fixture: {par}", file=sys.stderr, flush=True)
 print(json.dumps(dict(
+    parity_T200=par,
     metric="edited-clips/sec (config 5: Stable Audio Open 1.0, 200-step inv+edit, 47.55 s@44.1 kHz stereo)",
     value=args.steps / dt, unit="clips/s", n_gpus=1, steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * dt / args.steps,
     higher_is_better=True, scaling="weak", vs_baseline=None, dtype="fp32", data="synthetic",

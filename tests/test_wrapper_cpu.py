@@ -469,3 +469,36 @@ def test_export_model_images_on_cpu(monkeypatch, tmp_path):
     voc = Image(str(tmp_path / "vocoder.aedimg"), host=True)
     assert voc.buffer("wav")[1] > 0 and voc.buffer("mel_in")[1] > 0
     voc.close()
+
+
+def test_bench_parity_fixture_leg_plumbing_on_cpu(cpu_stack, monkeypatch, tmp_path):
+    """bench.parity_fixture_leg (the reported-only T=200 parity of the bench line) on a stand-in fixture of the tiny model:
+    keys, shapes, seeding and the skip rules of the function -- with a fixture made from the same model the three distances
+    are zero; a fixture for another schedule or other prompts is skipped, not compared."""
+    import importlib.util
+    import os
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    T, tstart = 4, 3
+    m = _model(T)
+    src, tgt, neg = ["a dog barking"], ["a cat meowing"], [""]
+    x0, _, _ = load_audio((synthetic_clip(seconds=0.64, seed=7), 16000), m.get_fn_STFT(), device="cpu", stft=True)
+    torch.manual_seed(77)
+    audio, _, w_edit = edit_clip(m, x0, src, tgt, neg, [3.0], [12.0], T, tstart)
+    mel = m.vae_decode(w_edit)
+    fx = dict(x0=x0.numpy(), w_edit=w_edit.numpy(), mel=mel.numpy(), wav=audio.numpy(), T=np.array(T), tstart=np.array(tstart),
+              seed=np.array(77), clip=np.array(1), prompts=np.array([src[0], tgt[0], neg[0]]))
+    golden = tmp_path / "tests" / "golden"
+    golden.mkdir(parents=True)
+    np.savez(golden / "bench_parity_T200.npz", **fx)
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    out = bench.parity_fixture_leg(m, src, tgt, neg, T, tstart)
+    assert out["latent_rel_l2"] == 0.0 and out["mel_rel_l2"] == 0.0 and out["waveform_rel_l2"] == 0.0, out
+    assert "skipped" in bench.parity_fixture_leg(m, src, tgt, neg, T + 4, tstart)
+    assert "skipped" in bench.parity_fixture_leg(m, ["another prompt"], tgt, neg, T, tstart)
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path / "nowhere"))
+    assert "skipped" in bench.parity_fixture_leg(m, src, tgt, neg, T, tstart)

@@ -91,3 +91,31 @@ def test_stable_audio_dit_at_full_depth_vs_the_oracle_fixture(golden_dir):
     print("DiT at full depth, HIP vs oracle: rel L2", r)
     assert torch.isfinite(v).all() and r < 5e-3, r
     assert float((v[0] - v[1]).abs().max()) > 1e-3
+
+
+def test_eight_clips_per_engine_at_full_size_vs_the_oracle_fixture(golden_dir):
+    """BASELINE config 3's per-rank shape (8 clips of the full-size AudioLDM2 U-Net per engine: edit batch 16, batched
+    inversion batch 32) against the CPU ORACLE's one-at-a-time edits of clips 0, 5 and 7 from the same per-clip noise maps
+    (tests/golden/fullsize_eight_clips_T4.npz; test_gpu_loops.py compares the same batch with single-clip GPU runs)."""
+    from oracle.make_fullsize_loop_golden import CLIPS8, N8, T8, TSTART8, inputs_eight
+    path = os.path.join(golden_dir, "fullsize_eight_clips_T4.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/fullsize_eight_clips_T4.npz: run oracle/make_fullsize_loop_golden.py eight")
+    fx = np.load(path)
+    assert [int(c) for c in fx["clips"]] == list(CLIPS8) and int(fx["T"]) == T8
+    cfg = configs.FAMILIES["audioldm2"]["unet"]
+    sd = weights.random_state_dict(weights.unet_param_shapes(cfg), seed=0)
+    src, tgt, unc, x0s, noise = inputs_eight()
+    to_c = lambda d: Conditioning(ehs0=d["encoder_hidden_states"], ehs1=d["encoder_hidden_states_1"],  # noqa: E731
+                                  mask1=d["encoder_attention_mask_1"])
+    sched = DDIMScheduler()
+    sched.set_timesteps(T8)
+    eng = EditEngine(cfg, sd, sched, DEV, 256, 16, "audioldm2")
+    w8 = eng.edit_latents(x0s, to_c(src), to_c(unc), to_c(tgt), to_c(unc), [3.0], [12.0], TSTART8, schedule="batched",
+                          group=2, noise=noise)
+    torch.cuda.synchronize()
+    assert w8.shape == (N8, 8, 256, 16)
+    ref = torch.from_numpy(fx["w_edit"])
+    errs = [float((w8[c].cpu().double() - ref[j].double()).norm() / ref[j].double().norm()) for j, c in enumerate(CLIPS8)]
+    print("8 clips per engine, full size, HIP vs oracle:", errs)
+    assert max(errs) < 5e-3, errs

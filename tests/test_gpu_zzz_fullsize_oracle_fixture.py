@@ -10,7 +10,11 @@ import numpy as np
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+# Non-strict xfail: these comparisons were written after the round-3 GPU lease ended and have never run on hardware; the
+# magnitudes of HIP-vs-oracle deviations at T=200 / 24 layers are predictions.  A miss must not mask the validated suite
+# (`-x`); a pass shows as XPASS.  Remove the mark once the first values are known (NOTES.md, first GPU hour of round 4).
+pytestmark = [pytest.mark.gpu, pytest.mark.xfail(strict=False, reason="first run on hardware is the driver's (added after "
+                                                                    "the round-3 lease ended)")]
 
 from audioeditingcode_amd import configs, weights                          # noqa: E402
 from audioeditingcode_amd.editing import Conditioning, EditEngine          # noqa: E402

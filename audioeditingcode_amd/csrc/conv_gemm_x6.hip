@@ -476,11 +476,19 @@ int launch_conv_gemm_x6(const aed_op* op, hipStream_t s) {
     const long long batch = i[0] / (i[9] * i[10] > 0 ? i[9] * i[10] : 1);
     const bool fits = (Cin % X6_BK == 0) && (i[3] % 4 == 0) && ((uintptr_t)op->p[0] % 16 == 0) &&
                       ((uintptr_t)op->p[1] % 16 == 0) && cfg < 10 && cfg != 5 && cfg != 6 && cfg != 7 && i[36] == 0 &&
-                      i[37] == 0 && i[39] == 0 &&
+                      i[37] == 0 && i[38] <= 1 && i[39] == 0 &&
                       // buffer loads address bytes below 2 GB of every operand
                       batch * i[20] + (long long)i[7] * i[8] * i[3] < (1LL << 29) && (long long)i[1] * i[2] < (1LL << 29) &&
                       (i[32] == 0 || batch * i[34] + (long long)i[7] * i[8] * i[33] < (1LL << 29));
-    if (!fits) return launch_conv_gemm(op, s);
+    if (!fits) {
+        // the fp32 launcher does not know the x6-only tile codes 8 / 9 (256x128, 128x256): hand it the 128x128 tile
+        if (cfg == 8 || cfg == 9) {
+            aed_op fp32_op = *op;
+            fp32_op.i[29] = 1;
+            return launch_conv_gemm(&fp32_op, s);
+        }
+        return launch_conv_gemm(op, s);
+    }
     CGParams p;
     int rc = cg_fill_params(op, p, X6_BK);
     if (rc) return rc;

@@ -9,6 +9,7 @@
 // boundary SURVEY 8(b) sketched (aed_create / aed_unet_forward / ...), realised as "load a compiled model, fill its named
 // inputs, run a named program".
 #include <stdio.h>
+#include <exception>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -49,9 +50,25 @@ int aed_image_load(const char* path, int flags, void** image_out) {
             break;
         }
         if (h.snapshot_bytes > h.arena_bytes) { aed_set_error("aed_image_load: corrupt header"); break; }
-        im->programs.resize(h.n_programs);
-        im->names.resize(h.n_names);
-        im->ops.resize(h.n_ops);
+        // the three tables and the snapshot must fit the file: a corrupt count must not turn into a huge resize()
+        long fsize = -1;
+        if (fseek(f, 0, SEEK_END) == 0) fsize = ftell(f);
+        if (fsize < 0 || fseek(f, (long)sizeof(h), SEEK_SET) != 0) { aed_set_error("aed_image_load: cannot size %s", path); break; }
+        const uint64_t room = (uint64_t)fsize - sizeof(h);
+        if (h.n_programs > room / sizeof(Program) || h.n_names > room / sizeof(Named) || h.n_ops > room / sizeof(aed_op) ||
+            sizeof(Program) * (uint64_t)h.n_programs + sizeof(Named) * (uint64_t)h.n_names + sizeof(aed_op) * (uint64_t)h.n_ops +
+                    h.snapshot_bytes > room) {
+            aed_set_error("aed_image_load: %s: header counts exceed the file size", path);
+            break;
+        }
+        try {
+            im->programs.resize(h.n_programs);
+            im->names.resize(h.n_names);
+            im->ops.resize(h.n_ops);
+        } catch (const std::exception&) {       // never let an allocation failure cross the C boundary
+            aed_set_error("aed_image_load: out of host memory (tables)");
+            break;
+        }
         if (!read_all(f, im->programs.data(), sizeof(Program) * h.n_programs) ||
             !read_all(f, im->names.data(), sizeof(Named) * h.n_names) ||
             !read_all(f, im->ops.data(), sizeof(aed_op) * h.n_ops)) {
@@ -60,7 +77,10 @@ int aed_image_load(const char* path, int flags, void** image_out) {
         }
         im->arena_bytes = h.arena_bytes;
         im->host = (flags & 1) != 0;            // inspection / tests: keep the arena in host memory (not runnable)
-        std::vector<char> chunk(std::min<uint64_t>(h.snapshot_bytes ? h.snapshot_bytes : 1, 64ull << 20));
+        std::vector<char> chunk;
+        try {
+            chunk.resize(std::min<uint64_t>(h.snapshot_bytes ? h.snapshot_bytes : 1, 64ull << 20));
+        } catch (const std::exception&) { aed_set_error("aed_image_load: out of host memory (staging)"); break; }
         if (im->host) {
             im->arena = (char*)calloc(h.arena_bytes ? h.arena_bytes : 1, 1);
             if (!im->arena) { aed_set_error("aed_image_load: out of host memory"); break; }
@@ -91,7 +111,7 @@ int aed_image_load(const char* path, int flags, void** image_out) {
                 else op.p[k] = im->arena + off;
             }
         for (auto& p : im->programs) bad |= (uint64_t)p.first + p.count > h.n_ops;
-        for (auto& n : im->names) bad |= n.offset + n.nbytes > h.arena_bytes;
+        for (auto& n : im->names) bad |= n.nbytes > h.arena_bytes || n.offset > h.arena_bytes - n.nbytes;   // no u64 wrap
         if (bad) { aed_set_error("aed_image_load: %s has out-of-range offsets", path); break; }
         rc = 0;
     } while (false);

@@ -16,14 +16,28 @@ import torch
 import torch.distributed as dist
 
 
-def init_distributed(backend=None):
-    """Initialise from the torchrun environment; returns (rank, world, local_rank). No-op at world size 1."""
+def _free_port() -> int:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def init_distributed(backend=None, force=False):
+    """Initialise from the torchrun environment; returns (rank, world, local_rank).  At world size 1 nothing is initialised
+    unless `force` (a one-rank RCCL group: lets a single MI355X execute the same broadcast / all_gather / all_reduce calls
+    the 8-rank run makes, tests/test_gpu_dist.py and `torchrun --nproc-per-node 1 bench.py`).  A launcher always provides
+    MASTER_PORT; without one (world 1 only) a free port is taken -- two jobs on one box must not meet on a fixed port."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force or "TORCHELASTIC_RUN_ID" in os.environ) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
+        if "MASTER_PORT" not in os.environ:
+            if world > 1:
+                raise RuntimeError("WORLD_SIZE > 1 without MASTER_PORT: launch the ranks with torch.distributed.run "
+                                   "(bench.py --gpus N does) or export one port for all of them")
+            os.environ["MASTER_PORT"] = str(_free_port())
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
@@ -56,7 +70,7 @@ def broadcast_state_dict(sd, shapes: Dict[str, tuple], device, src: int = 0, max
     identically ordered on every rank) comes from weights.*_param_shapes.  Returns the state dict.
     on_device=True: the returned tensors are views of the received arenas on `device` (no host bounce: the engines'
     weight packers consume device tensors directly); False keeps the round-1 behaviour (CPU copies)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return sd
     rank = dist.get_rank()
     offs, total = _arena_shapes(shapes)
@@ -93,7 +107,7 @@ def state_checksum(sd) -> float:
 
 def gather_to_rank0(local: torch.Tensor, dst: int = 0):
     """Gather equally-shaped per-rank tensors on `dst`; returns the list there, None elsewhere."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return [local]
     world = dist.get_world_size()
     if dist.get_backend() == "nccl":
@@ -106,7 +120,7 @@ def gather_to_rank0(local: torch.Tensor, dst: int = 0):
 
 
 def max_over_ranks(x: float, device) -> float:
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return x
     t = torch.tensor([x], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -114,5 +128,5 @@ def max_over_ranks(x: float, device) -> float:
 
 
 def barrier():
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.barrier()

@@ -18,9 +18,11 @@ Plans (measured on the MI355X, profiles/r03_cu_partition.md and profiles/r03_lan
     saturates the chip at ~1.6x, i.e. 1.6-1.9 s per clip: no better than one clip at a time with the batched inversion.
     Kept as a plan because it is the only one that needs no timestep regrouping.
 
-Nothing about a clip's computation changes: the same plans, tapes, hipGraphs and kernels run in the same order on the
-same values as in main_run.edit_clip -- only the stream they are launched on differs -- so a pipelined clip is
-bit-identical to the same clip edited alone (tests/test_gpu_pipeline.py).
+Nothing about a clip's computation changes: a worker's plans, tapes, hipGraphs and kernels run in the same order on the
+same values whether other clips are in flight or not -- only the stream they are launched on differs -- so a pipelined clip
+is bit-identical to the same clip pushed through the SAME ENGINES alone (tests/test_gpu_pipeline.py, asserted by bench.py).
+Against main_run.edit_clip on the model's own whole-chip engines the values agree to ~1e-6 relative, not bit for bit: a back-stage
+worker builds its engines under tape.tile_regime("cus128" / "cus64"), i.e. with other tiles and split-K summation orders.
 
 Workers are host threads (one per lane; the HIP calls release the GIL), each with a lane view of the wrapper
 (models.PipelineWrapper.lane_view: shares the frozen weights / scheduler / text encoders, owns every mutable buffer --

@@ -279,7 +279,8 @@ class Tape:
         flags = 2 if LATE_EPILOGUE else 0
         arith = ARITH_FLAGS[getattr(_regime, "arith", "f32")]
         x6_ok = arith and vec_ok and B * a_bs + IH * IW * lda < (1 << 29) and N * K < (1 << 29) and \
-            (x2 is None or B * a_bs2 + IH * IW * lda2 < (1 << 29)) and not (w_bs or vec_bs or sm_group or vec_ld != 1)
+            (x2 is None or B * a_bs2 + IH * IW * lda2 < (1 << 29)) and not (w_bs or vec_bs or sm_group or vec_ld != 1) and \
+            self._ptr(x) % 16 == 0 and self._ptr(w) % 16 == 0      # buffer_load_dwordx4 (the launcher's `fits`)
         swept = X6_TABLES.get(getattr(_regime, "name", None), {}).get((M, N, K, int(bool(geglu)))) if x6_ok else None
         if swept is not None and not tile_forced and (swept[0] >= 100 or lin_ok):
             # measured per shape: tile >= 100 = split-bf16 kernel with tile - 100, else the fp32 kernel with that tile

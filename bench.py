@@ -243,7 +243,8 @@ def main():
     if rank == 0:
         sds = {k: weights.random_state_dict(shapes[k], seed=i) for i, k in enumerate(("unet", "vae", "vocoder"))}
     t0 = time.time()
-    if world > 1:
+    grouped = torch.distributed.is_available() and torch.distributed.is_initialized()
+    if grouped:             # world > 1, or a one-rank RCCL group under torchrun (executes the same collectives)
         sds = {k: adist.broadcast_state_dict(None if sds is None else sds[k], shapes[k], dev, on_device=True)
                for k in shapes}
         torch.cuda.synchronize()
@@ -337,6 +338,7 @@ def main():
 
     PLAN = args.plan if NC == 1 else "serial"
     pipe = None
+    extra = {}
 
     def timed_pipeline(K, W):
         """K clips through pipeline.ClipPipeline.  Same waveforms and per-clip seeds as `timed`, so the serial legs below
@@ -354,13 +356,20 @@ def main():
         return finish(t0, [r[2] for r in res])
 
     log(f"model ready ({m.weights_source}); timing {args.steps} clip(s) after {args.warmup} warm-up")
-    extra = {}
     if PLAN != "serial":
         from audioeditingcode_amd.pipeline import ClipPipeline
-        pipe = ClipPipeline(m, plan=PLAN, edit_cus=args.edit_cus, edit_lanes=args.edit_lanes, lanes=args.lanes,
-                            launch=args.lane_launch, timestep_group=args.group, overlap_prep=not args.no_overlap_prep,
-                            **({"lane_cus": args.lane_cus} if args.lane_cus else {}))
-        dt, gathered = timed_pipeline(args.steps, args.warmup)
+        try:
+            pipe = ClipPipeline(m, plan=PLAN, edit_cus=args.edit_cus, edit_lanes=args.edit_lanes, lanes=args.lanes,
+                                launch=args.lane_launch, timestep_group=args.group, overlap_prep=not args.no_overlap_prep,
+                                **({"lane_cus": args.lane_cus} if args.lane_cus else {}))
+            dt, gathered = timed_pipeline(args.steps, args.warmup)
+        except Exception as e:                                  # noqa: BLE001
+            # a driver / container without CU-masked streams (hipExtStreamCreateWithCUMask, HSA_CU_MASK set, <= edit_cus CUs)
+            # must still produce a headline: fall back to one clip at a time on the whole GPU
+            log(f"clip pipeline unavailable ({e!r}): falling back to --plan serial")
+            extra["pipeline_fallback"] = repr(e)
+            pipe, PLAN = None, "serial"
+    if PLAN != "serial":
         extra["pipeline"] = pipe.report()
         if PLAN == "partition":
             headline = (f"{pipe.clips_in_flight} clips in flight per GPU: clip i+1's forward inversion ({args.group} timesteps "
@@ -494,7 +503,8 @@ def main():
                           "clips_in_flight_per_gpu": NC if pipe_info is None else pipe_info["clips_in_flight"],
                           "parallelism": f"clip-dp{world}" + ("" if pipe_info is None else f" x {PLAN} pipeline"),
                           "arith": args.arith,
-                          "weights_broadcast_s": t_bcast if world > 1 else 0.0,
+                          "weights_broadcast_s": t_bcast if grouped else 0.0,
+                          "process_group": (torch.distributed.get_backend() if grouped else None),
                           "gathered_latents": None if gathered is None else [list(g.shape) for g in gathered][:2]},
                "roofline": roof, "cpu_baseline": base, "parity": parity, "phases_ms_one_clip_alone": phases}
         out.update(extra)
@@ -609,7 +619,11 @@ def roofline_leg(m, pipe, args, NC, dt):
             break
         except (OSError, KeyError, ValueError) as e:
             log(f"PMC summary unreadable: {e!r}")
-    s_clip = dt / args.steps / NC
+    # `per_clip_flops` / `per_clip_exec` were summed over the forwards of ONE STEP = NC clips per U-Net batch: price them against
+    # the step time (round 3 divided the time by NC as well and printed path_frac = 4.23 for NC = 8), report them per clip
+    s_step = dt / args.steps
+    per_clip_flops, per_clip_exec = per_clip_flops / NC, per_clip_exec / NC
+    s_clip = s_step / NC
     arith_note = {} if args.arith == "f32" else dict(
         arith=args.arith, peak_note="`peak` stays the fp32-MFMA rate (the arithmetic the results are equivalent to); the batched "
         "engines' GEMMs run on split-bf16 MFMAs whose own nominal roof is 2500 / 6 = 416.7 TFLOP/s fp32-equivalent (measured "

@@ -19,8 +19,10 @@ def pytest_addoption(parser):
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     if config.getoption("--arith") != "f32":
-        from audioeditingcode_amd import models
+        from audioeditingcode_amd import editing, models, stable_audio
         models.PipelineWrapper.arith = config.getoption("--arith")      # editor() reads it with getattr(self, "arith", "f32")
+        editing.EditEngine.arith = config.getoption("--arith")          # engines the tests build directly
+        stable_audio.StableAudioEditEngine.arith = config.getoption("--arith")
 
 
 @pytest.fixture(scope="session")

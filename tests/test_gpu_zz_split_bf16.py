@@ -3,17 +3,12 @@ same records with flag bits 2|3 against the fp32-MFMA kernel and an fp64 CPU con
 built in that arithmetic against the fp32 engine and the oracle.
 
 The kernel itself was validated on the MI355X through the C ABI (tools/x6_bench.cpp: 20 loader / epilogue modes x 2 variants,
-profiles/r03_x6_gemm.md); this file sorts last on purpose -- its first run through pytest is the driver's."""
+profiles/r03_x6_gemm.md); the Python host path first ran on hardware in the round-3 driver's GPUTEST (passed)."""
 import pytest
 import torch
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
-# Non-strict xfail for the tests that go through the PYTHON host path of the experimental arithmetic: it has only run on the
-# CPU interpreter (the kernel itself is validated on hardware through the C ABI, last test of this file, which is a plain test).
-# A miss must not mask the validated suite (`-x`); a pass shows as XPASS.  Remove once observed (NOTES.md).
-first_python_run = pytest.mark.xfail(strict=False, reason="first run of the Python host path of tape.arith_mode on hardware "
-                                                          "is the driver's (added after the round-3 lease ended)")
 
 from audioeditingcode_amd import _lib as L, configs, tape as tape_mod, weights          # noqa: E402
 from audioeditingcode_amd.tape import Tape                                               # noqa: E402
@@ -53,7 +48,6 @@ def _conv_pair(B, H, W, Cin, N, k, stride, res, act, seed):
     return outs, ref
 
 
-@first_python_run
 @pytest.mark.parametrize("B,H,W,Cin,N,k,stride,res,act", [
     (8, 32, 16, 64, 128, 3, 1, False, 0),
     (8, 32, 16, 128, 128, 3, 2, True, 0),
@@ -68,7 +62,6 @@ def test_split_bf16_conv_is_as_close_to_fp64_as_the_fp32_kernel(B, H, W, Cin, N,
     assert e6 < 1.5 * e32 + 1e-7, (e6, e32)          # six bf16 piece products lose nothing against the fp32 chain
 
 
-@first_python_run
 def test_full_audioldm2_unet_in_split_bf16_matches_the_fp32_engine_and_the_oracle():
     """AudioLDM2 U-Net (346.9 M) at batch 8: the engine built under arith_mode("bf16x6") flags its LDS-staged GEMMs only, and
     its eps agrees with the fp32 engine to ~1e-5 (both carry fp32 rounding through ~400 GEMMs) and with the CPU oracle (first two rows) like the fp32 engine does."""

@@ -68,12 +68,20 @@ def run_clips(arith):
 
 res = dict(workload=f"AudioLDM2 T={a.T} tstart={a.tstart}, inversion batched {a.group} timesteps per U-Net call, one clip at "
                     f"a time; arith of the batched engines' LDS-staged GEMMs: f32 MFMA vs split-bf16 (bf16x6)")
+def partial(tag):
+    """Every finished leg is printed at once (stderr): a later failure must not lose it (round 3 lost both clip legs that way)."""
+    print(f"[x6_inversion partial:{tag}] " + json.dumps(res), file=sys.stderr, flush=True)
+
+
 (audio_f, w_f), s_f = run_clips("f32")
+res.update(clip_s_f32=round(s_f, 4), clips_per_s_f32=round(1 / s_f, 4))
+partial("f32 clips")
 (audio_x, w_x), s_x = run_clips("bf16x6")
 res.update(clip_s_f32=round(s_f, 4), clip_s_bf16x6=round(s_x, 4), clips_per_s_f32=round(1 / s_f, 4),
            clips_per_s_bf16x6=round(1 / s_x, 4), edited_latent_rel_l2=rel(w_x, w_f), waveform_rel_l2=rel(audio_x, audio_f))
 if oracle_w is not None:        # the oracle ran the reference step order; the batched schedule differs from it by ~2e-6 (bench.py)
     res.update(latent_rel_l2_vs_cpu_oracle_f32=rel(w_f, oracle_w), latent_rel_l2_vs_cpu_oracle_bf16x6=rel(w_x, oracle_w))
+partial("bf16x6 clips")
 
 # the batched forward alone, both arithmetics, same inputs
 with torch.inference_mode():
@@ -81,6 +89,8 @@ with torch.inference_mode():
 ed = m.editor(w0.shape[2], w0.shape[3])
 fwd = {}
 eps = {}
+_inference = torch.inference_mode()          # engine buffers are inference tensors: in-place writes need the mode (round-3 crash)
+_inference.__enter__()
 for arith in ("f32", "bf16x6"):
     ed.arith = arith
     key = [k for k in ed._unets if k[0] == 2 * a.group and (len(k) == 4) == (arith != "f32")]
@@ -103,6 +113,7 @@ for arith in ("f32", "bf16x6"):
     ops = eng.tape.ops
     res[f"conv_gemm_ops_{arith}"] = dict(total=sum(o.code == L.OP_CONV_GEMM for o in ops),
                                          split_bf16=sum(o.code == L.OP_CONV_GEMM and bool(o.flags & 4) for o in ops))
+_inference.__exit__(None, None, None)
 if len(fwd) == 2:
     res.update(forward_ms_f32=round(fwd["f32"], 2), forward_ms_bf16x6=round(fwd["bf16x6"], 2),
                forward_speedup=round(fwd["f32"] / fwd["bf16x6"], 3), eps_rel_l2=rel(eps["bf16x6"], eps["f32"]),

@@ -172,10 +172,14 @@ class EditEngine(LoopPlumbing):
         self.ts_dev[:n] = ts.to(self.device)
         self._ts_host = ts
 
-    # EXPERIMENTAL (round 3): arithmetic of the LDS-staged GEMMs of the BATCHED engines (tape.arith_mode); the latency-regime
-    # engines of the edit loop (batch < ARITH_MIN_BATCH) always stay fp32.  Set by PipelineWrapper.editor from `model.arith`.
-    arith = "f32"
-    ARITH_MIN_BATCH = 8
+    # Arithmetic of the LDS-staged GEMMs of this engine's U-Nets (tape.arith_mode; set by PipelineWrapper.editor from
+    # `model.arith`).  "bf16x6" (default since round 4): fp32 operands cut exactly into three bf16 pieces in the kernel's
+    # loader, six piece products on the bf16 MFMAs, fp32 accumulation -- as close to fp64 as the fp32 MFMA chain
+    # (csrc/conv_gemm_x6.hip); which GEMMs take it is decided per shape by the swept tables
+    # (tape.X6_TABLES) or, without an entry, by "every LDS-staged tile".  "f32": v_mfma_f32_32x32x2_f32 everywhere.
+    # Engines below ARITH_MIN_BATCH rows stay fp32.
+    arith = "bf16x6"
+    ARITH_MIN_BATCH = 2
 
     def _arith_for(self, B):
         return self.arith if B >= self.ARITH_MIN_BATCH else "f32"

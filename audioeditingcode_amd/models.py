@@ -83,6 +83,10 @@ class _FnSTFT:
 
 class PipelineWrapper(torch.nn.Module):
     family_name = None
+    # arithmetic of the U-Net engines' LDS-staged GEMMs (editing.EditEngine.arith): "bf16x6" = exact three-way bf16 split of the
+    # fp32 operands, six bf16-MFMA piece products, fp32 accumulate (results as close to fp64 as the fp32-MFMA chain's);
+    # "f32" = fp32-input MFMAs everywhere.  Set on the class or on an instance BEFORE the first editor() call of a shape.
+    arith = "bf16x6"
 
     def __init__(self, model_id: str, device: torch.device, double_precision: bool = False,
                  token: Optional[str] = None, seed: int = 0, state_dicts: Optional[Dict] = None,
@@ -198,8 +202,8 @@ class PipelineWrapper(torch.nn.Module):
         # inside a clip pipeline (pipeline.ClipPipeline) the loops replay on the caller's CU-partition lane
         ed.lane_stream = self.__dict__.get("_lane_stream")
         ed.eager_steps = bool(self.__dict__.get("_lane_eager"))       # lanes issue their steps launch by launch
-        ed.arith = getattr(self, "arith", "f32")       # EXPERIMENTAL: "bf16x6" = split-bf16 GEMMs in the batched engines
-        if hasattr(self, "arith_min_batch"):           # ... and, with a swept tape.X6_TABLES regime, in smaller ones too
+        ed.arith = self.arith
+        if hasattr(self, "arith_min_batch"):           # smallest U-Net batch whose engine takes `arith` (default: every engine)
             ed.ARITH_MIN_BATCH = int(self.arith_min_batch)
         return ed
 
@@ -525,6 +529,10 @@ class StableAudWrapper(PipelineWrapper):
     [1, 64, 1024], CosineDPMSolver++ (SDE, order 2) inversion / edit, Oobleck VAE on raw 44.1 kHz stereo.  Same method
     names and argument meaning; every tensor-valued method runs in libaed.so.  `self.model` has no `unet` attribute,
     which is how the reference's loops pick the 3-D expands (inversion_utils.py:88-89)."""
+    # DiT engines: fp32 MFMA until the split-bf16 arithmetic has its own full-length parity run for this family
+    # (tools/bench_stable_audio.py --arith bf16x6; DESIGN.md section 8)
+    arith = "f32"
+
     family_name = "stable_audio"
 
     def __init__(self, model_id: str, device: torch.device, double_precision: bool = False,
@@ -594,7 +602,7 @@ class StableAudWrapper(PipelineWrapper):
         if self._editor is None:
             self._editor = StableAudioEditEngine(self.family["dit"], self.dit_weights, self.model.scheduler, self.device)
         self._editor.sched = self.model.scheduler
-        self._editor.arith = getattr(self, "arith", "f32")        # EXPERIMENTAL: "bf16x6" = split-bf16 GEMMs (tape.arith_mode)
+        self._editor.arith = self.arith
         return self._editor
 
     def load_scheduler(self) -> None:

@@ -128,8 +128,12 @@ class ClipPipeline:
             # they go to a side stream, so their host-blocking copies and checks wait for THAT stream and the work itself
             # overlaps the inversion still running on the partition (otherwise ~50 ms of set-up per clip sit exposed
             # between two inversions: `assert min(y) >= -1` alone drains the lane before anything else is enqueued).
+            front_regime = None
+            for name, lo, hi in (("cus128", 96, 160), ("cus64", 48, 80)):       # tables swept on a stream of about that size
+                if lo <= self.total - self.edit_cus <= hi and name in tape_mod.REGIME_TABLES:
+                    front_regime = name
             front = [_Worker("front", 0, self._view(), Lane(dev, cus=range(self.edit_cus, self.total), total=self.total),
-                             self.full, prep=Lane(dev, index=17) if overlap_prep else None)]
+                             self.full, regime=front_regime, prep=Lane(dev, index=17) if overlap_prep else None)]
             # the edit loop's batch-2 kernels on half the chip are no longer purely latency-bound: their tiles come from
             # the sweep taken on a 128-CU stream (tile_table_cus128.py) when the partition is about that size
             # Several edit lanes get DISJOINT slices of the edit partition when it splits into multiples of 32 CUs (a mask must

@@ -10,19 +10,21 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
 def pytest_addoption(parser):
-    parser.addoption("--arith", default="f32", choices=["f32", "bf16x6"],
-                     help="EXPERIMENTAL: run the suite with the batched U-Net engines of every wrapper built under "
-                          "tape.arith_mode(<this>) (default f32 = the product); `-m gpu --arith bf16x6` is the acceptance run "
-                          "of the split-bf16 GEMMs: every parity tolerance of the suite must hold unchanged")
+    parser.addoption("--arith", default="default", choices=["default", "f32", "bf16x6"],
+                     help="arithmetic of the U-Net (and, when given explicitly, DiT) engines' LDS-staged GEMMs for the whole run: "
+                          "`default` = the product's (PipelineWrapper.arith = bf16x6, StableAudWrapper.arith = f32); `f32` = "
+                          "fp32 MFMAs everywhere; `bf16x6` = split-bf16 everywhere incl. the DiT.  Every parity tolerance of the "
+                          "suite must hold unchanged in all three")
 
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    if config.getoption("--arith") != "f32":
+    if config.getoption("--arith") != "default":
         from audioeditingcode_amd import editing, models, stable_audio
-        models.PipelineWrapper.arith = config.getoption("--arith")      # editor() reads it with getattr(self, "arith", "f32")
-        editing.EditEngine.arith = config.getoption("--arith")          # engines the tests build directly
-        stable_audio.StableAudioEditEngine.arith = config.getoption("--arith")
+        a = config.getoption("--arith")
+        models.PipelineWrapper.arith = models.StableAudWrapper.arith = a
+        editing.EditEngine.arith = a                                    # engines the tests build directly
+        stable_audio.StableAudioEditEngine.arith = a
 
 
 @pytest.fixture(scope="session")

@@ -154,6 +154,7 @@ def _run_inner(argv, batches):
             mock.patch("torch.cuda.synchronize"), mock.patch("torch.cuda.Stream", _Stream), \
             mock.patch("torch.cuda.stream", _stream_ctx), mock.patch("torch.cuda.Event", _Event), \
             mock.patch.object(models, "load_model", lambda *a, **k: _Model(batches)), \
+            mock.patch.object(bench, "check_fractions", lambda roof: None), \
             mock.patch.object(main_run, "edit_clip", lambda m, x0, *a, **k: (None, None, torch.ones(1, 8, 256, 16))), \
             mock.patch("audioeditingcode_amd.weights.random_state_dict", lambda *a, **k: {}), \
             mock.patch("torch.Tensor.to", lambda self, *a, **k: self), mock.patch("torch.device", lambda *a, **k: "cpu"):
@@ -235,3 +236,15 @@ def test_extras_are_reported_and_never_fatal():
     assert out["config3_per_rank"]["value"] == 2.5 and out["config3_per_rank"]["roofline"] == {"frac": 0.5}
     assert out["config4_pc_extract_apply"]["failed"] == "rc=3"
     assert out["config5_stable_audio_fp32"]["value"] == 2.5
+
+
+def test_roofline_fraction_check_refuses_the_round_3_defect():
+    """check_fractions: a fraction above its own roof (round 3's path_frac = 4.23) raises; under bf16x6 the fp32-referenced
+    fractions may exceed 1 and the bf16/6 twins are the ones checked."""
+    import pytest
+    bench.check_fractions(dict(frac=0.53, path_frac=0.47, path_frac_executed=0.46, by_batch={"b": dict(cu_fraction_of_chip=0.5)}))
+    with pytest.raises(AssertionError, match="path_frac"):
+        bench.check_fractions(dict(frac=0.53, path_frac=4.23, path_frac_executed=0.46))
+    bench.check_fractions(dict(frac=1.21, path_frac=0.74, frac_vs_bf16_over_6=0.46, path_frac_vs_bf16_over_6=0.28))
+    with pytest.raises(AssertionError, match="frac_vs_bf16_over_6"):
+        bench.check_fractions(dict(frac=3.1, path_frac=0.74, frac_vs_bf16_over_6=1.17, path_frac_vs_bf16_over_6=0.28))

@@ -30,7 +30,7 @@ got = {k: adist.broadcast_state_dict(sds[k], shapes[k], dev, on_device=True) for
 torch.cuda.synchronize()
 t_b = time.time() - t0
 assert all(v.is_cuda for sd in got.values() for v in sd.values())
-have = {k: adist.state_checksum(v) for k, v in got.items()}
+have = {k: adist.state_checksum({n: t.cpu() for n, t in v.items()}) for k, v in got.items()}   # same summation order as `want`
 lat = torch.randn(3, 8, 256, 16, device=dev)
 g = adist.gather_to_rank0(lat)
 mx = adist.max_over_ranks(1.25, dev)

@@ -137,7 +137,6 @@ def test_attention(B, H, Nq, Nk, D, masked):
 def test_attention_ragged_long_keys(B, H, Nq, Nk, D, masked):
     """long-key kernels with key / query counts that are not multiples of their tiles"""
     _attention_case(B, H, Nq, Nk, D, masked, variant=0)
-    _attention_case(B, H, Nq, Nk, D, masked, variant=2)
 
 
 @pytest.mark.parametrize("B,H,Nq,Nk,D,masked", [(16, 8, 512, 512, 32, False), (32, 8, 256, 256, 48, True),
@@ -147,9 +146,6 @@ def test_attention_transposed_kernel_throughput_mode(B, H, Nq, Nk, D, masked):
     _attention_case(B, H, Nq, Nk, D, masked, variant=0)
 
 
-@pytest.mark.parametrize("B,H,Nq,Nk,D,masked", [(2, 8, 1024, 1024, 32, False), (2, 8, 256, 256, 48, False)])
-def test_attention_split_kv_kernel_kept_for_ab(B, H, Nq, Nk, D, masked):
-    _attention_case(B, H, Nq, Nk, D, masked, variant=2)
 
 
 def _attention_case(B, H, Nq, Nk, D, masked, variant):

@@ -133,9 +133,11 @@ def test_ddim_baseline_matches_oracle():
 
 
 def test_full_size_audioldm2_loop_both_schedules_vs_oracle():
-    """BASELINE config 2 shapes (AudioLDM2 U-Net, latent 8x256x16) at T=8/tstart=4: the reference step order
-    and the timestep-batched inversion land at the same distance from the CPU oracle (reference order)."""
-    T, tstart = 8, 4
+    """BASELINE config 2 shapes (AudioLDM2 U-Net, latent 8x256x16) against a LIVE run of the CPU oracle at T=2/tstart=1 (the
+    full-length comparison -- T=200, both schedules -- is tests/test_gpu_zzz_fullsize_oracle_fixture.py against a committed
+    oracle run; this one needs no fixture and was T=8 = 124 s of the GPU suite's budget until round 4): the reference step
+    order and the timestep-batched inversion land at the same distance from the oracle (reference order)."""
+    T, tstart = 2, 1
     fam = configs.FAMILIES["audioldm2"]
     cfg = fam["unet"]
     sd = weights.random_state_dict(weights.unet_param_shapes(cfg), seed=0)
@@ -159,12 +161,13 @@ def test_full_size_audioldm2_loop_both_schedules_vs_oracle():
     eng = EditEngine(cfg, sd, sched, DEV, 256, 16, "audioldm2")
     errs = {}
     for mode in ("sequential", "batched"):
-        zs, xts = eng.invert(x0, to_c(src), to_c(unc), [3.0], xts=xts0.unsqueeze(1), mode=mode, group=4)
+        zs, xts = eng.invert(x0, to_c(src), to_c(unc), [3.0], xts=xts0.unsqueeze(1), mode=mode, group=2)
         w = eng.edit(xts, zs, tstart, to_c(tgt), to_c(unc), [12.0], eta=1.0)
         torch.cuda.synchronize()
         errs[mode] = (rel(eng.to_nchw(zs)[1:, 0].cpu(), zs_o[1:]), rel(eng.to_nchw(w).cpu(), w_o))
+    print("full-size loop vs live oracle (zs, edited latent):", errs)
     for mode, (ez, ew) in errs.items():
-        assert ez < 2e-3 and ew < 2e-3, (mode, ez, ew)
+        assert ez < 2e-4 and ew < 2e-4, (mode, ez, ew)
     assert errs["batched"][1] < 3 * errs["sequential"][1] + 1e-5, errs
 
 

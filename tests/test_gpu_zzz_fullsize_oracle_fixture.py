@@ -57,8 +57,10 @@ def test_full_size_headline_length_loops_vs_the_oracle_fixture(golden_dir):
             xts_norms=float((xts_c.flatten(1).norm(dim=1) - torch.from_numpy(fx["xts_norms"])).abs().max()
                             / torch.from_numpy(fx["xts_norms"]).max()))
     print("HIP vs oracle at T=200, full size:", errs)
-    for mode, e in errs.items():            # the north star's tolerance (5e-3 on the latent); observed values are printed above
-        assert e["w_edit"] < 5e-3 and e["xT"] < 5e-3 and e["zs"] < 5e-3 and e["zs_norms"] < 5e-3 and e["xts_norms"] < 5e-3, (mode, e)
+    # ~10x the values observed on the MI355X (round 4, both arithmetics: w_edit 4.4e-6 / 4.6e-6, zs 3.8e-6 ... 4.7e-6, xT 7e-8,
+    # norms 1.9e-7); the path's stated tolerance is 5e-3 on the edited latent
+    for mode, e in errs.items():
+        assert e["w_edit"] < 5e-5 and e["xT"] < 2e-6 and e["zs"] < 5e-5 and e["zs_norms"] < 5e-6 and e["xts_norms"] < 5e-6, (mode, e)
 
 
 def test_stable_audio_dit_at_full_depth_vs_the_oracle_fixture(golden_dir):
@@ -89,7 +91,7 @@ def test_stable_audio_dit_at_full_depth_vs_the_oracle_fixture(golden_dir):
     ref = torch.from_numpy(fx["v"])
     r = float((v.double() - ref.double()).norm() / ref.double().norm())
     print("DiT at full depth, HIP vs oracle: rel L2", r)
-    assert torch.isfinite(v).all() and r < 5e-3, r
+    assert torch.isfinite(v).all() and r < 5e-5, r              # observed 2.3e-6 (round 4)
     assert float((v[0] - v[1]).abs().max()) > 1e-3
 
 
@@ -118,4 +120,4 @@ def test_eight_clips_per_engine_at_full_size_vs_the_oracle_fixture(golden_dir):
     ref = torch.from_numpy(fx["w_edit"])
     errs = [float((w8[c].cpu().double() - ref[j].double()).norm() / ref[j].double().norm()) for j, c in enumerate(CLIPS8)]
     print("8 clips per engine, full size, HIP vs oracle:", errs)
-    assert max(errs) < 5e-3, errs
+    assert max(errs) < 1e-4, errs                                # observed 7.0e-6 ... 7.3e-6 (round 4, both arithmetics)

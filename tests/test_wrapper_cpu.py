@@ -385,7 +385,8 @@ def test_clip_pipeline_plans_equal_serial_edit_clip(cpu_stack, monkeypatch):
         assert pipe.workers[2].lane.cus == list(range(96))              # 48 CUs per lane is not a legal mask: the lanes share
         split = ClipPipeline(m, plan="partition", edit_cus=128, edit_lanes=2, timestep_group=3)
         assert [w.lane.cus for w in split.workers] == [list(range(128, 256)), list(range(64)), list(range(64, 128))]
-        assert split.edit_lane_cus == 64 and split.workers[1].regime is None
+        # 64-CU lanes and the 128-CU inversion partition take the tile tables swept on streams of that size (round 4)
+        assert split.edit_lane_cus == 64 and split.workers[1].regime == "cus64" and split.workers[0].regime == "cus128"
         quad = ClipPipeline(m, plan="lanes", lanes=4, lane_cus=64, timestep_group=3)       # four mini-chips, whole clips each
         assert [w.lane.cus for w in quad.workers] == [list(range(64 * k, 64 * k + 64)) for k in range(4)]
         assert quad._args(["a"], ["b"], [""], [3.0], [12.0], 6, 4, 1.0)["schedule"] == "batched"

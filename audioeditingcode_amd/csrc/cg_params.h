@@ -27,6 +27,13 @@ struct CGParams {
     int in_act, out_act, accumulate, ksplit;
     int rpb;                 // output rows per batch item = OH*OW
     int nchunks;             // ceil(K/BKT)
+    // K traversal of the LDS-staged kernels (conv_gemm.hip, conv_gemm_x6.hip).  A chunk is (tap, channel offset); both operands
+    // use the same map, so the order only decides WHEN a byte is fetched.  kgroup = channels per group: the chunks walk
+    // [group][tap][chunk within group].  kgroup = Cin is the tap-major order of rounds 1-3 (all channels of tap 0, then tap 1 ...):
+    // the 9 taps of a 3x3 conv re-read the same activation lines Cin/32 chunks apart and, at the inversion's batch, out of
+    // the 4 MB L2 (measured 2.08x the algorithmic bytes).  kgroup = 32 (one 128-byte line per pixel; 64 for 64-wide chunks)
+    // consumes all taps of a line group back to back: the re-reads hit the L2.
+    int kgroup;
     float in_slope, out_p, out_div;
     int ln_mode;             // 1: A rows are LayerNorm inputs; W has gamma folded in, rowvec = sum_k W'[n,k], bias = W.beta (+bias)
     float ln_eps;

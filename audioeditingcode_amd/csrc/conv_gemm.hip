@@ -104,11 +104,16 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 1) void conv_gemm
     const int vIH = p.vIH, vIW = p.vIW;
     // running (tap, channel) position of the NEXT chunk to prefetch (prefetch() is always called with
     // consecutive kc): no per-chunk integer divisions
-    int pf_c0 = 0, pf_ty = 0, pf_tx = 0;
+    // [group of p.kgroup channels][tap][chunk within the group] (cg_params.h): pf_cg = first channel of the group
+    int pf_cg = 0, pf_sub = 0, pf_ty = 0, pf_tx = 0;
+    const int gq = p.kgroup / BKT;            // chunks per (group, tap)
     if constexpr (!GENERIC) {
-        const int k0 = kc_begin * BKT;
-        const int tap = k0 / p.Cin;
-        pf_c0 = k0 - tap * p.Cin;
+        const int per_group = p.KH * p.KW * gq;
+        const int g = kc_begin / per_group;
+        const int rem = kc_begin - g * per_group;
+        const int tap = rem / gq;
+        pf_cg = g * p.kgroup;
+        pf_sub = rem - tap * gq;
         pf_ty = tap / p.KW;
         pf_tx = tap - pf_ty * p.KW;
     }
@@ -120,14 +125,18 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 1) void conv_gemm
     unsigned rmask[DEPTH];      // per stage: bit q set = A row q of that chunk is in-bounds (else zero padding)
 
     auto prefetch = [&](int kc, float4 (&ra)[PA], float4 (&rb)[PB], unsigned& mask) {
-        const int k0 = min(kc, p.nchunks - 1) * BKT;      // dead prefetches past the end stay in bounds
+        const int k0 = min(kc, p.nchunks - 1) * BKT;      // dead prefetches past the end stay in bounds (generic path)
         if constexpr (!GENERIC) {
-            int c0 = pf_c0;
+            const bool live = kc < p.nchunks;                 // a dead prefetch reads clamped addresses and is never staged
+            int c0 = pf_cg + pf_sub * BKT;
             const int dy = pf_ty * p.dil_h, dx = pf_tx * p.dil_w;
-            pf_c0 += BKT;
-            if (pf_c0 >= p.Cin) {
-                pf_c0 = 0;
-                if (++pf_tx == p.KW) { pf_tx = 0; ++pf_ty; }
+            const unsigned kw = live ? (unsigned)((pf_ty * p.KW + pf_tx) * p.Cin + c0) : 0u;    // W column of this chunk
+            if (++pf_sub == gq) {
+                pf_sub = 0;
+                if (++pf_tx == p.KW) {
+                    pf_tx = 0;
+                    if (++pf_ty == p.KH) { pf_ty = 0; pf_cg += p.kgroup; }
+                }
             }
             // two-source A (an up-block concat that is never materialised): block-uniform select per chunk
             const float* src = p.A;
@@ -138,7 +147,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 1) void conv_gemm
 #pragma unroll
             for (int q = 0; q < PA; ++q) {
                 const int iy = ay0[q] + dy, ix = ax0[q] + dx;
-                const bool ok = avalid[q] & ((unsigned)iy < (unsigned)vIH) & ((unsigned)ix < (unsigned)vIW);
+                const bool ok = avalid[q] & ((unsigned)iy < (unsigned)vIH) & ((unsigned)ix < (unsigned)vIW) & live;
                 // clamped, always-valid address; the zero padding is applied at the LDS write so that the
                 // raw load stays in flight (nothing consumes it here)
                 const int cy = ok ? (iy >> p.up) : 0, cx = ok ? (ix >> p.up) : 0;
@@ -149,7 +158,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 1) void conv_gemm
             }
             mask = mk;
 #pragma unroll
-            for (int q = 0; q < PB; ++q) rb[q] = *reinterpret_cast<const float4*>(p.W + wbase[q] + k0);
+            for (int q = 0; q < PB; ++q) rb[q] = *reinterpret_cast<const float4*>(p.W + wbase[q] + kw);
         } else {
 #pragma unroll
             for (int q = 0; q < PA; ++q) {
@@ -486,6 +495,11 @@ int cg_fill_params(const aed_op* op, CGParams& p, int bkt) {
     p.kbias = (const float*)op->p[9];
     p.rpb = p.OH * p.OW;
     p.nchunks = (p.K + bkt - 1) / bkt;
+    // op flag bit 5 (32): keep the tap-major K order (A/B switch for the traffic measurement)
+    {
+        const int g = bkt > 32 ? bkt : 32;
+        p.kgroup = (p.KH * p.KW > 1 && p.Cin % g == 0 && p.Cin > g && !(op->flags & 32)) ? g : p.Cin;
+    }
     p.vIH = p.IH << p.up;
     p.vIW = p.IW << p.up;
     if (p.up) {

@@ -145,11 +145,16 @@ __global__ __launch_bounds__(64 * WROWS * WCOLS, 2) void conv_gemm_x6_kernel(CGP
     }
     const int vIH = p.vIH, vIW = p.vIW;
     // running (tap, channel) position of the next chunk to prefetch: prefetch() is called with consecutive kc
-    int pf_c0, pf_ty, pf_tx;
+    // [group of p.kgroup channels][tap][chunk within the group] (cg_params.h): pf_cg = first channel of the group
+    int pf_cg, pf_sub, pf_ty, pf_tx;
+    const int gq = p.kgroup / X6_BK;          // chunks per (group, tap)
     {
-        const int k0 = kc_begin * X6_BK;
-        const int tap = k0 / p.Cin;
-        pf_c0 = k0 - tap * p.Cin;
+        const int per_group = p.KH * p.KW * gq;
+        const int g = kc_begin / per_group;
+        const int rem = kc_begin - g * per_group;
+        const int tap = rem / gq;
+        pf_cg = g * p.kgroup;
+        pf_sub = rem - tap * gq;
         pf_ty = tap / p.KW;
         pf_tx = tap - pf_ty * p.KW;
     }
@@ -169,16 +174,19 @@ __global__ __launch_bounds__(64 * WROWS * WCOLS, 2) void conv_gemm_x6_kernel(CGP
         return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
     };
     auto prefetch = [&](int kc, float4 (&ra)[PA], float4 (&rb)[PB]) {
-        const int k0 = kc * X6_BK;
-        int c0 = pf_c0;
+        int c0 = pf_cg + pf_sub * X6_BK;
         const int dy = pf_ty * p.dil_h, dx = pf_tx * p.dil_w;
-        pf_c0 += X6_BK;
-        const bool wrap = pf_c0 >= p.Cin;
-        pf_c0 = wrap ? 0 : pf_c0;
+        const unsigned k0 = (unsigned)((pf_ty * p.KW + pf_tx) * p.Cin + c0);     // W column of this chunk
+        pf_sub += 1;
+        const bool wrap = pf_sub == gq;
+        pf_sub = wrap ? 0 : pf_sub;
         pf_tx += wrap ? 1 : 0;
         const bool wrap2 = pf_tx == p.KW;
         pf_tx = wrap2 ? 0 : pf_tx;
         pf_ty += wrap2 ? 1 : 0;
+        const bool wrap3 = pf_ty == p.KH;
+        pf_ty = wrap3 ? 0 : pf_ty;
+        pf_cg += wrap3 ? p.kgroup : 0;
         const bool second = p.C1 > 0 && c0 >= p.C1;         // two-source A: block-uniform select per chunk
         c0 -= second ? p.C1 : 0;
         const unsigned ld = second ? (unsigned)p.lda2 : (unsigned)p.lda;
@@ -195,7 +203,7 @@ __global__ __launch_bounds__(64 * WROWS * WCOLS, 2) void conv_gemm_x6_kernel(CGP
 #pragma unroll
         for (int q = 0; q < PB; ++q)
             rb[q] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(
-                srd_w, (wvalid[q] & !dead) ? (wbase[q] + (unsigned)k0) * 4u : X6_OOB, 0, 0));
+                srd_w, (wvalid[q] & !dead) ? (wbase[q] + k0) * 4u : X6_OOB, 0, 0));
     };
 
     // one fetched float4 -> three 8-byte piece groups of its LDS row

@@ -18,6 +18,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--edit-lanes", type=int, default=2)
 ap.add_argument("--edit-cus", type=int, default=128)
 ap.add_argument("--arith", default="bf16x6")
+ap.add_argument("--front-arith", default=None, help="arithmetic of the inversion stage's engines only (A/B: is it the bf16 stream?)")
 ap.add_argument("--T", type=int, default=200)
 a = ap.parse_args()
 
@@ -29,6 +30,10 @@ dev = torch.device("cuda:0")
 m = models.load_model("cvssp/audioldm2", dev, a.T, allow_synthetic=True)
 m.arith = a.arith
 pipe = ClipPipeline(m, plan="partition", edit_cus=a.edit_cus, edit_lanes=a.edit_lanes, timestep_group=100)
+if a.front_arith:
+    for w in pipe.workers:
+        if w.stage == "front":
+            w.view.arith = a.front_arith
 wave = torch.clip(torch.from_numpy(prepare_waveform(synthetic_clip(10.0, seed=1), 1024 * 160))[None], -1, 1).to(dev)
 
 
@@ -44,9 +49,41 @@ torch.cuda.synchronize()
 def engine(w, B):
     ed = w.view.editor(256, 16)
     cand = sorted(((len(k), e) for k, e in ed._unets.items() if k[0] == B), key=lambda t: -t[0])
-    for pl in ed._plans.values():
-        pl["state"].zero_()
+    with torch.inference_mode():
+        for pl in ed._plans.values():
+            pl["state"].zero_()
     return cand[0][1]
+
+
+class Clocks:
+    """sclk samples (rocm-smi) while a scenario runs: is the slowdown a clock drop under the split-bf16 stream's power?"""
+
+    def __init__(self):
+        import subprocess
+        import threading
+        self.samples, self.stop = [], threading.Event()
+
+        def loop():
+            while not self.stop.is_set():
+                try:
+                    r = subprocess.run(["rocm-smi", "--showclocks", "--json"], capture_output=True, text=True, timeout=5)
+                    d = json.loads(r.stdout)
+                    card = next(iter(d.values()))
+                    v = [val for key, val in card.items() if "sclk" in key.lower()]
+                    if v:
+                        self.samples.append(str(v[0]))
+                except Exception as e:                  # noqa: BLE001
+                    self.samples.append(f"err:{e!r}"[:40])
+                    return
+        self.th = threading.Thread(target=loop, daemon=True)
+
+    def __enter__(self):
+        self.th.start()
+        return self
+
+    def __exit__(self, *a):
+        self.stop.set()
+        self.th.join(timeout=6)
 
 
 front = [(engine(w, 200), w.lane.stream) for w in pipe.workers if w.stage == "front"]
@@ -87,16 +124,26 @@ def run(members):
     return [round(x, 3) for x in out]
 
 
-res = dict(env_GPU_MAX_HW_QUEUES=os.environ.get("GPU_MAX_HW_QUEUES"), arith=a.arith, edit_lanes=a.edit_lanes,
-           edit_lane_cus=pipe.edit_lane_cus)
+res = dict(env_GPU_MAX_HW_QUEUES=os.environ.get("GPU_MAX_HW_QUEUES"), arith=a.arith, front_arith=a.front_arith or a.arith,
+           edit_lanes=a.edit_lanes, edit_lane_cus=pipe.edit_lane_cus)
+
+
+def scenario(name, members, labels):
+    with Clocks() as ck:
+        out = run(members)
+    res[name] = dict(zip(labels, out), sclk=ck.samples[:6])
+    print(name, res[name], file=sys.stderr, flush=True)
+
+
 with torch.inference_mode():
     f, b = front[0], back
-    res["back_lanes_alone_ms_per_fwd"] = run([(e, s, 40) for e, s in b])
-    res["one_back_lane_alone"] = run([(b[0][0], b[0][1], 40)])
-    res["front_alone_ms_per_fwd"] = run([(f[0], f[1], 3)])
-    nb = 40
-    nf = 4
-    res["front_and_back_lanes"] = dict(zip(["front"] + [f"back{k}" for k in range(len(b))],
-                                           run([(f[0], f[1], nf)] + [(e, s, nb) for e, s in b])))
-    res["front_and_one_back"] = dict(zip(["front", "back0"], run([(f[0], f[1], nf), (b[0][0], b[0][1], nb)])))
+    nb, nf = 60, 5
+    bl = [f"back{k}" for k in range(len(b))]
+    scenario("back_lanes_alone", [(e, s, nb) for e, s in b], bl)
+    scenario("one_back_lane_alone", [(b[0][0], b[0][1], nb)], bl[:1])
+    scenario("front_alone", [(f[0], f[1], nf)], ["front"])
+    scenario("front_and_back_lanes", [(f[0], f[1], nf)] + [(e, s, nb) for e, s in b], ["front"] + bl)
+    scenario("front_and_one_back", [(f[0], f[1], nf), (b[0][0], b[0][1], nb)], ["front", "back0"])
+    if len(b) > 1:
+        scenario("front_and_other_back", [(f[0], f[1], nf), (b[1][0], b[1][1], nb)], ["front", "back1"])
 print(json.dumps(res))

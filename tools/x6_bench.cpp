@@ -241,6 +241,7 @@ struct Rec {
 };
 
 static bool read_records(const char* path, std::vector<Rec>& recs);
+static bool g_ab_korder = false;
 static int run_replay_records(const char* path, const std::vector<Rec>& recs, int iters, hipStream_t st, bool x6only);
 
 static int run_replay(const char* path, int iters, hipStream_t st, bool x6only) {
@@ -330,11 +331,14 @@ static int run_replay_records(const char* path, const std::vector<Rec>& recs, in
         int rc0 = 0, rc1 = 0;
         const bool flagged = r.flags & 4;
         // x6only: the fp32 launch of an eligible record is skipped (timing a partition where only the split kernel matters)
-        const float ms0 = (x6only && flagged) ? 0.f : timed(r.flags & ~28, r.tile_f32, C0, &rc0);
+        // korder A/B (round 4): both launches run the record's own arithmetic and tile; C0 = tap-major K order (flag 32), C1 = the
+        // grouped order (cg_params.h kgroup) -- same sums in another order, so rel_l2 ~ 1e-7 doubles as the correctness check
+        const float ms0 = g_ab_korder ? timed((flagged ? r.flags : (r.flags & ~28)) | 32, flagged ? r.i[29] : r.tile_f32, C0, &rc0)
+                          : (x6only && flagged) ? 0.f : timed(r.flags & ~28, r.tile_f32, C0, &rc0);
         float ms1 = ms0;
         double rel = 0.0;
-        if (flagged) {
-            ms1 = timed(r.flags, r.i[29], C1, &rc1);
+        if (flagged || (g_ab_korder && r.i[12] * r.i[13] > 1)) {
+            ms1 = timed(flagged ? r.flags : (r.flags & ~28), flagged ? r.i[29] : r.tile_f32, C1, &rc1);
             if (x6only) { tot6 += ms1; tot32 += ms0; flops += 2.0 * r.i[0] * (double)r.i[1] * r.i[2]; ++n_flagged; continue; }
             HIPCHECK(hipMemsetAsync(d_acc, 0, 16, st)); HIPCHECK(hipMemsetAsync(d_max, 0, 4, st));
             hipLaunchKernelGGL(compare_kernel, dim3(1024), dim3(256), 0, st, C1, C0, c, d_acc, d_max);
@@ -510,6 +514,7 @@ int main(int argc, char** argv) {
         hipStream_t rs = st;
         for (int k = 4; k < argc; ++k) {
             if (!strcmp(argv[k], "x6only")) x6only = true;
+            if (!strcmp(argv[k], "korder")) g_ab_korder = true;
             if (!strcmp(argv[k], "x6")) with_x6 = true;
             if (!strncmp(argv[k], "cus=", 4)) {
                 const int n = atoi(argv[k] + 4);

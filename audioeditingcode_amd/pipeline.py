@@ -97,7 +97,7 @@ class ClipPipeline:
     event_type = torch.cuda.Event
 
     def __init__(self, model, plan="partition", edit_cus=None, edit_lanes=1, lanes=None, launch="graph",
-                 timestep_group=100, overlap_prep=True, lane_cus=None):
+                 timestep_group=100, overlap_prep=True, lane_cus=None, separate_queues=None):
         if getattr(model, "kind", None) == "stable_audio":
             raise NotImplementedError("ClipPipeline drives the mel-latent families (AudioLDM / AudioLDM2 / TANGO)")
         if plan not in ("partition", "lanes"):
@@ -151,6 +151,21 @@ class ClipPipeline:
             back = [_Worker("back", k, self._view(), Lane(dev, cus=lane_cus(k), total=self.total, index=k),
                             Lane(dev, index=1 + k), regime=regime) for k in range(n)]
             self.stages = [("front", ("front",), front), ("back", ("back",), back)]
+            self.queue_log = []
+            if separate_queues is None:
+                separate_queues = n > 1
+            if separate_queues and hasattr(self.lane_type, "respin") and dev.type == "cuda":
+                # every lane that is busy at the same time needs its own dispatch pipe (streams.py); with several edit lanes
+                # the codec also stays on the lane (one busy queue per worker: the chip serves four at a time)
+                from .streams import separate_queues as _separate
+                busy = [front[0].lane] + [w.lane for w in back] + ([front[0].prep] if front[0].prep is not None else [])
+                kept = _separate(busy, log=self.queue_log)
+                front[0].lane = kept[0]
+                for w, ps in zip(back, kept[1:1 + n]):
+                    w.lane = ps
+                if front[0].prep is not None:
+                    front[0].prep = kept[-1]
+            self.codec_on_lane = n > 1
         else:
             n = DEFAULT_LANES if lanes is None else int(lanes)
             if n < 1:
@@ -176,6 +191,14 @@ class ClipPipeline:
             self.stages = [("clip", ("front", "back"),
                             [_Worker("clip", k, self._view(), Lane(dev, cus=cus_of(k), total=self.total, index=1 + k), None,
                                      regime=regime) for k in range(n)])]
+            self.queue_log = []
+            if separate_queues is None:
+                separate_queues = self.lane_cus is not None and n > 1
+            if separate_queues and hasattr(self.lane_type, "respin") and dev.type == "cuda":
+                from .streams import separate_queues as _separate     # one dispatch pipe per busy lane (streams.py)
+                ws = self.stages[0][2]
+                for w, ps in zip(ws, _separate([w.lane for w in ws], log=self.queue_log)):
+                    w.lane = ps
         self._build_lock = threading.Lock()     # an un-warmed worker builds engines (and lazily folds shared weights)
         self.stats = []
 
@@ -300,7 +323,7 @@ class ClipPipeline:
         # beside a busy inversion partition: profiles/r03_codec_partition.md): they run unmasked, and the edit partition is
         # free for the next clip's set-up meanwhile
         cs = st
-        if w.full is not None and w.full.stream is not st:
+        if w.full is not None and w.full.stream is not st and not getattr(self, "codec_on_lane", False):
             cs = w.full.stream
             edited = self.event_type()
             edited.record(st)
@@ -489,6 +512,7 @@ class ClipPipeline:
                     edit_cus=self.edit_cus, edit_lanes=self.edit_lanes, edit_lane_cus=getattr(self, "edit_lane_cus", None), lane_cus=getattr(self, "lane_cus", None),
                     inversion_cus=None if self.edit_cus is None else self.total - self.edit_cus,
                     device_ms={k: dict(n=len(v), avg=sum(v) / len(v)) for k, v in acc.items()},
+                    queue_separation=getattr(self, "queue_log", None),
                     clip_latency_ms_avg=(sum(lats) / len(lats)) if lats else None,
                     clip_latency_ms_max=max(lats) if lats else None)
 

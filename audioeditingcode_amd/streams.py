@@ -9,8 +9,16 @@ lasts ~10 us.  So each class gets its own hardware queue with a DISJOINT CU mask
 
 Bit k of the mask is CU k in the driver's enumeration; consecutive bits rotate over the 8 XCDs, so a contiguous range of
 8*m bits is m CUs on every XCD (each XCD keeps serving both partitions from its own L2).
+
+Disjoint CUs are not enough (measured in round 4, tools/lane_interference.py): every hardware queue is served by one of the
+command processor's few dispatch pipes, and a pipe launches ONE kernel's workgroups at a time.  Two busy queues on the same
+pipe take turns -- an edit lane's 10 us kernels then wait for a batch-200 GEMM to finish handing out its ~3000 workgroups
+(edit step 15.8 -> 47 ms although the CU sets were disjoint), while the same lanes on different pipes run undisturbed.
+Which pipe a queue lands on is the driver's choice at creation, so `separate_queues` measures it: a long dispatch on one
+stream, a chain of tiny kernels on the other, and a stream that is delayed is replaced by a fresh queue with the same mask.
 """
 import ctypes
+import time
 
 import torch
 
@@ -71,6 +79,10 @@ class PartitionStream:
         self.handle = handle
         self.stream = torch.cuda.ExternalStream(handle.value, device=self.device)
 
+    def respin(self, k):
+        """Another hardware queue with this stream's CU mask (the driver may place it on a different dispatch pipe)."""
+        return type(self).acquire(self.device, cus=self.cus, total=self.total, index=1000 + int(k))
+
     def census(self, n_blocks=2048, spin_clocks=200000):
         """Physical CUs this stream's workgroups land on: sorted list of (xcc, se, sh, cu)."""
         out = torch.zeros(2 * n_blocks, dtype=torch.int32, device=self.device)
@@ -88,3 +100,60 @@ class PartitionStream:
             if destroy and self not in self._cache.values():
                 L.check(L.lib().aed_stream_destroy(self.handle), "aed_stream_destroy")
                 self.handle = None
+
+
+def _census_launch(ps, buf, n_blocks, spin):
+    L.check(L.lib().aed_cu_census(buf.data_ptr(), int(n_blocks), int(spin), ctypes.c_void_p(ps.stream.cuda_stream)),
+            "aed_cu_census")
+
+
+def queue_delay(busy, victim, chain=40, rounds=3):
+    """How much longer a chain of `chain` tiny kernels on `victim` takes while `busy` dispatches long grids (ratio of wall
+    times, >= ~1).  ~1: the two hardware queues are served independently; several: they share a dispatch pipe."""
+    dev = victim.device
+    nb = len(busy.cus) if busy.cus is not None else busy.total
+    nv = len(victim.cus) if victim.cus is not None else victim.total
+    big = torch.zeros(2 * 64 * nb, dtype=torch.int32, device=dev)
+    small = torch.zeros(2 * nv, dtype=torch.int32, device=dev)
+
+    def tiny():
+        for _ in range(chain):
+            _census_launch(victim, small, nv, 2000)
+
+    def timed(with_busy):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        if with_busy:
+            for _ in range(rounds):                      # 64 blocks per CU of ~0.17 ms each: the pipe is held ~0.3 ms per grid
+                _census_launch(busy, big, 64 * nb, 400000)
+        tiny()
+        victim.stream.synchronize()
+        dt = time.perf_counter() - t0
+        torch.cuda.synchronize(dev)
+        return dt
+    timed(False)
+    alone = min(timed(False) for _ in range(2))
+    together = min(timed(True) for _ in range(2))
+    return together / max(alone, 1e-6)
+
+
+def separate_queues(streams, threshold=2.0, attempts=6, log=None):
+    """Given PartitionStreams that will be busy AT THE SAME TIME (first = highest priority to keep), return a list in which
+    each later stream has been replaced -- by fresh queues with the same CU mask, `PartitionStream.respin` -- until no earlier
+    stream's dispatches delay it (`queue_delay` < threshold) or `attempts` run out (then the least-delayed candidate is
+    kept).  Streams that are replaced stay alive (process-lifetime cache) but idle."""
+    out = []
+    for ps in streams:
+        best, best_d = ps, None
+        cand = ps
+        for k in range(attempts):
+            d = max([queue_delay(o, cand) for o in out] + [queue_delay(cand, o) for o in out] + [1.0])
+            if log is not None:
+                log.append(dict(cus=None if cand.cus is None else (cand.cus[0], cand.cus[-1] + 1), attempt=k, delay=round(d, 2)))
+            if best_d is None or d < best_d:
+                best, best_d = cand, d
+            if d < threshold:
+                break
+            cand = ps.respin(k + 1)
+        out.append(best)
+    return out

@@ -128,8 +128,9 @@ def test_pc_clis_extract_pt_apply_on_the_gpu(tmp_path, monkeypatch):
     # ---- (2) HIP vs the CPU interpreter stack, same seeds
     a = pext.finish_args(Namespace(seed=1, cfg_tar=3, model_id="tiny/audioldm2", init_aud=None, num_diffusion_steps=T,
                                    source_prompt=["rain"], target_neg_prompt=[""], corr_to_swap=0.8, drift_start=5,
-                                   drift_end=3, results_path="unused", const=1e-2, n_evs=2, patch=None, iters=4,
-                                   dry=False))
+                                   drift_end=3, results_path="unused", const=0.3, n_evs=2, patch=None, iters=4,
+                                   dry=False))      # const: see oracle/make_fullsize_pc_golden.py (1e-2 here gave eigenvalue
+    #                                                 deviations of 1.3e-2 and drifted latents 4.9e-2 apart: amplification ~ 1 / const)
     ap = Namespace(drift_start=5, drift_end=3, amount=1.5, use_specific_ts_pc=None, fix_alpha=None, fade_length=0.0,
                    evs=[1, 2], combine_evs=False, evals_pt=None, rand_v=False, shift_x0_for_np=True, sub_iters=None)
     w0 = torch.randn(1, 8, 32, 16, generator=torch.Generator().manual_seed(5)) * 0.7
@@ -155,8 +156,8 @@ def test_pc_clis_extract_pt_apply_on_the_gpu(tmp_path, monkeypatch):
     out_c = papply.apply_pcs(mc, {k: ck_c[k] for k in keys}, ap, torch.device("cpu"))
     rel = lambda x, y: ((x - y).norm() / y.norm().clamp_min(1e-12)).item()                        # noqa: E731
     stack = lambda lst: torch.cat([t.cpu() for t in lst])                                         # noqa: E731
-    assert rel(stack(ck_g["latents"]), stack(ck_c["latents"])) < 5e-3                             # x_T and the noise maps
-    assert rel(stack(ck_g["xts"]), stack(ck_c["xts"])) < 5e-3                                     # the guided replay
+    assert rel(stack(ck_g["latents"]), stack(ck_c["latents"])) < 1e-4                             # x_T and the noise maps (observed 1.2e-6)
+    assert rel(stack(ck_g["xts"]), stack(ck_c["xts"])) < 5e-4                                     # the guided replay (observed 4.5e-5)
     assert sorted(ck_g["eigdata"]) == sorted(ck_c["eigdata"])
     seen = dict(latents=rel(stack(ck_g["latents"]), stack(ck_c["latents"])), xts=rel(stack(ck_g["xts"]), stack(ck_c["xts"])),
                 final=rel(ck_g["final"].cpu(), ck_c["final"]), drifted=rel(out_g, out_c), eigval_rel=[], cos_min=[])
@@ -168,11 +169,11 @@ def test_pc_clis_extract_pt_apply_on_the_gpu(tmp_path, monkeypatch):
     print("PC CLIs, HIP vs the CPU interpreter stack:", seen)
     for t in ck_c["eigdata"]:
         eg, ec = ck_g["eigdata"][t], ck_c["eigdata"][t]
-        torch.testing.assert_close(eg["eigval"].cpu().reshape(-1), ec["eigval"].reshape(-1), rtol=0.1, atol=1e-6)
+        torch.testing.assert_close(eg["eigval"].cpu().reshape(-1), ec["eigval"].reshape(-1), rtol=3e-3, atol=1e-6)
         cos = (eg["eigvec"].cpu().reshape(2, -1) * ec["eigvec"].reshape(2, -1)).sum(1).abs()
-        assert cos.min() > 0.98, (t, cos)
-    assert rel(ck_g["final"].cpu(), ck_c["final"]) < 5e-3
-    assert out_g.shape == out_c.shape == (2, 8, 32, 16) and rel(out_g, out_c) < 8e-2, rel(out_g, out_c)      # the drift scales eigenvector differences by amount * sqrt(eigval)
+        assert cos.min() > 0.9999, (t, cos)
+    assert rel(ck_g["final"].cpu(), ck_c["final"]) < 1e-3                                          # observed 1.0e-4
+    assert out_g.shape == out_c.shape == (2, 8, 32, 16) and rel(out_g, out_c) < 8e-3, rel(out_g, out_c)      # the drift scales eigenvector differences by amount * sqrt(eigval)
     assert rel(out_g[0:1], ck_g["final"].cpu()) > 1e-3                                           # the drift moved the sample
 
 
@@ -234,6 +235,7 @@ def test_full_size_power_iteration_vs_the_oracle_fixture(golden_dir):
           f"|cos| {one[1]}, principal {one[2]}; {ITERS} iterations: eigenvalues max rel {full[0]:.2e}, |cos| {full[1]}, "
           f"principal {full[2]}; drifted sample rel {e_drift:.2e}")
     assert max(e_step) < 1e-4, e_step
-    assert one[0] < 1e-3 and min(one[2]) > 0.9999, one               # one application of the Jacobian: tight
-    assert full[0] < 1e-2 and min(full[2]) > 0.999, full            # five un-contracting iterations accumulate ~3e-3 each
+    # ~10x the values observed on the MI355X (round 4): 1 iteration 1.5e-6 / principal 1.000000; 5 iterations 1.6e-4 / 0.999976
+    assert one[0] < 5e-5 and min(one[2]) > 0.99999, one              # one application of the Jacobian
+    assert full[0] < 2e-3 and min(full[2]) > 0.9997, full           # five un-contracting iterations
     assert e_drift < 1e-4, e_drift

@@ -22,7 +22,7 @@ def short(n):
 
 
 def fam(n):
-    m = re.match(r"(conv_gemm_kernel<\d+, \d+|lin_gemm_kernel<\d+, \d+, \d+|conv_gemm_wsk_kernel|attention_split_kernel<\d+|"
+    m = re.match(r"(conv_gemm_x6_kernel<\d+, \d+|conv_gemm_kernel<\d+, \d+|lin_gemm_kernel<\d+, \d+, \d+|conv_gemm_wsk_kernel|attention_split_kernel<\d+|"
                  r"attention_kernel<\d+|gn_small_kernel|gn_stats_kernel|gn_apply_kernel|splitk_reduce_kernel)", n)
     return m.group(1) + (">" if "<" in m.group(1) else "") if m else n[:40]
 
@@ -72,7 +72,7 @@ if n_gemm:
 if out_json:
     h = hashlib.sha1()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for f_ in ("conv_gemm.hip", "lin_gemm.hip", "cg_params.h", "aed_common.h"):     # same file set as bench.csrc_hash()
+    for f_ in ("conv_gemm.hip", "conv_gemm_x6.hip", "lin_gemm.hip", "cg_params.h", "aed_common.h"):     # = bench.csrc_hash()
         h.update(open(os.path.join(root, "audioeditingcode_amd", "csrc", f_), "rb").read())
     # --alg-total-bytes: the sum tools/pmc_forward.py prints ("algorithmic bytes", all forwards of the profiled command);
     # measured and algorithmic are divided by the SAME launch count so their ratio is the ratio of the totals

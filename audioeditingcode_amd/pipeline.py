@@ -97,7 +97,7 @@ class ClipPipeline:
     event_type = torch.cuda.Event
 
     def __init__(self, model, plan="partition", edit_cus=None, edit_lanes=1, lanes=None, launch="graph",
-                 timestep_group=100, overlap_prep=True, lane_cus=None, separate_queues=None):
+                 timestep_group=100, overlap_prep=True, lane_cus=None, separate_queues=None, codec_stage=None):
         if getattr(model, "kind", None) == "stable_audio":
             raise NotImplementedError("ClipPipeline drives the mel-latent families (AudioLDM / AudioLDM2 / TANGO)")
         if plan not in ("partition", "lanes"):
@@ -150,22 +150,35 @@ class ClipPipeline:
                     regime = name
             back = [_Worker("back", k, self._view(), Lane(dev, cus=lane_cus(k), total=self.total, index=k),
                             Lane(dev, index=1 + k), regime=regime) for k in range(n)]
+            # Several edit lanes: the edited latent's VAE decode + vocoder (throughput kernels, 44 ms on the whole chip, ~150 ms on
+            # a 64-CU lane) leave the lane -- a third stage with ONE worker decodes on a queue of its own over the INVERSION
+            # partition's CUs (the front stage has the slack once two edit lanes share the back stage's work), and the next
+            # clip's set-up shares that queue: four busy hardware queues in all, the number of dispatch pipes that are served
+            # concurrently (streams.py).  With one edit lane the codec stays in the back stage on an unmasked stream (round 3).
+            self.codec_stage = n > 1 if codec_stage is None else bool(codec_stage)
             self.stages = [("front", ("front",), front), ("back", ("back",), back)]
+            codec = []
+            if self.codec_stage:
+                codec = [_Worker("codec", 0, self._view(), Lane(dev, cus=range(self.edit_cus, self.total), total=self.total,
+                                                                   index=2), None)]
+                self.stages.append(("codec", ("codec",), codec))
+                if front[0].prep is not None:
+                    front[0].prep = codec[0].lane
             self.queue_log = []
             if separate_queues is None:
                 separate_queues = n > 1
             if separate_queues and hasattr(self.lane_type, "respin") and dev.type == "cuda":
-                # every lane that is busy at the same time needs its own dispatch pipe (streams.py); with several edit lanes
-                # the codec also stays on the lane (one busy queue per worker: the chip serves four at a time)
+                # every lane that is busy at the same time needs its own dispatch pipe (streams.py)
                 from .streams import separate_queues as _separate
-                busy = [front[0].lane] + [w.lane for w in back] + ([front[0].prep] if front[0].prep is not None else [])
+                busy = [front[0].lane] + [w.lane for w in back] + [w.lane for w in codec]
                 kept = _separate(busy, log=self.queue_log)
                 front[0].lane = kept[0]
                 for w, ps in zip(back, kept[1:1 + n]):
                     w.lane = ps
-                if front[0].prep is not None:
-                    front[0].prep = kept[-1]
-            self.codec_on_lane = n > 1
+                if codec:
+                    codec[0].lane = kept[1 + n]
+                    if front[0].prep is not None:
+                        front[0].prep = codec[0].lane
         else:
             n = DEFAULT_LANES if lanes is None else int(lanes)
             if n < 1:
@@ -308,8 +321,9 @@ class ClipPipeline:
         done.record(st)
         return dict(x0=x0, zs=zs, wts=wts, done=done)
 
-    def _back(self, w, st, job, f):
-        """main_run.py:152-185: edit loop from x_tstart -> VAE decode -> vocoder (edited + original)."""
+    def _back(self, w, st, job, f, with_codec=True):
+        """main_run.py:152-185: edit loop from x_tstart (-> VAE decode -> vocoder of edited + original unless a codec stage
+        follows)."""
         v, a = w.view, job["a"]
         st.wait_event(f["done"])
         for t in (f["x0"], f["zs"], f["wts"]):
@@ -319,11 +333,15 @@ class ClipPipeline:
         w_edit, _ = inversion_reverse_process(v, xT=f["wts"], tstart=torch.tensor([tstart], dtype=torch.int),
                                               etas=a["eta"], prompts=a["tgt"], neg_prompts=a["neg"],
                                               cfg_scales=a["cfg_tar"], zs=f["zs"][:tstart])
+        if not with_codec:
+            edited = self.event_type()
+            edited.record(st)
+            return dict(x0=f["x0"], w_edit=w_edit, done=edited)
         # VAE decode + vocoder are throughput kernels (44 ms alone on 256 CUs, 71 ms on the 128-CU partition, 64 ms unmasked
         # beside a busy inversion partition: profiles/r03_codec_partition.md): they run unmasked, and the edit partition is
         # free for the next clip's set-up meanwhile
         cs = st
-        if w.full is not None and w.full.stream is not st and not getattr(self, "codec_on_lane", False):
+        if w.full is not None and w.full.stream is not st:
             cs = w.full.stream
             edited = self.event_type()
             edited.record(st)
@@ -332,12 +350,24 @@ class ClipPipeline:
                 if t.is_cuda:
                     t.record_stream(cs)
         with self._stream_ctx(cs):
-            x0_dec = v.vae_decode(w_edit)
-            if x0_dec.dim() < 4:
-                x0_dec = x0_dec[None]
-            audio = v.decode_to_mel(x0_dec)              # CPU tensors: the host blocks here until this clip is done
-            orig = v.decode_to_mel(f["x0"])
+            return self._decode(v, w_edit, f["x0"])
+
+    @staticmethod
+    def _decode(v, w_edit, x0):
+        x0_dec = v.vae_decode(w_edit)
+        if x0_dec.dim() < 4:
+            x0_dec = x0_dec[None]
+        audio = v.decode_to_mel(x0_dec)              # CPU tensors: the host blocks here until this clip is done
+        orig = v.decode_to_mel(x0)
         return audio, orig, w_edit
+
+    def _codec(self, w, st, job, e):
+        """main_run.py:184-185 on the codec stage's own queue: edited latent -> mel -> waveform, original mel -> waveform."""
+        st.wait_event(e["done"])
+        for t in (e["w_edit"], e["x0"]):
+            if t.is_cuda:
+                t.record_stream(st)
+        return self._decode(w.view, e["w_edit"], e["x0"])
 
     # ------------------------------------------------------------------ workers
     def _pick_lane(self, w, job, stage_idx):
@@ -359,7 +389,9 @@ class ClipPipeline:
             if "front" in halves:
                 payload = self._front(w, st, job, i)
             if "back" in halves:
-                payload = self._back(w, st, job, payload)
+                payload = self._back(w, st, job, payload, with_codec=not getattr(self, "codec_stage", False))
+            if "codec" in halves:
+                payload = self._codec(w, st, job, payload)
         w.warm = True
         return payload
 
@@ -404,7 +436,8 @@ class ClipPipeline:
                 if last_stage:
                     job["out"][i] = payload
                 else:
-                    job["front_event"] = payload["done"]
+                    if stage_idx == 0:
+                        job["front_event"] = payload["done"]
                     job["queues"][stage_idx + 1].put((i, payload))
         finally:
             v.__dict__.pop("sample_xts_from_x0", None)

@@ -212,7 +212,7 @@ def main():
                          "inversion on disjoint CU partitions; 'lanes' = --lanes whole clips at once in the reference's "
                          "step order; 'serial' = one clip at a time")
     ap.add_argument("--edit-cus", type=int, default=128, help="partition plan: CUs of the edit-loop partition")
-    ap.add_argument("--edit-lanes", type=int, default=1,
+    ap.add_argument("--edit-lanes", type=int, default=2,
                     help="partition plan: concurrent edit loops (disjoint CU slices of the edit partition where they are "
                          "multiples of 32 CUs, shared otherwise)")
     ap.add_argument("--arith", default="bf16x6", choices=["f32", "bf16x6"],
@@ -385,9 +385,12 @@ def main():
     if PLAN != "serial":
         extra["pipeline"] = pipe.report()
         if PLAN == "partition":
-            headline = (f"{pipe.clips_in_flight} clips in flight per GPU: clip i+1's forward inversion ({args.group} timesteps "
-                        f"per U-Net call) on {pipe.total - pipe.edit_cus} CUs beside clip i's edit loop "
-                        f"({pipe.edit_lanes} lane(s)) on {pipe.edit_cus} CUs")
+            lanes_txt = (f"{pipe.edit_lanes} edit loops on disjoint {pipe.edit_lane_cus}-CU lanes" if pipe.edit_lanes > 1 and
+                         pipe.edit_lane_cus != pipe.edit_cus else f"{pipe.edit_lanes} edit loop(s) on {pipe.edit_cus} CUs")
+            headline = (f"up to {pipe.clips_in_flight} clips in flight per GPU, each alone in its U-Net batches: forward inversion "
+                        f"({args.group} timesteps per U-Net call) on {pipe.total - pipe.edit_cus} CUs beside {lanes_txt}"
+                        + ("; VAE decode + vocoder as a third stage on a queue of its own over the inversion partition's CUs"
+                           if getattr(pipe, "codec_stage", False) else ""))
         elif args.lane_cus:
             headline = (f"{pipe.clips_in_flight} whole clips in flight per GPU, each on its own {args.lane_cus}-CU slice of the chip "
                         f"(timestep-batched inversion, {args.group} timesteps per U-Net call, then the edit loop)")

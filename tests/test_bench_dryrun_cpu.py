@@ -119,6 +119,7 @@ class _Pipe:
                  overlap_prep=True):
         assert launch in ("eager", "graph") and plan in ("partition", "lanes")
         self.plan, self.total, self.edit_cus, self.edit_lanes = plan, 256, edit_cus, edit_lanes
+        self.edit_lane_cus, self.codec_stage = edit_cus, False
         if plan == "partition":
             self.workers = [_W("front", _Model([2 * timestep_group]))] + [_W("back", _Model([2])) for _ in range(edit_lanes)]
         else:

@@ -98,7 +98,7 @@ def test_partition_pipeline_full_size_audioldm2_bit_identical_and_finite():
     seeds = [7, 8, 9, 10]
     ref = _serial_b(m, mels, T, tstart, seeds, G)
     pipe = ClipPipeline(m, plan="partition", edit_cus=128, timestep_group=G)
-    assert [w.regime for w in pipe.workers] == [None, "cus128"]
+    assert [w.regime for w in pipe.workers] == ["cus128", "cus128"]      # both stages take the tables swept on 128-CU streams
     pipe.warm_up(mels[0], *ARGS, T, tstart)
     got = pipe.edit_clips(mels, *ARGS, T, tstart, seeds=seeds)
     alone = [pipe.edit_clips([x0], *ARGS, T, tstart, seeds=[s])[0] for x0, s in zip(mels, seeds)]

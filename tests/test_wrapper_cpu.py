@@ -380,11 +380,15 @@ def test_clip_pipeline_plans_equal_serial_edit_clip(cpu_stack, monkeypatch):
         monkeypatch.setattr(ed_cls, "edit", lambda self, *a, **k: (seen.append(("edit", self.loop_stream().name)),
                                                                    orig_edit(self, *a, **k))[1])
         pipe = ClipPipeline(m, plan="partition", edit_cus=96, edit_lanes=2, timestep_group=3)
-        assert [w.stage for w in pipe.workers] == ["front", "back", "back"] and pipe.clips_in_flight == 3
+        # two edit lanes -> a third stage decodes (VAE decode + vocoder) on a queue over the inversion partition's CUs
+        assert [w.stage for w in pipe.workers] == ["front", "back", "back", "codec"] and pipe.clips_in_flight == 4
+        assert pipe.workers[3].lane.cus == list(range(96, 256)) and pipe.codec_stage
+        assert not ClipPipeline(m, plan="partition", edit_cus=96, timestep_group=3).codec_stage           # one lane: as in round 3
         assert pipe.workers[0].lane.cus == list(range(96, 256)) and pipe.workers[1].lane.cus == list(range(96))
         assert pipe.workers[2].lane.cus == list(range(96))              # 48 CUs per lane is not a legal mask: the lanes share
         split = ClipPipeline(m, plan="partition", edit_cus=128, edit_lanes=2, timestep_group=3)
-        assert [w.lane.cus for w in split.workers] == [list(range(128, 256)), list(range(64)), list(range(64, 128))]
+        assert [w.lane.cus for w in split.workers] == [list(range(128, 256)), list(range(64)), list(range(64, 128)),
+                                                       list(range(128, 256))]
         # 64-CU lanes and the 128-CU inversion partition take the tile tables swept on streams of that size (round 4)
         assert split.edit_lane_cus == 64 and split.workers[1].regime == "cus64" and split.workers[0].regime == "cus128"
         quad = ClipPipeline(m, plan="lanes", lanes=4, lane_cus=64, timestep_group=3)       # four mini-chips, whole clips each

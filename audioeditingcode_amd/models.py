@@ -529,9 +529,8 @@ class StableAudWrapper(PipelineWrapper):
     [1, 64, 1024], CosineDPMSolver++ (SDE, order 2) inversion / edit, Oobleck VAE on raw 44.1 kHz stereo.  Same method
     names and argument meaning; every tensor-valued method runs in libaed.so.  `self.model` has no `unet` attribute,
     which is how the reference's loops pick the 3-D expands (inversion_utils.py:88-89)."""
-    # DiT engines: fp32 MFMA until the split-bf16 arithmetic has its own full-length parity run for this family
-    # (tools/bench_stable_audio.py --arith bf16x6; DESIGN.md section 8)
-    arith = "f32"
+    # DiT engines: split-bf16 GEMMs like the U-Net families since its full-length run against the oracle fixture (round 4: edited
+    # latent 3.7e-6 from the CPU oracle at T=200 in both arithmetics, 10.2 s per clip against 13.6 s; DESIGN.md section 8)
 
     family_name = "stable_audio"
 

@@ -151,34 +151,27 @@ class ClipPipeline:
             back = [_Worker("back", k, self._view(), Lane(dev, cus=lane_cus(k), total=self.total, index=k),
                             Lane(dev, index=1 + k), regime=regime) for k in range(n)]
             # Several edit lanes: the edited latent's VAE decode + vocoder (throughput kernels, 44 ms on the whole chip, ~150 ms on
-            # a 64-CU lane) leave the lane -- a third stage with ONE worker decodes on a queue of its own over the INVERSION
-            # partition's CUs (the front stage has the slack once two edit lanes share the back stage's work), and the next
-            # clip's set-up shares that queue: four busy hardware queues in all, the number of dispatch pipes that are served
-            # concurrently (streams.py).  With one edit lane the codec stays in the back stage on an unmasked stream (round 3).
+            # a 64-CU lane) leave the lane.  A third stage with ONE worker decodes ON THE INVERSION PARTITION'S OWN QUEUE, in
+            # stream order between that stage's inversions: the front stage has the slack once two lanes share the back stage's
+            # work, and a queue of its own over the same CUs was measured 8x slower (codec and batch-200 workgroups then
+            # compete for the same CUs one workgroup at a time: 600 ms per clip, and the inversion slows as well).  The next
+            # clip's set-up stays on the front lane too: three busy hardware queues, each on a dispatch pipe of its own
+            # (streams.py).  With one edit lane the codec stays in the back stage on an unmasked stream (round 3).
             self.codec_stage = n > 1 if codec_stage is None else bool(codec_stage)
             self.stages = [("front", ("front",), front), ("back", ("back",), back)]
-            codec = []
             if self.codec_stage:
-                codec = [_Worker("codec", 0, self._view(), Lane(dev, cus=range(self.edit_cus, self.total), total=self.total,
-                                                                   index=2), None)]
-                self.stages.append(("codec", ("codec",), codec))
-                if front[0].prep is not None:
-                    front[0].prep = codec[0].lane
+                front[0].prep = None
+                self.stages.append(("codec", ("codec",), [_Worker("codec", 0, self._view(), front[0].lane, None)]))
             self.queue_log = []
             if separate_queues is None:
                 separate_queues = n > 1
             if separate_queues and hasattr(self.lane_type, "respin") and dev.type == "cuda":
                 # every lane that is busy at the same time needs its own dispatch pipe (streams.py)
                 from .streams import separate_queues as _separate
-                busy = [front[0].lane] + [w.lane for w in back] + [w.lane for w in codec]
+                busy = [front[0].lane] + [w.lane for w in back]            # (the first stream is never replaced)
                 kept = _separate(busy, log=self.queue_log)
-                front[0].lane = kept[0]
                 for w, ps in zip(back, kept[1:1 + n]):
                     w.lane = ps
-                if codec:
-                    codec[0].lane = kept[1 + n]
-                    if front[0].prep is not None:
-                        front[0].prep = codec[0].lane
         else:
             n = DEFAULT_LANES if lanes is None else int(lanes)
             if n < 1:

@@ -434,9 +434,9 @@ class StableAudioEditEngine(LoopPlumbing):
                 "aed_sample_xts_from_x0")
         return xts
 
-    # EXPERIMENTAL (round 3): arithmetic of the DiT engines' LDS-staged GEMMs (tape.arith_mode); set by
-    # StableAudWrapper.editor from `model.arith`.  Not measured on hardware yet for this model.
-    arith = "f32"
+    # arithmetic of the DiT engines' LDS-staged GEMMs (tape.arith_mode; set by StableAudWrapper.editor from `model.arith`):
+    # "bf16x6" = exact three-way bf16 split of the fp32 operands, six bf16-MFMA products, fp32 accumulate; "f32" = fp32 MFMAs
+    arith = "bf16x6"
 
     def _dit(self, B, S, tt, tgroup, rows_per_t):
         with tape_mod.arith_mode(self.arith):

@@ -815,7 +815,7 @@ def sub_benchmarks(elapsed_s):
     jobs = [("config3_per_rank", [py, os.path.join(ROOT, "bench.py"), "--clips-per-gpu", "8", "--steps", "1", "--warmup",
                                   "1", "--lanes", "1", "--no-extras", "--no-cpu-baseline", "--no-batched"], 240),
             ("config4_pc_extract_apply", [py, os.path.join(ROOT, "tools", "bench_config4.py")], 300),
-            ("config5_stable_audio_fp32", [py, os.path.join(ROOT, "tools", "bench_stable_audio.py"), "--steps", "1",
+            ("config5_stable_audio", [py, os.path.join(ROOT, "tools", "bench_stable_audio.py"), "--steps", "1",
                                            "--warmup", "1"], 300),
             # the round-1..3 arithmetic (fp32-input MFMAs everywhere) through the same pipeline, for the A/B in one driver run
             ("pipeline_arith_f32", [py, os.path.join(ROOT, "bench.py"), "--arith", "f32", "--steps", "6", "--warmup", "2",

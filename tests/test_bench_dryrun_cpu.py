@@ -236,7 +236,7 @@ def test_extras_are_reported_and_never_fatal():
     assert out["parity"] == dict(latent_rel_l2=1e-4, parity_T200=dict(latent_rel_l2=2e-5))      # live T=8 leg + fixture leg
     assert out["config3_per_rank"]["value"] == 2.5 and out["config3_per_rank"]["roofline"] == {"frac": 0.5}
     assert out["config4_pc_extract_apply"]["failed"] == "rc=3"
-    assert out["config5_stable_audio_fp32"]["value"] == 2.5
+    assert out["config5_stable_audio"]["value"] == 2.5
 
 
 def test_roofline_fraction_check_refuses_the_round_3_defect():

@@ -49,14 +49,18 @@ def test_partition_pipeline_is_bit_identical_to_one_clip_at_a_time_tiny(edit_lan
     ref = _serial_b(m, mels, T, tstart, seeds, G)
     pipe = ClipPipeline(m, plan="partition", edit_cus=96, edit_lanes=edit_lanes, launch=launch, timestep_group=G,
                         overlap_prep=overlap)
-    assert (pipe.workers[0].prep is not None) == overlap
+    assert (pipe.workers[0].prep is not None) == (overlap and edit_lanes == 1)       # several lanes: set-up stays on the front lane
     pipe.warm_up(wavs[0], *ARGS, T, tstart, prepare=to_mel)
     got = pipe.edit_clips(wavs, *ARGS, T, tstart, seeds=seeds, prepare=to_mel)
     for i, ((a, o, w), (a2, o2, w2)) in enumerate(zip(got, ref)):
         assert torch.equal(w, w2), (i, float((w - w2).abs().max()))
         assert torch.equal(a, a2) and torch.equal(o, o2), i
     rep = pipe.report()
-    assert rep["plan"] == "partition" and rep["edit_cus"] == 96 and rep["clips_in_flight"] == 1 + edit_lanes
+    # two edit lanes: + the codec stage's worker (VAE decode + vocoder on the inversion partition's queue)
+    assert rep["plan"] == "partition" and rep["edit_cus"] == 96
+    assert rep["clips_in_flight"] == 1 + edit_lanes + (1 if edit_lanes > 1 else 0)
+    if edit_lanes > 1:
+        assert rep["device_ms"]["codec_lane"]["n"] == 5 and pipe.workers[-1].lane is pipe.workers[0].lane
     assert rep["device_ms"]["front_chip"]["n"] >= 1               # the first inversion ran on the whole chip (fill)
     assert sum(v["n"] for k, v in rep["device_ms"].items() if k.startswith("back")) == 5
     pipe.close()

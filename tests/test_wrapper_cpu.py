@@ -382,7 +382,7 @@ def test_clip_pipeline_plans_equal_serial_edit_clip(cpu_stack, monkeypatch):
         pipe = ClipPipeline(m, plan="partition", edit_cus=96, edit_lanes=2, timestep_group=3)
         # two edit lanes -> a third stage decodes (VAE decode + vocoder) on a queue over the inversion partition's CUs
         assert [w.stage for w in pipe.workers] == ["front", "back", "back", "codec"] and pipe.clips_in_flight == 4
-        assert pipe.workers[3].lane.cus == list(range(96, 256)) and pipe.codec_stage
+        assert pipe.workers[3].lane is pipe.workers[0].lane and pipe.codec_stage           # decodes on the inversion partition's queue
         assert not ClipPipeline(m, plan="partition", edit_cus=96, timestep_group=3).codec_stage           # one lane: as in round 3
         assert pipe.workers[0].lane.cus == list(range(96, 256)) and pipe.workers[1].lane.cus == list(range(96))
         assert pipe.workers[2].lane.cus == list(range(96))              # 48 CUs per lane is not a legal mask: the lanes share

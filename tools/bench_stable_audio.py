@@ -19,8 +19,8 @@ ap.add_argument("--tstart", type=int, default=100)
 ap.add_argument("--group", type=int, default=20)
 ap.add_argument("--schedule", default="batched", choices=["batched", "sequential"])
 ap.add_argument("--model_id", default="stabilityai/stable-audio-open-1.0")
-ap.add_argument("--arith", default="f32", choices=["f32", "bf16x6"],
-                help="EXPERIMENTAL: arithmetic of the DiT engines' LDS-staged GEMMs (tape.arith_mode; csrc/conv_gemm_x6.hip)")
+ap.add_argument("--arith", default="bf16x6", choices=["f32", "bf16x6"],
+                help="arithmetic of the DiT engines' LDS-staged GEMMs (tape.arith_mode; csrc/conv_gemm_x6.hip): bf16x6 = the product")
 args = ap.parse_args()
 
 from audioeditingcode_amd import models                     # noqa: E402

@@ -669,7 +669,7 @@ def roofline_leg(m, pipe, args, NC, dt):
     # passes serialise every dispatch and cannot run inside a timed bench) committed under profiles/, used only when
     # they were taken on THIS source tree (hash of csrc/); null otherwise
     traffic = traffic_note = None
-    for name in ("r03_pmc_forward.json", "r02_pmc_forward.json"):
+    for name in ("r04_pmc_forward.json", "r03_pmc_forward.json", "r02_pmc_forward.json"):
         pmc_path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(pmc_path):
             continue

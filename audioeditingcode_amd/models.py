@@ -87,6 +87,8 @@ class PipelineWrapper(torch.nn.Module):
     # fp32 operands, six bf16-MFMA piece products, fp32 accumulate (results as close to fp64 as the fp32-MFMA chain's);
     # "f32" = fp32-input MFMAs everywhere.  Set on the class or on an instance BEFORE the first editor() call of a shape.
     arith = "bf16x6"
+    # arithmetic of the codec engines (STFT-as-DFT, VAE, vocoder; `_cached`), independent of `arith`
+    codec_arith = "f32"
 
     def __init__(self, model_id: str, device: torch.device, double_precision: bool = False,
                  token: Optional[str] = None, seed: int = 0, state_dicts: Optional[Dict] = None,
@@ -170,7 +172,7 @@ class PipelineWrapper(torch.nn.Module):
     def _cached(self, key, make):
         # EXPERIMENTAL: `codec_arith = "bf16x6"` builds the codec engines (STFT-as-DFT, VAE, vocoder) under tape.arith_mode
         # (split-bf16 GEMMs, csrc/conv_gemm_x6.hip); default "f32".  Independent of `arith` (the U-Net / DiT engines).
-        arith = getattr(self, "codec_arith", "f32")
+        arith = self.codec_arith
         key = key if arith == "f32" else key + (arith,)
         if key not in self._engines:
             with tape_mod.arith_mode(arith):

@@ -97,7 +97,8 @@ class ClipPipeline:
     event_type = torch.cuda.Event
 
     def __init__(self, model, plan="partition", edit_cus=None, edit_lanes=1, lanes=None, launch="graph",
-                 timestep_group=100, overlap_prep=True, lane_cus=None, separate_queues=None, codec_stage=None):
+                 timestep_group=100, overlap_prep=True, lane_cus=None, separate_queues=None, codec_stage=None,
+                 share_edit_cus=False):
         if getattr(model, "kind", None) == "stable_audio":
             raise NotImplementedError("ClipPipeline drives the mel-latent families (AudioLDM / AudioLDM2 / TANGO)")
         if plan not in ("partition", "lanes"):
@@ -141,7 +142,8 @@ class ClipPipeline:
             # lane k runs on CUs [k * edit_cus / n, (k + 1) * edit_cus / n).  Otherwise the lanes SHARE the partition's CUs --
             # measured in round 3 (128 CUs, 2 lanes): CU-time bound, 2 x 2.87 s per clip per lane = the one-lane rate.
             n = self.edit_lanes
-            per = self.edit_cus // n if (n > 1 and self.edit_cus % n == 0 and (self.edit_cus // n) % 32 == 0) else None
+            per = self.edit_cus // n if (n > 1 and self.edit_cus % n == 0 and (self.edit_cus // n) % 32 == 0
+                                         and not share_edit_cus) else None
             self.edit_lane_cus = per or self.edit_cus
             lane_cus = (lambda k: range(k * per, (k + 1) * per)) if per else (lambda k: range(self.edit_cus))
             regime = None
@@ -246,7 +248,11 @@ class ClipPipeline:
         finally:
             w.view._lane_stream = None
         w.last = (t1, st)
-        self.stats.append((w.stage, w.k, "chip" if (lane is w.full and w.full is not None) else "lane", t0, t1))
+        where = "chip" if (lane is w.full and w.full is not None) else "lane"
+        self.stats.append((w.stage, w.k, where, t0, t1))
+        for name, ev in getattr(w, "marks", None) or ():        # sub-phase marks a half recorded on this stream
+            self.stats.append((f"{w.stage}.{name}", w.k, where, t0, ev))
+        w.marks = None
 
     # ------------------------------------------------------------------ the two halves of main_run.edit_clip
     @staticmethod
@@ -309,6 +315,9 @@ class ClipPipeline:
             for t in (x0, w0, prepared["xts0"], *conds):
                 if torch.is_tensor(t) and t.is_cuda:
                     t.record_stream(st)
+        setup = self.event_type(enable_timing=True)
+        setup.record(st)                # everything before this on the lane is the clip's set-up (report(): front.setup_*)
+        w.marks = [("setup", setup)]
         _, zs, wts, _ = run_forward(v, w0, prepared, a["eta"], a["cfg_src"], True, a["schedule"], a["group"])
         done = self.event_type()
         done.record(st)
@@ -488,6 +497,10 @@ class ClipPipeline:
         self.stats, self._times = [], job["times"]
         if not job["items"]:
             return []
+        self._base = None
+        if self.model.device.type == "cuda":
+            self._base = self.event_type(enable_timing=True)     # origin of report()'s per-job timeline
+            self._base.record(self.full.stream)
         ths = [threading.Thread(target=self._run_stage, args=(s, job), daemon=True) for s in range(len(self.stages))]
         for th in ths:
             th.start()
@@ -526,9 +539,14 @@ class ClipPipeline:
         where they ran (their CU partition, or the whole chip during fill / drain)."""
         if self.model.device.type == "cuda":
             torch.cuda.synchronize(self.model.device)
-        acc = {}
+        acc, timeline = {}, []
+        base = getattr(self, "_base", None)
         for stage, k, where, t0, t1 in self.stats:
             acc.setdefault(f"{stage}_{where}", []).append(t0.elapsed_time(t1))
+            if base is not None and "." not in stage:
+                # device-side start / end of every job relative to the start of edit_clips: which queue was busy when
+                timeline.append([f"{stage}{k}", where, round(base.elapsed_time(t0), 1), round(base.elapsed_time(t1), 1)])
+        timeline.sort(key=lambda r: r[2])
         lat = {}
         for t in getattr(self, "_times", []):
             d = lat.setdefault(t["clip"], [t["start"], t["end"]])
@@ -538,7 +556,7 @@ class ClipPipeline:
                     edit_cus=self.edit_cus, edit_lanes=self.edit_lanes, edit_lane_cus=getattr(self, "edit_lane_cus", None), lane_cus=getattr(self, "lane_cus", None),
                     inversion_cus=None if self.edit_cus is None else self.total - self.edit_cus,
                     device_ms={k: dict(n=len(v), avg=sum(v) / len(v)) for k, v in acc.items()},
-                    queue_separation=getattr(self, "queue_log", None),
+                    queue_separation=getattr(self, "queue_log", None), timeline=timeline,
                     clip_latency_ms_avg=(sum(lats) / len(lats)) if lats else None,
                     clip_latency_ms_max=max(lats) if lats else None)
 

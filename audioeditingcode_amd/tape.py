@@ -86,6 +86,7 @@ def tile_regime(name):
 #   (tools/bf16_split_study.py, profiles/r03_x6_gemm.md), 1.5-1.8x faster at the inversion's batch-200 shapes.  Ops the
 #   split kernel does not take (latency-regime tiles >= 10, skinny tiles 5 / 6, scalar-gather shapes) stay fp32.
 ARITH_FLAGS = {"f32": 0, "bf16x6": 4 | 8}
+DEFAULT_ARITH = "f32"   # arithmetic of engines built OUTSIDE any arith_mode context (tests/conftest.py --codec-arith sets it)
 
 
 @contextlib.contextmanager
@@ -93,7 +94,7 @@ def arith_mode(name):
     """Engines built inside this context (on this thread) mark their eligible AED_OP_CONV_GEMM records with ARITH_FLAGS[name]."""
     if name not in ARITH_FLAGS:
         raise KeyError(f"unknown arithmetic {name!r} (have {sorted(ARITH_FLAGS)})")
-    prev = getattr(_regime, "arith", "f32")
+    prev = getattr(_regime, "arith", None)
     _regime.arith = name
     try:
         yield
@@ -277,7 +278,7 @@ class Tape:
              C1 if x2 is not None else 0, lda2 or 0, a_bs2 or 0, int(geglu), sm_group, w_bs, vec_ld, vec_bs]
         n_out = N // 2 if geglu else N
         flags = 2 if LATE_EPILOGUE else 0
-        arith = ARITH_FLAGS[getattr(_regime, "arith", "f32")]
+        arith = ARITH_FLAGS[getattr(_regime, "arith", None) or DEFAULT_ARITH]
         x6_ok = arith and vec_ok and B * a_bs + IH * IW * lda < (1 << 29) and N * K < (1 << 29) and \
             (x2 is None or B * a_bs2 + IH * IW * lda2 < (1 << 29)) and not (w_bs or vec_bs or sm_group or vec_ld != 1) and \
             self._ptr(x) % 16 == 0 and self._ptr(w) % 16 == 0      # buffer_load_dwordx4 (the launcher's `fits`)

@@ -220,6 +220,12 @@ def main():
                          "fp32 operand cut exactly into three bf16 pieces in the loader, six piece products on the bf16 MFMAs, "
                          "fp32 accumulation (csrc/conv_gemm_x6.hip; as close to fp64 as the fp32 chain); f32 = fp32-input MFMAs "
                          "everywhere (the round-1..3 arithmetic, kept for A/B)")
+    ap.add_argument("--edit-share", action="store_true",
+                    help="partition plan: the edit lanes SHARE the edit partition's CUs (each on its own dispatch pipe) instead of "
+                         "disjoint slices")
+    ap.add_argument("--codec-arith", default=None, choices=["f32", "bf16x6"],
+                    help="arithmetic of the codec engines' LDS-staged GEMMs (STFT-as-DFT, VAE, vocoder); default: the wrapper's "
+                         "`codec_arith`")
     ap.add_argument("--lanes", type=int, default=3, help="lanes plan: clips in flight")
     ap.add_argument("--lane-cus", type=int, default=0,
                     help="lanes plan: every lane on its own slice of this many CUs (a multiple of 32), whole clips with the "
@@ -264,6 +270,8 @@ def main():
     t_bcast = time.time() - t0
     m = models.load_model(args.model_id, dev, args.T, state_dicts=sds, allow_synthetic=True)   # no checkpoint exists offline
     m.arith = args.arith        # lane views of the pipeline copy it
+    if args.codec_arith is not None:
+        m.codec_arith = args.codec_arith
 
     # ---- synthetic inputs, resident in HBM before the timed region
     src, tgt, neg = ["a recording of a piano melody"], ["a recording of an electric guitar melody"], [""]
@@ -374,7 +382,7 @@ def main():
         try:
             pipe = ClipPipeline(m, plan=PLAN, edit_cus=args.edit_cus, edit_lanes=args.edit_lanes, lanes=args.lanes,
                                 launch=args.lane_launch, timestep_group=args.group, overlap_prep=not args.no_overlap_prep,
-                                **({"lane_cus": args.lane_cus} if args.lane_cus else {}))
+                                share_edit_cus=args.edit_share, **({"lane_cus": args.lane_cus} if args.lane_cus else {}))
             dt, gathered = timed_pipeline(args.steps, args.warmup)
         except Exception as e:                                  # noqa: BLE001
             # a driver / container without CU-masked streams (hipExtStreamCreateWithCUMask, HSA_CU_MASK set, <= edit_cus CUs)
@@ -389,7 +397,7 @@ def main():
                          pipe.edit_lane_cus != pipe.edit_cus else f"{pipe.edit_lanes} edit loop(s) on {pipe.edit_cus} CUs")
             headline = (f"up to {pipe.clips_in_flight} clips in flight per GPU, each alone in its U-Net batches: forward inversion "
                         f"({args.group} timesteps per U-Net call) on {pipe.total - pipe.edit_cus} CUs beside {lanes_txt}"
-                        + ("; VAE decode + vocoder as a third stage on a queue of its own over the inversion partition's CUs"
+                        + ("; VAE decode + vocoder as a third stage on the inversion partition's queue, between its inversions"
                            if getattr(pipe, "codec_stage", False) else ""))
         elif args.lane_cus:
             headline = (f"{pipe.clips_in_flight} whole clips in flight per GPU, each on its own {args.lane_cus}-CU slice of the chip "
@@ -525,7 +533,7 @@ def main():
                           "clips_per_gpu_per_step": NC,
                           "clips_in_flight_per_gpu": NC if pipe_info is None else pipe_info["clips_in_flight"],
                           "parallelism": f"clip-dp{world}" + ("" if pipe_info is None else f" x {PLAN} pipeline"),
-                          "arith": ARITH_TEXT[args.arith],
+                          "arith": ARITH_TEXT[args.arith], "codec_arith": getattr(m, "codec_arith", "f32"),
                           "weights_broadcast_s": t_bcast if grouped else 0.0,
                           "process_group": (torch.distributed.get_backend() if grouped else None),
                           "gathered_latents": None if gathered is None else [list(g.shape) for g in gathered][:2]},

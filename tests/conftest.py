@@ -12,9 +12,14 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 def pytest_addoption(parser):
     parser.addoption("--arith", default="default", choices=["default", "f32", "bf16x6"],
                      help="arithmetic of the U-Net (and, when given explicitly, DiT) engines' LDS-staged GEMMs for the whole run: "
-                          "`default` = the product's (PipelineWrapper.arith = bf16x6, StableAudWrapper.arith = f32); `f32` = "
+                          "`default` = the product's (PipelineWrapper.arith = StableAudWrapper.arith = bf16x6); `f32` = "
                           "fp32 MFMAs everywhere; `bf16x6` = split-bf16 everywhere incl. the DiT.  Every parity tolerance of the "
                           "suite must hold unchanged in all three")
+
+
+    parser.addoption("--codec-arith", default="default", choices=["default", "f32", "bf16x6"],
+                     help="arithmetic of the codec engines (STFT, VAE, vocoder) -- the wrappers' `codec_arith` and every engine a "
+                          "test builds outside an arith_mode context (tape.DEFAULT_ARITH)")
 
 
 def pytest_configure(config):
@@ -25,6 +30,9 @@ def pytest_configure(config):
         models.PipelineWrapper.arith = models.StableAudWrapper.arith = a
         editing.EditEngine.arith = a                                    # engines the tests build directly
         stable_audio.StableAudioEditEngine.arith = a
+    if config.getoption("--codec-arith") != "default":
+        from audioeditingcode_amd import models, tape
+        models.PipelineWrapper.codec_arith = tape.DEFAULT_ARITH = config.getoption("--codec-arith")
 
 
 @pytest.fixture(scope="session")

@@ -87,8 +87,10 @@ class PipelineWrapper(torch.nn.Module):
     # fp32 operands, six bf16-MFMA piece products, fp32 accumulate (results as close to fp64 as the fp32-MFMA chain's);
     # "f32" = fp32-input MFMAs everywhere.  Set on the class or on an instance BEFORE the first editor() call of a shape.
     arith = "bf16x6"
-    # arithmetic of the codec engines (STFT-as-DFT, VAE, vocoder; `_cached`), independent of `arith`
-    codec_arith = "f32"
+    # arithmetic of the codec engines' LDS-staged GEMMs (STFT-as-DFT, VAE, vocoder; `_cached`), independent of `arith`.
+    # bf16x6 since round 4: VAE decode + two vocoder passes 75 -> 42 ms on the inversion partition's queue, every codec / e2e
+    # parity tolerance unchanged (profiles/r04_pipeline_variants.md)
+    codec_arith = "bf16x6"
 
     def __init__(self, model_id: str, device: torch.device, double_precision: bool = False,
                  token: Optional[str] = None, seed: int = 0, state_dicts: Optional[Dict] = None,
@@ -169,10 +171,11 @@ class PipelineWrapper(torch.nn.Module):
                              f"The CPU restatement lives in oracle/ and is test infrastructure only.")
 
     # ------------------------------------------------------------------ engine caches
-    def _cached(self, key, make):
-        # EXPERIMENTAL: `codec_arith = "bf16x6"` builds the codec engines (STFT-as-DFT, VAE, vocoder) under tape.arith_mode
-        # (split-bf16 GEMMs, csrc/conv_gemm_x6.hip); default "f32".  Independent of `arith` (the U-Net / DiT engines).
-        arith = self.codec_arith
+    def _cached(self, key, make, arith=None):
+        # codec engines (STFT-as-DFT, VAE, vocoder) are built under tape.arith_mode(self.codec_arith); the single-call U-Net /
+        # DiT engines of `unet_forward` (hook path, PC power iteration: finite differences of the U-Net) stay on fp32 MFMAs,
+        # the arithmetic their tolerances were observed with
+        arith = self.codec_arith if arith is None else arith
         key = key if arith == "f32" else key + (arith,)
         if key not in self._engines:
             with tape_mod.arith_mode(arith):
@@ -378,7 +381,8 @@ class PipelineWrapper(torch.nn.Module):
         cond, L0, L1 = self._cond_from_args(B, encoder_hidden_states, class_labels, encoder_attention_mask)
         eng = self._cached(("unet", B, H, W, L0, L1),
                            lambda: UNetEngine(self.family["unet"], self.unet_weights, self.device, B, H, W,
-                                              ctx_len0=L0, ctx_len1=L1, use_ehs=self.kind != "audioldm"))
+                                              ctx_len0=L0, ctx_len1=L1, use_ehs=self.kind != "audioldm"),
+                           arith="f32")
         pending = getattr(eng, "_pending_skips", None)
         pending = pending() if pending is not None else None
         if pending is not None:            # a previous call's result is still held by the caller: its views go stale now
@@ -535,6 +539,7 @@ class StableAudWrapper(PipelineWrapper):
     # latent 3.7e-6 from the CPU oracle at T=200 in both arithmetics, 10.2 s per clip against 13.6 s)
 
     family_name = "stable_audio"
+    codec_arith = "f32"         # Oobleck encoder / decoder: fp32 MFMAs (not measured under the split-bf16 kernel yet)
 
     def __init__(self, model_id: str, device: torch.device, double_precision: bool = False,
                  token: Optional[str] = None, seed: int = 0, state_dicts: Optional[Dict] = None,
@@ -783,7 +788,7 @@ class StableAudWrapper(PipelineWrapper):
         B = sample.shape[0]
         ctx = self.assemble_context(encoder_hidden_states, encoder_attention_mask)
         eng = self._cached(("dit", B, ctx.shape[1]), lambda: DiTEngine(self.family["dit"], self.dit_weights, self.device,
-                                                                        B, ctx.shape[1]))
+                                                                        B, ctx.shape[1]), arith="f32")
         eng.set_conditioning(ctx.expand(B, -1, -1), self.audio_duration_embeds.reshape(1, -1).expand(B, -1))
         eng.set_timestep(timestep)
         eng.x_in.copy_(sample.to(self.device, torch.float32).transpose(1, 2))

@@ -97,8 +97,7 @@ class ClipPipeline:
     event_type = torch.cuda.Event
 
     def __init__(self, model, plan="partition", edit_cus=None, edit_lanes=1, lanes=None, launch="graph",
-                 timestep_group=100, overlap_prep=True, lane_cus=None, separate_queues=None, codec_stage=None,
-                 share_edit_cus=False):
+                 timestep_group=100, overlap_prep=True, lane_cus=None, separate_queues=None, codec_stage=None):
         if getattr(model, "kind", None) == "stable_audio":
             raise NotImplementedError("ClipPipeline drives the mel-latent families (AudioLDM / AudioLDM2 / TANGO)")
         if plan not in ("partition", "lanes"):
@@ -140,10 +139,11 @@ class ClipPipeline:
             # Several edit lanes get DISJOINT slices of the edit partition when it splits into multiples of 32 CUs (a mask must
             # give every shader engine of every XCD the same number of CUs; 64 consecutive mask bits = 8 CUs on each XCD):
             # lane k runs on CUs [k * edit_cus / n, (k + 1) * edit_cus / n).  Otherwise the lanes SHARE the partition's CUs --
-            # measured in round 3 (128 CUs, 2 lanes): CU-time bound, 2 x 2.87 s per clip per lane = the one-lane rate.
+            # measured in round 3 (128 CUs, 2 lanes: 2 x 2.87 s per clip per lane = the one-lane rate) and again in round 4 with
+            # one dispatch pipe per lane attempted (queues with the SAME mask cannot be separated: 0.71-0.78 clips/s against
+            # 0.95 for disjoint slices, profiles/r04_pipeline_variants.md).
             n = self.edit_lanes
-            per = self.edit_cus // n if (n > 1 and self.edit_cus % n == 0 and (self.edit_cus // n) % 32 == 0
-                                         and not share_edit_cus) else None
+            per = self.edit_cus // n if (n > 1 and self.edit_cus % n == 0 and (self.edit_cus // n) % 32 == 0) else None
             self.edit_lane_cus = per or self.edit_cus
             lane_cus = (lambda k: range(k * per, (k + 1) * per)) if per else (lambda k: range(self.edit_cus))
             regime = None

@@ -220,9 +220,6 @@ def main():
                          "fp32 operand cut exactly into three bf16 pieces in the loader, six piece products on the bf16 MFMAs, "
                          "fp32 accumulation (csrc/conv_gemm_x6.hip; as close to fp64 as the fp32 chain); f32 = fp32-input MFMAs "
                          "everywhere (the round-1..3 arithmetic, kept for A/B)")
-    ap.add_argument("--edit-share", action="store_true",
-                    help="partition plan: the edit lanes SHARE the edit partition's CUs (each on its own dispatch pipe) instead of "
-                         "disjoint slices")
     ap.add_argument("--codec-arith", default=None, choices=["f32", "bf16x6"],
                     help="arithmetic of the codec engines' LDS-staged GEMMs (STFT-as-DFT, VAE, vocoder); default: the wrapper's "
                          "`codec_arith`")
@@ -382,7 +379,7 @@ def main():
         try:
             pipe = ClipPipeline(m, plan=PLAN, edit_cus=args.edit_cus, edit_lanes=args.edit_lanes, lanes=args.lanes,
                                 launch=args.lane_launch, timestep_group=args.group, overlap_prep=not args.no_overlap_prep,
-                                share_edit_cus=args.edit_share, **({"lane_cus": args.lane_cus} if args.lane_cus else {}))
+                                **({"lane_cus": args.lane_cus} if args.lane_cus else {}))
             dt, gathered = timed_pipeline(args.steps, args.warmup)
         except Exception as e:                                  # noqa: BLE001
             # a driver / container without CU-masked streams (hipExtStreamCreateWithCUMask, HSA_CU_MASK set, <= edit_cus CUs)

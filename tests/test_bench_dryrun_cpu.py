@@ -116,7 +116,7 @@ class _Pipe:
     made = []
 
     def __init__(self, model, plan="partition", edit_cus=None, edit_lanes=1, lanes=None, launch="graph", timestep_group=100,
-                 overlap_prep=True, share_edit_cus=False):
+                 overlap_prep=True):
         assert launch in ("eager", "graph") and plan in ("partition", "lanes")
         self.plan, self.total, self.edit_cus, self.edit_lanes = plan, 256, edit_cus, edit_lanes
         self.edit_lane_cus, self.codec_stage = edit_cus, False

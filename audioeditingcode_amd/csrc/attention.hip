@@ -12,13 +12,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-struct AttnParams {
-    const float* q; const float* k; const float* v; const float* bias; float* o;
-    int Nq, Nk, H;
-    int ldq, ldk, ldv, ldo, ld_bias;
-    long bsq, bsk, bsv, bso;
-    float scale;
-};
+#include "attn_params.h"
 
 #define KV_TILE 64
 #define Q_TILE 64
@@ -431,7 +425,8 @@ static int launch_t(const AttnParams& p, int B, hipStream_t s) {
 
 // slots: p0=q p1=k p2=v p3=bias(or null) p4=out
 //        i0=B i1=H i2=Nq i3=Nk i4=D i5=ldq i6=ldk i7=ldv i8=ldo i9=ld_bias
-//        i10=bsq i11=bsk i12=bsv i13=bso (elements) i14=variant (0 auto: transposed-score kernel when Nk > 64; 1 forces the single-pass kernel) ; f0=scale
+//        i10=bsq i11=bsk i12=bsv i13=bso (elements) i14=variant (0 auto: transposed-score kernel when Nk > 64; 1 forces the single-pass kernel;
+//        3 forces the split-bf16 kernel) ; f0=scale
 int launch_attention(const aed_op* op, hipStream_t s) {
     const int32_t* i = op->i;
     AttnParams p;
@@ -451,6 +446,13 @@ int launch_attention(const aed_op* op, hipStream_t s) {
         const long wg_ksplit1 = (long)aed_cdiv(p.Nq, 128) * p.H * i[0];
         const bool ks4 = wg_ksplit1 < 2L * aed_num_cus();
         int rc = 0;
+        // flag bit 2 (tapes built under tape.arith_mode("bf16x6")): the throughput-regime kernel on split-bf16 MFMAs
+        // (attention_x6.hip) for the head dims it takes; variant 3 forces it whatever the grid size (tests)
+        if (((op->flags & 4) && !ks4) || i[14] == 3) {
+            rc = launch_attention_x6(p, i[0], i[4], s);
+            if (rc >= 0) return rc;
+            AED_REQUIRE(i[14] != 3, "attention: the split-bf16 kernel does not take head dim %d / these operands", i[4]);
+        }
         switch (i[4]) {
             case 32: rc = ks4 ? launch_t<32, 4>(p, i[0], s) : launch_t<32, 1>(p, i[0], s); break;
             case 48: rc = ks4 ? launch_t<48, 4>(p, i[0], s) : launch_t<48, 1>(p, i[0], s); break;

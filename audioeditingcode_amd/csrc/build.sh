@@ -10,6 +10,7 @@ hipcc $FLAGS -c conv_gemm.hip -o obj/conv_gemm.o & pids+=($!)
 hipcc $FLAGS -c lin_gemm.hip -o obj/lin_gemm.o & pids+=($!)
 hipcc $FLAGS -c conv_gemm_x6.hip -o obj/conv_gemm_x6.o & pids+=($!)
 hipcc $FLAGS -c attention.hip -o obj/attention.o & pids+=($!)
+hipcc $FLAGS -c attention_x6.hip -o obj/attention_x6.o & pids+=($!)
 hipcc $FLAGS -c norm.hip -o obj/norm.o & pids+=($!)
 hipcc $FLAGS -ffp-contract=off -c elementwise.hip -o obj/elementwise.o & pids+=($!)
 hipcc $FLAGS -ffp-contract=off -c stable_audio.hip -o obj/stable_audio.o & pids+=($!)

@@ -24,6 +24,7 @@ CU_COUNT = 256          # MI355X; tiling heuristics target this, overridable for
 # configuration now, and the profiling tools (tools/unet_profile.py) set the module attributes directly for A/B runs.
 FORCE_BK = 0            # K-chunk width of conv_gemm: 0 auto, 1 force 32, 2 allow 64 on the 128x128 tile too
 ATTN_VARIANT = 0        # 0 auto (transposed-score kernel when Nk > 64), 1 forces the single-pass kernel
+ATTN_X6 = 1             # 0: attention records stay on the fp32 kernels under arith_mode("bf16x6") as well (A/B)
 GN_VARIANT = 0          # 1: never use the register-resident single-launch GroupNorm
 GN_FORCE_SMALL = 0      # 1: always take the single-launch GroupNorm when it fits
 LIN_MODE = 1            # 1: small contractions go to the latency-regime kernels of lin_gemm.hip
@@ -347,11 +348,14 @@ class Tape:
     # ------------------------------------------------------------------ attention & friends
     def attention(self, q, k, v, out, *, B, H, Nq, Nk, D, ldq, ldk, ldv, ldo, bsq, bsk, bsv, bso, scale,
                   bias=None, ld_bias=0, variant=None, name="attn"):
-        """variant: 0 auto (transposed-score kernel when Nk > 64), 1 single-pass kernel."""
+        """variant: 0 auto (transposed-score kernel when Nk > 64), 1 single-pass kernel, 3 split-bf16 kernel (tests)."""
         variant = ATTN_VARIANT if variant is None else variant
+        # under arith_mode("bf16x6") the record carries flag bit 2: the launcher then takes the split-bf16 kernel
+        # (attention_x6.hip) in the throughput regime for the head dims it has (32 / 48 / 64), the fp32 kernels otherwise
+        arith = ARITH_FLAGS[getattr(_regime, "arith", None) or DEFAULT_ARITH] if ATTN_X6 else 0
         self._add(L.OP_ATTENTION, [B, H, Nq, Nk, D, ldq, ldk, ldv, ldo, ld_bias, bsq, bsk, bsv, bso, variant], [scale],
                   [q, k, v, bias, out], name=name, flops=4 * B * H * Nq * Nk * D,
-                  nbytes=4 * B * H * D * (2 * Nq + 2 * Nk))
+                  nbytes=4 * B * H * D * (2 * Nq + 2 * Nk), flags=arith & 4)
         return out
 
     def xattn_fold(self, kv, xq, xs, xo, G, gs, VOt, *, B, Lk, H, C, D, name="xattn_fold"):

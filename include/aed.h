@@ -50,7 +50,10 @@ enum aed_opcode {
     AED_OP_GN_STATS = 2,      /* GroupNorm partial sums (K4)                                   */
     AED_OP_GN_APPLY = 3,      /* GroupNorm normalise + affine (+SiLU) (K4)                     */
     AED_OP_LAYERNORM = 4,     /* RETIRED in v4 (returns an error): LayerNorm is fused into the consuming GEMM (K8)  */
-    AED_OP_ATTENTION = 5,     /* softmax(QK^T*scale + bias)V, flash-style, fp32 MFMA (K7)      */
+    AED_OP_ATTENTION = 5,     /* softmax(QK^T*scale + bias)V, flash-style, fp32 MFMA (K7).  flags bit 2 (tapes built under
+                                 tape.arith_mode("bf16x6")): in the throughput regime (every wave its own query tile) both
+                                 contractions run on split-bf16 MFMAs (csrc/attention_x6.hip: K, V, Q and the probabilities cut
+                                 exactly into three bf16 pieces, six piece products, fp32 accumulate and fp32 softmax)       */
     AED_OP_GEGLU = 6,         /* RETIRED in v4 (returns an error): the gate rides in the FF1 epilogue (K8)         */
     AED_OP_COPY2D = 7,        /* strided 2-D copy (skip concat, h-space tap/replace) (K10)     */
     AED_OP_TIME_EMBED = 8,    /* sinusoidal timestep embedding (K9)                            */

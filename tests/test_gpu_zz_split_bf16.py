@@ -113,3 +113,84 @@ def test_c_abi_harness_feature_matrix():
     bad = [row for row in rows if not row["pass"]]
     assert r.returncode == 0 and not bad, (bad[:3], r.stderr[-400:])
     assert max(row["rel_l2_vs_fp32_kernel"] for row in rows) < 5e-6
+
+
+def _attention_pair(B, H, Nq, Nk, D, masked, qkv_packed, seed):
+    """One attention record through the fp32 transposed-score kernel and the split-bf16 kernel (variant 3) over the same
+    device operands; fp64 reference on the CPU.  qkv_packed: q / k / v are column slices of one [B*N, 3C] buffer (the
+    U-Net's fused projection), otherwise separate [B, N, C] tensors with Nq != Nk allowed."""
+    C = H * D
+    g = torch.Generator().manual_seed(seed)
+    if qkv_packed:
+        assert Nq == Nk
+        qkv = torch.randn(B, Nq, 3 * C, generator=g) * torch.exp(0.5 * torch.randn(3 * C, generator=g))
+        q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    else:
+        q, k, v = (torch.randn(B, n, C, generator=g) for n in (Nq, Nk, Nk))
+    bias = None
+    if masked:
+        m = (torch.randn(B, Nk, generator=g) > -0.3).float()
+        m[:, 0] = 1
+        bias = (1 - m) * -10000.0
+    qh, kh, vh = (t.reshape(B, -1, H, D).transpose(1, 2).double() for t in (q, k, v))
+    s = qh @ kh.transpose(-1, -2) * D ** -0.5
+    if bias is not None:
+        s = s + bias[:, None, None, :].double()
+    ref = (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B, Nq, C)
+    outs = {}
+    for variant in (0, 3):
+        tp = Tape(DEV)
+        out = tp.alloc(B, Nq, C)
+        if qkv_packed:
+            d = tp.hold(qkv.to(DEV))
+            qd, kd, vd, ld, bs = d, d[..., C:], d[..., 2 * C:], 3 * C, Nq * 3 * C
+            tp.attention(qd, kd, vd, out, B=B, H=H, Nq=Nq, Nk=Nk, D=D, ldq=ld, ldk=ld, ldv=ld, ldo=C, bsq=bs, bsk=bs, bsv=bs,
+                         bso=Nq * C, scale=D ** -0.5, bias=None if bias is None else bias.to(DEV), ld_bias=Nk, variant=variant)
+        else:
+            tp.attention(q.contiguous().to(DEV), k.contiguous().to(DEV), v.contiguous().to(DEV), out, B=B, H=H, Nq=Nq, Nk=Nk,
+                         D=D, ldq=C, ldk=C, ldv=C, ldo=C, bsq=Nq * C, bsk=Nk * C, bsv=Nk * C, bso=Nq * C, scale=D ** -0.5,
+                         bias=None if bias is None else bias.to(DEV), ld_bias=Nk, variant=variant)
+        tp.run()
+        torch.cuda.synchronize()
+        outs[variant] = out.cpu()
+    return outs, ref
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk,D,masked,packed", [
+    (6, 8, 1024, 1024, 32, False, True),        # the inversion's level-1 self-attention (fused qkv buffer)
+    (10, 8, 256, 256, 48, False, True),         # level 2 (d_head 48: zero-padded second O^T row tile)
+    (3, 4, 200, 1000, 64, True, False),         # ragged queries and keys, key mask, d_head 64 (the DiT's)
+    (2, 2, 130, 33, 32, True, False),           # two key tiles, the second almost empty (odd tile count: one dead tile)
+    (1, 1, 32, 65, 32, False, False),           # three key tiles
+])
+def test_split_bf16_attention_is_as_close_to_fp64_as_the_fp32_kernel(B, H, Nq, Nk, D, masked, packed):
+    """csrc/attention_x6.hip (forced with variant 3) against the fp32 transposed-score kernel and an fp64 reference."""
+    outs, ref = _attention_pair(B, H, Nq, Nk, D, masked, packed, seed=Nq + D)
+    rel = lambda a: float((a.double() - ref).norm() / ref.norm())                           # noqa: E731
+    e32, e6 = rel(outs[0]), rel(outs[3])
+    print(f"\n[attention x6] B={B} H={H} Nq={Nq} Nk={Nk} D={D}: rel L2 vs fp64: fp32 kernel {e32:.2e}, split-bf16 {e6:.2e}; "
+          f"max abs {float((outs[3].double() - ref).abs().max()):.2e}")
+    assert torch.isfinite(outs[3]).all()
+    assert (outs[3].double() - ref).abs().max() < 2e-5
+    assert e6 < 2e-6 and e6 < 3 * e32 + 2e-7
+
+
+def test_arith_mode_flags_attention_records_and_the_launcher_takes_the_split_kernel_only_in_the_throughput_regime():
+    """Under tape.arith_mode("bf16x6") attention records carry flag bit 2; with few workgroups (the edit loop's batch 2) the
+    launcher keeps the key-split fp32 kernel, so the result is bit-identical to the unflagged record's."""
+    B, H, N, D = 2, 8, 256, 32
+    C = H * D
+    g = torch.Generator().manual_seed(5)
+    q, k, v = (torch.randn(B, N, C, generator=g).to(DEV) for _ in range(3))
+    outs = []
+    for arith in ("f32", "bf16x6"):
+        tp = Tape(DEV)
+        out = tp.alloc(B, N, C)
+        with tape_mod.arith_mode(arith):
+            tp.attention(q, k, v, out, B=B, H=H, Nq=N, Nk=N, D=D, ldq=C, ldk=C, ldv=C, ldo=C, bsq=N * C, bsk=N * C, bsv=N * C,
+                         bso=N * C, scale=D ** -0.5)
+        assert bool(tp.ops[0].flags & 4) == (arith == "bf16x6")
+        tp.run()
+        torch.cuda.synchronize()
+        outs.append(out.cpu())
+    assert torch.equal(outs[0], outs[1])

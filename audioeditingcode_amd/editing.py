@@ -124,8 +124,12 @@ class LoopPlumbing:
                     if plan is not None:
                         plan["graph"] = g
                 ev0.record(stream)
-                for _ in range(steps):
-                    Tape.graph_replay(g)
+                chooser = getattr(self, "lane_chooser", None)
+                if chooser is None:
+                    for _ in range(steps):
+                        Tape.graph_replay(g)
+                else:
+                    stream = self._replay_in_chunks(g, steps, stream, chooser)
                 ev1.record(stream)
                 self._last_events = (ev0, ev1)
                 if plan is None:
@@ -138,6 +142,34 @@ class LoopPlumbing:
                 ev1.record(stream)
                 self._last_events = (ev0, ev1)
         cur.wait_stream(stream)
+
+    LANE_CHUNK = 5          # step-graph replays per lane decision (see _replay_in_chunks)
+
+    def _replay_in_chunks(self, g, steps, stream, chooser):
+        """`steps` replays of the step graph in chunks of LANE_CHUNK, asking `chooser()` before each chunk which stream the
+        chunk goes to (None = stay on `stream`): a clip pipeline widens an edit lane's CU mask once the other stage has
+        drained (pipeline.ClipPipeline._back).  The host stays at most two chunks ahead of the device, so the decision is
+        taken ~10 steps before the chunk runs instead of 100; a stream change is ordered by an event.  Same graph, same
+        kernels, same values on any stream.  Returns the stream the last chunk was issued on."""
+        pending, cur_s, done = [], stream, 0
+        while done < steps:
+            if len(pending) >= 2:
+                pending.pop(0).synchronize()
+            s = chooser() or stream
+            if s is not cur_s:
+                hand = torch.cuda.Event()
+                hand.record(cur_s)
+                s.wait_event(hand)
+                cur_s = s
+            n = min(self.LANE_CHUNK, steps - done)
+            with torch.cuda.stream(cur_s):
+                for _ in range(n):
+                    Tape.graph_replay(g)
+            ev = torch.cuda.Event()
+            ev.record(cur_s)
+            pending.append(ev)
+            done += n
+        return cur_s
 
     def last_loop_ms(self):
         ev0, ev1 = self._last_events

@@ -87,6 +87,7 @@ class _Worker:
         self.stage, self.k, self.view, self.lane, self.full = stage, k, view, lane, full
         self.regime = regime        # tile regime its engines are built under (tape.tile_regime)
         self.prep = prep            # side stream for the part of a front half that does not touch the loop engine
+        self.wide = None            # edit lanes: this lane's CUs + a slice of the inversion partition (drain, see _back)
         self.last = None            # (event, stream) of this worker's previous job
         self.warm = False
 
@@ -97,7 +98,8 @@ class ClipPipeline:
     event_type = torch.cuda.Event
 
     def __init__(self, model, plan="partition", edit_cus=None, edit_lanes=1, lanes=None, launch="graph",
-                 timestep_group=100, overlap_prep=True, lane_cus=None, separate_queues=None, codec_stage=None):
+                 timestep_group=100, overlap_prep=True, lane_cus=None, separate_queues=None, codec_stage=None,
+                 widen_on_drain=True):
         if getattr(model, "kind", None) == "stable_audio":
             raise NotImplementedError("ClipPipeline drives the mel-latent families (AudioLDM / AudioLDM2 / TANGO)")
         if plan not in ("partition", "lanes"):
@@ -174,6 +176,24 @@ class ClipPipeline:
                 kept = _separate(busy, log=self.queue_log)
                 for w, ps in zip(back, kept[1:1 + n]):
                     w.lane = ps
+            # Drain: when the front stage has finished its last inversion, its CUs idle while the last edit loops run on
+            # their 64-CU lanes for another ~1.6 s.  Each edit lane gets a second queue over its own CUs PLUS its share of
+            # the inversion partition; the edit loop is issued in chunks of a few steps and moves there once the front
+            # stage is done (editing.LoopPlumbing._replay_in_chunks).  Same engines, same graphs, same values.
+            inv = self.total - self.edit_cus
+            if widen_on_drain and per and n > 1 and inv % n == 0 and (inv // n) % 32 == 0:
+                wper = inv // n
+                for k, w in enumerate(back):
+                    w.wide = Lane(dev, cus=list(lane_cus(k)) + list(range(self.edit_cus + k * wper,
+                                                                         self.edit_cus + (k + 1) * wper)),
+                                  total=self.total, index=50 + k)
+                if separate_queues and hasattr(self.lane_type, "respin") and dev.type == "cuda":
+                    # busy together in the drain: the inversion queue (codec jobs) and the widened lanes
+                    from .streams import separate_queues as _separate
+                    self.drain_queue_log = []
+                    kept = _separate([front[0].lane] + [w.wide for w in back], log=self.drain_queue_log)
+                    for w, ps in zip(back, kept[1:]):
+                        w.wide = ps
         else:
             n = DEFAULT_LANES if lanes is None else int(lanes)
             if n < 1:
@@ -209,6 +229,7 @@ class ClipPipeline:
                     w.lane = ps
         self._build_lock = threading.Lock()     # an un-warmed worker builds engines (and lazily folds shared weights)
         self.stats = []
+        self.widened = set()                    # edit lanes that moved to their widened queue during the last edit_clips
 
     def _view(self):
         v = self.model.lane_view()
@@ -332,9 +353,21 @@ class ClipPipeline:
             if t.is_cuda:
                 t.record_stream(st)
         tstart = a["tstart"]
-        w_edit, _ = inversion_reverse_process(v, xT=f["wts"], tstart=torch.tensor([tstart], dtype=torch.int),
-                                              etas=a["eta"], prompts=a["tgt"], neg_prompts=a["neg"],
-                                              cfg_scales=a["cfg_tar"], zs=f["zs"][:tstart])
+        if w.wide is not None and st is w.lane.stream:
+            def chooser():          # the widened lane once the front stage has issued AND finished its last inversion
+                with job["lock"]:
+                    ev = job["front_event"]
+                    drained = job["stage_done"][0] and (ev is None or ev.query())
+                if drained:
+                    self.widened.add(w.k)
+                return w.wide.stream if drained else None
+            v._lane_chooser = chooser
+        try:
+            w_edit, _ = inversion_reverse_process(v, xT=f["wts"], tstart=torch.tensor([tstart], dtype=torch.int),
+                                                  etas=a["eta"], prompts=a["tgt"], neg_prompts=a["neg"],
+                                                  cfg_scales=a["cfg_tar"], zs=f["zs"][:tstart])
+        finally:
+            v._lane_chooser = None
         if not with_codec:
             edited = self.event_type()
             edited.record(st)
@@ -495,6 +528,7 @@ class ClipPipeline:
         job = self._job(items, seeds, prepare, self._args(source_prompt, target_prompt, target_neg_prompt, cfg_src,
                                                           cfg_tar, T, tstart, eta))
         self.stats, self._times = [], job["times"]
+        self.widened = set()
         if not job["items"]:
             return []
         self._base = None
@@ -557,6 +591,8 @@ class ClipPipeline:
                     inversion_cus=None if self.edit_cus is None else self.total - self.edit_cus,
                     device_ms={k: dict(n=len(v), avg=sum(v) / len(v)) for k, v in acc.items()},
                     queue_separation=getattr(self, "queue_log", None), timeline=timeline,
+                    widened_on_drain=sorted(getattr(self, "widened", ())),
+                    drain_queue_separation=getattr(self, "drain_queue_log", None),
                     clip_latency_ms_avg=(sum(lats) / len(lats)) if lats else None,
                     clip_latency_ms_max=max(lats) if lats else None)
 

@@ -66,6 +66,33 @@ def test_partition_pipeline_is_bit_identical_to_one_clip_at_a_time_tiny(edit_lan
     pipe.close()
 
 
+def test_edit_lanes_widen_on_drain_and_stay_bit_identical_tiny(monkeypatch):
+    """Two edit lanes on disjoint 64-CU slices beside a 128-CU inversion partition: once the front stage has finished its
+    last inversion, the remaining edit loops continue on their widened queues (own CUs + a slice of the inversion partition;
+    editing.LoopPlumbing._replay_in_chunks).  Same engines and graphs on another stream: results stay bit-identical."""
+    from audioeditingcode_amd.editing import EditEngine
+    monkeypatch.setattr(EditEngine, "LANE_CHUNK", 1)             # a lane decision per step (6 edit steps per clip here)
+    T, tstart, G = 10, 6, 5
+    m = models.load_model("tiny/audioldm2", DEV, T, seed=0)
+    wavs = [synthetic_clip(seconds=1.25, seed=7 + i) for i in range(5)]
+    to_mel = lambda view, wav: load_audio((wav, 16000), view.get_fn_STFT(), device=DEV, stft=True)[0]     # noqa: E731
+    mels = [to_mel(m, w) for w in wavs]
+    seeds = [40 + i for i in range(5)]
+    ref = _serial_b(m, mels, T, tstart, seeds, G)
+    pipe = ClipPipeline(m, plan="partition", edit_cus=128, edit_lanes=2, timestep_group=G)
+    back = [w for w in pipe.workers if w.stage == "back"]
+    assert all(w.wide is not None and len(w.wide.cus) == 128 and set(w.lane.cus) < set(w.wide.cus) for w in back)
+    assert not set(back[0].wide.cus) & set(back[1].wide.cus)
+    pipe.warm_up(wavs[0], *ARGS, T, tstart, prepare=to_mel)
+    got = pipe.edit_clips(wavs, *ARGS, T, tstart, seeds=seeds, prepare=to_mel)
+    for i, ((a, o, w), (a2, o2, w2)) in enumerate(zip(got, ref)):
+        assert torch.equal(w, w2), (i, float((w - w2).abs().max()))
+        assert torch.equal(a, a2) and torch.equal(o, o2), i
+    rep = pipe.report()
+    assert rep["widened_on_drain"], rep["widened_on_drain"]      # the last clip's loop moved to its widened queue
+    pipe.close()
+
+
 def test_lanes_plan_is_bit_identical_to_one_clip_at_a_time_tiny():
     """Whole clips in the reference's step order on 3 streams == one at a time, with per-clip seeds and with one
     continuous global generator stream (the lanes draw in clip order)."""

@@ -64,6 +64,7 @@ for _reg, _mod in ((None, "tile_table_x6"), ("cus128", "tile_table_x6_cus128"), 
         X6_TABLES[_reg] = dict(__import__(f"{__package__}.{_mod}", fromlist=["TILE_TABLE"]).TILE_TABLE)
     except ImportError:
         pass
+REGIME_CUS = {"cus128": 128, "cus64": 64}       # CUs of the stream a regime's engines run on
 _regime = threading.local()
 
 
@@ -353,6 +354,13 @@ class Tape:
         # under arith_mode("bf16x6") the record carries flag bit 2: the launcher then takes the split-bf16 kernel
         # (attention_x6.hip) in the throughput regime for the head dims it has (32 / 48 / 64), the fp32 kernels otherwise
         arith = ARITH_FLAGS[getattr(_regime, "arith", None) or DEFAULT_ARITH] if ATTN_X6 else 0
+        # The launcher's own rule (every wave its own query tile only when that gives >= 2 workgroups per CU of the WHOLE chip)
+        # keeps the edit loop's batch-2 calls on the key-split fp32 kernel.  On a CU-masked lane the split-bf16 kernel wins as
+        # soon as there is a workgroup per CU of the LANE (measured, profiles/r04_attn_x6_ab.jsonl: 1024 tokens at batch 2 on a
+        # 64-CU stream 86 -> 51 us, on 128 CUs 48 -> 34 us, on the whole chip 30 -> 35 us; 256 tokens: fp32 wins everywhere)
+        if arith & 4 and variant == 0 and D in (32, 48, 64) and Nk > 64 and \
+                math.ceil(Nq / 128) * H * B >= REGIME_CUS.get(getattr(_regime, "name", None), CU_COUNT):
+            variant = 3
         self._add(L.OP_ATTENTION, [B, H, Nq, Nk, D, ldq, ldk, ldv, ldo, ld_bias, bsq, bsk, bsv, bso, variant], [scale],
                   [q, k, v, bias, out], name=name, flops=4 * B * H * Nq * Nk * D,
                   nbytes=4 * B * H * D * (2 * Nq + 2 * Nk), flags=arith & 4)

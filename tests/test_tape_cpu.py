@@ -420,3 +420,27 @@ def test_swept_x6_table_decides_kernel_and_tile_per_shape(monkeypatch):
     with tape_mod.arith_mode("bf16x6"):
         assert build() == [(12, 3), (0, 2)]
         assert build(forced=1) == [(12, 1), (12, 1)]
+
+
+def test_attention_records_under_bf16x6_flag_and_lane_rule():
+    """tape.attention under arith_mode("bf16x6"): the record carries flag bit 2 (the launcher then takes attention_x6.hip in the
+    throughput regime); on a CU-masked lane's regime the tape forces that kernel (variant 3) as soon as the call has one
+    workgroup per CU of the lane; short sequences, head dims the kernel does not have and fp32 engines keep variant 0."""
+    from audioeditingcode_amd import tape as tape_mod
+    from audioeditingcode_amd.tape import Tape
+
+    def rec(B, N, D, regime, arith, H=8):
+        tp = Tape("cpu")
+        C = H * D
+        q, o = tp.alloc(B, N, C), tp.alloc(B, N, C)
+        with tape_mod.tile_regime(regime), tape_mod.arith_mode(arith):
+            tp.attention(q, q, q, o, B=B, H=H, Nq=N, Nk=N, D=D, ldq=C, ldk=C, ldv=C, ldo=C, bsq=N * C, bsk=N * C, bsv=N * C,
+                         bso=N * C, scale=D ** -0.5)
+        return tp.ops[0].flags & 4, tp.ops[0].i[14]
+    assert rec(2, 1024, 32, "cus64", "bf16x6") == (4, 3)          # the edit lanes' level-1 self-attention
+    assert rec(2, 1024, 32, "cus128", "bf16x6") == (4, 3)
+    assert rec(2, 1024, 32, None, "bf16x6") == (4, 0)             # whole chip at batch 2: the key-split fp32 kernel is faster
+    assert rec(2, 256, 48, "cus64", "bf16x6") == (4, 0)           # 32 workgroups: fp32 kernel
+    assert rec(200, 1024, 32, "cus128", "bf16x6") == (4, 3)       # the inversion's batch
+    assert rec(2, 1024, 32, "cus64", "f32") == (0, 0)
+    assert rec(8, 64, 80, "cus64", "bf16x6") == (4, 0)            # <= 64 keys: single-pass kernel; d_head 80 not in the split kernel

@@ -45,7 +45,10 @@ static int launch_retired(const aed_op* op, hipStream_t) {
 }
 // CONV_GEMM, flag bit 2: contraction on split-bf16 MFMAs (conv_gemm_x6.hip; experimental, see include/aed.h)
 int launch_conv_gemm_x6(const aed_op* op, hipStream_t s);
+// flag bit 6: EXPERIMENT -- contraction on the MX-FP8 matrix cores (conv_gemm_f8.hip; not a parity path, see include/aed.h)
+int launch_conv_gemm_f8(const aed_op* op, hipStream_t s);
 static int launch_conv_gemm_any(const aed_op* op, hipStream_t s) {
+    if (op->flags & 64) return launch_conv_gemm_f8(op, s);
     return (op->flags & 4) ? launch_conv_gemm_x6(op, s) : launch_conv_gemm(op, s);
 }
 static launcher_t g_table[AED_OP_COUNT] = {

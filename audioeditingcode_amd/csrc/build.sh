@@ -9,6 +9,7 @@ pids=()
 hipcc $FLAGS -c conv_gemm.hip -o obj/conv_gemm.o & pids+=($!)
 hipcc $FLAGS -c lin_gemm.hip -o obj/lin_gemm.o & pids+=($!)
 hipcc $FLAGS -c conv_gemm_x6.hip -o obj/conv_gemm_x6.o & pids+=($!)
+hipcc $FLAGS -c conv_gemm_f8.hip -o obj/conv_gemm_f8.o & pids+=($!)
 hipcc $FLAGS -c attention.hip -o obj/attention.o & pids+=($!)
 hipcc $FLAGS -c attention_x6.hip -o obj/attention_x6.o & pids+=($!)
 hipcc $FLAGS -c norm.hip -o obj/norm.o & pids+=($!)

@@ -87,7 +87,10 @@ def tile_regime(name):
 #   relative size >= 2^-16 are accumulated in fp32 (conv_gemm_x6.hip): as close to fp64 as the fp32 chain
 #   (tools/bf16_split_study.py, profiles/r03_x6_gemm.md), 1.5-1.8x faster at the inversion's batch-200 shapes.  Ops the
 #   split kernel does not take (latency-regime tiles >= 10, skinny tiles 5 / 6, scalar-gather shapes) stay fp32.
-ARITH_FLAGS = {"f32": 0, "bf16x6": 4 | 8}
+# "fp8" (EXPERIMENT, BASELINE config 5's "fp8 MFMA path"; never a parity path): the flagged GEMMs quantise both operands to OCP
+#   MX-FP8 (e4m3 elements, one e8m0 scale per 32 k of a row) in the loader and run v_mfma_scale_f32_32x32x64_f8f6f4
+#   (conv_gemm_f8.hip); ops that kernel does not take (channel counts not a multiple of 64, ...) and attention run split-bf16.
+ARITH_FLAGS = {"f32": 0, "bf16x6": 4 | 8, "fp8": 64 | 4 | 8}
 DEFAULT_ARITH = "f32"   # arithmetic of engines built OUTSIDE any arith_mode context (tests/conftest.py --codec-arith sets it)
 
 

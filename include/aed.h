@@ -46,7 +46,11 @@ enum aed_opcode {
                                  (csrc/conv_gemm_x6.hip; as close to fp64 as the fp32 chain: tools/bf16_split_study.py,
                                  profiles/r03_x6_gemm.md; shapes that kernel does not take run the fp32 path);
                                  bit 3: with bit 2, interleave hints in the main loop (tapes set it; off = A/B);
-                                 bit 4: with bit 2, three-term DIAGNOSTIC arithmetic (~4e-6 rel error)            */
+                                 bit 4: with bit 2, three-term DIAGNOSTIC arithmetic (~4e-6 rel error);
+                                 bit 6 (EXPERIMENT, tapes built under tape.arith_mode("fp8")): contract on the MX-FP8 matrix
+                                 cores (csrc/conv_gemm_f8.hip: OCP microscaling e4m3, one e8m0 scale per 32 k of a row,
+                                 quantised in the loader, v_mfma_scale_f32_32x32x64_f8f6f4, fp32 accumulate).  NOT a parity
+                                 path (a few 1e-2 relative per GEMM); ops that kernel does not take run bits 2|3         */
     AED_OP_GN_STATS = 2,      /* GroupNorm partial sums (K4)                                   */
     AED_OP_GN_APPLY = 3,      /* GroupNorm normalise + affine (+SiLU) (K4)                     */
     AED_OP_LAYERNORM = 4,     /* RETIRED in v4 (returns an error): LayerNorm is fused into the consuming GEMM (K8)  */

@@ -19,8 +19,10 @@ ap.add_argument("--tstart", type=int, default=100)
 ap.add_argument("--group", type=int, default=20)
 ap.add_argument("--schedule", default="batched", choices=["batched", "sequential"])
 ap.add_argument("--model_id", default="stabilityai/stable-audio-open-1.0")
-ap.add_argument("--arith", default="bf16x6", choices=["f32", "bf16x6"],
-                help="arithmetic of the DiT engines' LDS-staged GEMMs (tape.arith_mode; csrc/conv_gemm_x6.hip): bf16x6 = the product")
+ap.add_argument("--arith", default="bf16x6", choices=["f32", "bf16x6", "fp8"],
+                help="arithmetic of the DiT engines' LDS-staged GEMMs (tape.arith_mode): bf16x6 = the product (csrc/conv_gemm_x6.hip); "
+                     "fp8 = EXPERIMENT, MX-FP8 matrix cores (csrc/conv_gemm_f8.hip): `parity_T200` then reads as the experiment's "
+                     "deviation from the fp32 CPU oracle, not as a parity claim")
 args = ap.parse_args()
 
 from audioeditingcode_amd import models                     # noqa: E402
@@ -126,12 +128,17 @@ print(json.dumps(dict(
     parity_T200=par,
     metric="edited-clips/sec (config 5: Stable Audio Open 1.0, 200-step inv+edit, 47.55 s@44.1 kHz stereo)",
     value=args.steps / dt, unit="clips/s", n_gpus=1, steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * dt / args.steps,
-    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+    higher_is_better=True, scaling="weak", vs_baseline=None, dtype=("fp8 (MX e4m3 x e4m3, fp32 accumulate; EXPERIMENT)" if args.arith == "fp8" else "f32"), data="synthetic",
     config=dict(workload="BASELINE configs[4]: Stable Audio Open 1.0 DiT (24 layers, 1536 wide, 1025 tokens, 130-token "
-                         "context) + Oobleck VAE, one clip; fp32 operands and results (fp8 path not built)",
-                arith=("fp32-input MFMAs" if args.arith == "f32" else
-                       "bf16x6: exact 3-way bf16 split of the fp32 operands, 6 bf16 MFMA piece products, fp32 accumulate "
-                       "(the DiT's LDS-staged GEMMs)"), T=args.T, tstart=args.tstart,
+                         "context) + Oobleck VAE, one clip; fp32 operands and results in HBM",
+                arith={"f32": "fp32-input MFMAs",
+                       "bf16x6": "bf16x6: exact 3-way bf16 split of the fp32 operands, 6 bf16 MFMA piece products, fp32 accumulate "
+                                 "(the DiT's LDS-staged GEMMs)",
+                       "fp8": "EXPERIMENT fp8: the DiT's LDS-staged GEMMs on the MX-FP8 matrix cores (OCP e4m3 elements, one e8m0 "
+                              "scale per 32 k, quantised in the loader, v_mfma_scale_f32_32x32x64_f8f6f4, fp32 accumulate); "
+                              "attention, norms, solver on fp32-exact arithmetic.  NOT a parity path: parity_T200 = its measured "
+                              "deviation from the fp32 CPU oracle"}[args.arith],
+                T=args.T, tstart=args.tstart,
                 schedule=args.schedule, timesteps_per_dit_call=args.group),
     phases_s_one_clip={k: round(v, 4) for k, v in phases.items()},
     roofline=dict(bound="mfma", unit="TFLOP/s", peak=157.3, kernel="whole DiT forward (tape-counted algorithmic FLOPs)",

@@ -8,8 +8,10 @@
 //
 // Format: OCP MX (microscaling) FP8.  Along K every run of 32 elements of a row shares one power-of-two scale (e8m0 byte):
 //   scale = 2^(floor(log2(amax)) - 8),  element = RNE_e4m3(clamp(x / scale, +-448))          (8 = emax of e4m3, 448 = its max)
-// v_mfma_scale_f32_32x32x64_f8f6f4 consumes exactly that: lane (row, half) holds 32 consecutive k of its row (32 bytes) and the
-// scale byte of that block; products are exact in fp32, the block scales are applied in hardware, accumulation is fp32.
+// v_mfma_scale_f32_32x32x64_f8f6f4 consumes exactly that; products are exact in fp32, the block scales are applied in hardware,
+// accumulation is fp32.  Operand layout (no ISA manual in the image: MEASURED with tools/f8_probe.cpp, profiles/r04_f8_probe.jsonl):
+// lane (row, half h) holds k = 16 h .. 16 h + 15 in VGPRs 0-3 and k = 32 + 16 h .. 32 + 16 h + 15 in VGPRs 4-7 -- each 32-k block
+// is spread over BOTH lane halves -- and supplies the scale byte (selected by op_sel) of block h of its row.
 //
 // Data path: operands stay fp32 in HBM (same record, same buffers as the other arithmetics -- no second weight copy).  The
 // loader threads quantise while writing the LDS stage: a row's 64-k chunk is fetched by 16 threads (float4 each), the block
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(64 * WROWS * WCOLS, 2) void conv_gemm_f8_kernel(CGP
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     const int fi = lane & 31;        // fragment row (A: m, W: n)
-    const int fh = lane >> 5;        // which 32 of the 64 k
+    const int fh = lane >> 5;        // which 16 of each 32-k block (operand layout above); also: whose block scale this lane supplies
     const int a_row = wr * WM + fi;
     const int b_row = BM + wc * WN + fi;
 
@@ -227,13 +229,13 @@ __global__ __launch_bounds__(64 * WROWS * WCOLS, 2) void conv_gemm_f8_kernel(CGP
         int sa[TM], sw[TN];
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
-            const uint4 lo = st[(a_row + a * 32) * F8_ROWQ + 2 * fh], hi = st[(a_row + a * 32) * F8_ROWQ + 2 * fh + 1];
+            const uint4 lo = st[(a_row + a * 32) * F8_ROWQ + fh], hi = st[(a_row + a * 32) * F8_ROWQ + 2 + fh];
             af[a] = (f8x32){(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
             sa[a] = (int)sc[(a_row + a * 32) * 2 + fh];
         }
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
-            const uint4 lo = st[(b_row + b * 32) * F8_ROWQ + 2 * fh], hi = st[(b_row + b * 32) * F8_ROWQ + 2 * fh + 1];
+            const uint4 lo = st[(b_row + b * 32) * F8_ROWQ + fh], hi = st[(b_row + b * 32) * F8_ROWQ + 2 + fh];
             bw[b] = (f8x32){(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
             sw[b] = (int)sc[(b_row + b * 32) * 2 + fh];
         }

@@ -2,8 +2,15 @@
 
 Not a parity path -- an MX-FP8 GEMM deviates from fp32 by a few percent (tools/fp8_tolerance_study.py).  What
 is tested: (1) the kernel computes EXACTLY the MX-FP8 contraction it claims to (against oracle/mxfp8.py, a CPU emulation of the same
-quantisation: agreement to fp32 accumulation order); (2) the Stable Audio DiT built in that arithmetic stays within the
-experiment's acceptance bound of the fp32-exact engine and of the oracle, and says so with numbers."""
+quantisation); (2) the Stable Audio DiT built in that arithmetic stays within the experiment's acceptance bound of the fp32-exact
+engine, and says so with numbers; (3) a clip edited in fp8 passes the experiment's acceptance criteria against the fp32-exact edit.
+
+Agreement level of (1): 1.5e-5 ... 4e-5 relative, three orders under the arithmetic's own deviation from fp32 (3e-2).  It is not
+1e-6 because ONE v_mfma_scale instruction does not add its 64 products exactly: with a spread of magnitudes inside the 64 products
+the small ones lose their low bits against the largest (measured with tools/f8_acc_probe.cpp, profiles/r04_f8_probes.md: exact for
+similar magnitudes, 5e-5 rel L2 / 1e-4 of the sum of magnitudes at worst for a wide spread), while the emulation sums in fp64.
+The conversions themselves are bit-identical to torch's (RNE incl. subnormals; values above 464 would become NaN -- the kernel
+clamps to +-448 first: tools/f8_cvt_probe.cpp)."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -44,7 +51,7 @@ def test_fp8_linear_equals_the_cpu_emulation_of_the_same_quantisation(M, N, K, t
     exact = x.double() @ w.double().T + b.double() + r.double()
     e_emu, e_exact = rel(out.cpu(), emu), rel(out.cpu(), exact)
     print(f"\n[fp8 linear] M={M} N={N} K={K} tile={tile}: vs CPU emulation {e_emu:.2e}, vs exact fp64 {e_exact:.2e}")
-    assert e_emu < 3e-6, e_emu
+    assert e_emu < 2e-4, e_emu                     # see the module docstring: the MFMA's internal sum, not the quantisation
     assert 1e-4 < e_exact < 0.1, e_exact           # it IS an fp8 contraction: percent-level, not parity
 
 
@@ -62,7 +69,7 @@ def test_fp8_conv3x3_with_silu_epilogue_equals_the_cpu_emulation():
     assert tp.ops[0].flags & 64
     _run(tp)
     emu = F.silu(mxfp8.mx_conv2d_nhwc(x, w) + b.double())
-    assert rel(out.cpu(), emu) < 3e-6, rel(out.cpu(), emu)
+    assert rel(out.cpu(), emu) < 2e-4, rel(out.cpu(), emu)
 
 
 def test_fp8_layernorm_fold_and_swiglu_epilogue_equal_the_cpu_emulation():
@@ -94,7 +101,7 @@ def test_fp8_layernorm_fold_and_swiglu_epilogue_equal_the_cpu_emulation():
     inv[perm] = torch.arange(2 * Fd)
     y = y[:, inv]
     emu = y[:, :Fd] * F.silu(y[:, Fd:])
-    assert rel(out.cpu(), emu) < 5e-6, rel(out.cpu(), emu)
+    assert rel(out.cpu(), emu) < 2e-4, rel(out.cpu(), emu)
 
 
 def test_shapes_the_fp8_kernel_does_not_take_fall_back_to_split_bf16():
@@ -147,3 +154,62 @@ def test_stable_audio_dit_in_fp8_stays_within_the_experiment_acceptance_bound():
     assert torch.isfinite(outs["fp8"]).all()
     assert 1e-4 < dev < 0.15, dev
     assert float((outs["fp8"][0] - outs["fp8"][1]).abs().max()) > 1e-3
+
+
+def _logmel_like(wav, n_fft=512, hop=128, bands=32):
+    """A perceptual proxy without external libraries: log of band-averaged STFT magnitudes (mean over channels)."""
+    w = torch.hann_window(n_fft)
+    mag = torch.stft(wav.float(), n_fft, hop, window=w, return_complex=True).abs()          # [ch, n_fft/2+1, frames]
+    edges = torch.logspace(0, torch.log10(torch.tensor(float(n_fft // 2))), bands + 1).long().clamp(1, n_fft // 2)
+    bandsum = torch.stack([mag[:, lo:max(hi, lo + 1)].mean(1) for lo, hi in zip(edges[:-1], edges[1:])], 1)
+    return torch.log(bandsum.clamp_min(1e-5)).mean(0)
+
+
+def test_fp8_edit_passes_the_experiment_acceptance_criteria_against_the_fp32_exact_edit(monkeypatch):
+    """Acceptance of the fp8 EXPERIMENT at clip level (Stable Audio Open at FULL WIDTH -- 1536-wide DiT, 1025 tokens, full Oobleck
+    -- with 4 of the 24 DiT layers and a short schedule; random weights: the criteria are structural, the numbers are reported).
+    A clip is inverted and edited with the DiT on MX-FP8 GEMMs and on the fp32-exact split-bf16 GEMMs:
+      (a) self-consistency: editing with the SOURCE prompt and guidance from x_T reproduces the input latent (the edit-friendly
+          inversion absorbs whatever the model computes) -- to 1e-4 in both arithmetics;
+      (b) the fp8 edit is finite, and closer to the fp32-exact edit than that edit is to the original clip, in the latent and in a
+          log-band-spectrum distance of the decoded audio: d(fp8, exact) < 0.5 * d(exact, original)."""
+    from audioeditingcode_amd.main_run import edit_clip
+    from audioeditingcode_amd.models import load_model
+    from audioeditingcode_amd.utils import load_audio
+    monkeypatch.setitem(configs.FAMILIES["stable_audio"]["dit"], "num_layers", 4)
+    T, tstart = 10, 7
+    g = torch.Generator().manual_seed(3)
+    res = {}
+    for arith in ("bf16x6", "fp8"):
+        m = load_model("stabilityai/stable-audio-open-1.0", DEV, T, allow_synthetic=True)
+        m.arith = arith
+        n = m.model.transformer.config.sample_size * m.model.vae.hop_length
+        sr = m.get_sr()
+        if "wav" not in res:
+            tt = torch.arange(n - 16, dtype=torch.float64) / sr
+            res["wav"] = torch.stack([0.3 * torch.sin(2 * torch.pi * (220.0 + 5 * c) * tt).float()
+                                      + 0.05 * torch.randn(n - 16, generator=g) for c in range(2)]).numpy()
+        x0, _, duration = load_audio((res["wav"], sr), None, stft=False, model_sr=sr)
+        torch.manual_seed(9)
+        audio, orig, w_edit = edit_clip(m, x0, ["a dog barking"], ["a cat meowing"], [""], [2.0], [6.0], T, tstart, duration=duration)
+        torch.manual_seed(9)
+        _, _, w_same = edit_clip(m, x0, ["a dog barking"], ["a dog barking"], [""], [2.0], [2.0], T, T, duration=duration)
+        torch.manual_seed(9)
+        w0 = m.vae_encode(x0)
+        res[arith] = dict(audio=audio.cpu(), orig=orig.cpu(), w=w_edit.cpu(), w_same=w_same.cpu(), w0=w0.cpu())
+        del m
+        torch.cuda.empty_cache()
+    a, b = res["bf16x6"], res["fp8"]
+    assert torch.isfinite(b["audio"]).all() and torch.isfinite(b["w"]).all()
+    rec = {k: rel(res[k]["w_same"].reshape(-1), res[k]["w0"].reshape(-1)) for k in ("bf16x6", "fp8")}
+    d_lat = rel(b["w"], a["w"])
+    d_edit = rel(a["w"].reshape(-1), a["w0"].reshape(-1))
+    ma, mb, mo = _logmel_like(a["audio"]), _logmel_like(b["audio"]), _logmel_like(a["orig"])
+    F_ = min(ma.shape[-1], mb.shape[-1], mo.shape[-1])
+    d_mel, d_mel_edit = float((mb[..., :F_] - ma[..., :F_]).norm()), float((ma[..., :F_] - mo[..., :F_]).norm())
+    print(f"\n[fp8 acceptance] reconstruction rel L2: {rec}; edited latent fp8 vs exact {d_lat:.3e} (the edit moved the latent by "
+          f"{d_edit:.3e}); log-band-spectrum distance fp8 vs exact {d_mel:.3f} (edit vs original {d_mel_edit:.3f})")
+    assert d_lat > 1e-4                                            # the fp8 kernel really ran (full width: its GEMMs are LDS-staged)
+    assert rec["bf16x6"] < 1e-4 and rec["fp8"] < 1e-4, rec
+    assert d_lat < 0.5 * d_edit, (d_lat, d_edit)
+    assert d_mel < 0.5 * d_mel_edit, (d_mel, d_mel_edit)

@@ -73,6 +73,7 @@ def lib():
         L.aed_get_zs_from_xts.argtypes = [vp, vp, vp, vp, vp, cf, ci, fp, ci, ci, vp, vp, ctypes.c_int64, vp]
         L.aed_reverse_step_with_custom_noise.argtypes = [vp, vp, vp, vp, cf, ci, fp, ci, vp, vp, ctypes.c_int64, vp]
         L.aed_sample_xts_from_x0.argtypes = [vp, vp, vp, vp, vp, ci, ctypes.c_int64, vp]
+        L.aed_mx_quantize_rows.argtypes = [vp, vp, vp, ctypes.c_longlong, ci, vp]
         L.aed_sa_get_zs_from_xts.argtypes = [vp, vp, vp, vp, cf, fp, vp, ci, vp, vp, ctypes.c_int64, vp]
         L.aed_sa_reverse_step_with_custom_noise.argtypes = [vp, vp, vp, cf, fp, vp, vp, vp, ctypes.c_int64, vp]
         for name in ("aed_launch", "aed_tape_run", "aed_tape_profile", "aed_graph_begin", "aed_graph_end",
@@ -80,7 +81,7 @@ def lib():
                      "aed_cu_census", "aed_image_load", "aed_image_free", "aed_image_run", "aed_image_program",
                      "aed_image_buffer", "aed_image_copy_in", "aed_image_copy_out", "aed_event_create", "aed_event_record", "aed_event_elapsed_ms", "aed_event_destroy", "aed_get_zs_from_xts",
                      "aed_reverse_step_with_custom_noise", "aed_sample_xts_from_x0", "aed_device_info",
-                     "aed_sa_get_zs_from_xts", "aed_sa_reverse_step_with_custom_noise"):
+                     "aed_sa_get_zs_from_xts", "aed_sa_reverse_step_with_custom_noise", "aed_mx_quantize_rows"):
             getattr(L, name).restype = ci
         if L.aed_version() != 4:
             raise AedError("libaed.so ABI version mismatch")
@@ -94,7 +95,7 @@ EXPORTS = ["aed_version", "aed_last_error", "aed_device_info", "aed_launch", "ae
            "aed_image_buffer", "aed_image_copy_in", "aed_image_copy_out", "aed_event_create",
            "aed_event_record", "aed_event_elapsed_ms", "aed_event_destroy", "aed_get_zs_from_xts",
            "aed_reverse_step_with_custom_noise", "aed_sample_xts_from_x0", "aed_sa_get_zs_from_xts",
-           "aed_sa_reverse_step_with_custom_noise"]
+           "aed_sa_reverse_step_with_custom_noise", "aed_mx_quantize_rows"]
 
 
 def check(rc, what=""):

@@ -48,6 +48,10 @@ struct CGParams {
     const float* kbias;
     int geglu;               // W rows are packed [32 value | 32 gate] per 32 output features; 1: out = value * gelu(gate)
                              // (GEGLU), 2: out = value * silu(gate) (SwiGLU, the Stable Audio DiT's feed-forward)
+    // conv_gemm_f8.hip with pre-quantised weights (op flag bit 7): W as MX-FP8 -- e4m3 bytes [N][K] and one e8m0 scale byte per
+    // 32 k [N][K/32] (aed_mx_quantize_rows); null otherwise
+    const unsigned char* Wq;
+    const unsigned char* Wsc;
 };
 
 __device__ __forceinline__ float in_transform(float v, int act, float slope) {

@@ -52,17 +52,21 @@ __device__ __forceinline__ unsigned f8_quant4(float4 v, int& sbyte) {
     return (unsigned)w;
 }
 
-template <int BM, int BN, int WROWS, int WCOLS, bool PLAIN>
+// WQ: the weights arrive pre-quantised (p.Wq / p.Wsc, aed_mx_quantize_rows): the W side of the loader is a plain 16-byte copy per
+// thread and chunk -- no VALU, a quarter of the HBM bytes -- and only the activations are quantised in flight
+template <int BM, int BN, int WROWS, int WCOLS, bool PLAIN, bool WQ>
 __global__ __launch_bounds__(64 * WROWS * WCOLS, 2) void conv_gemm_f8_kernel(CGParams p) {
     constexpr int NT = 64 * WROWS * WCOLS;
     constexpr int WM = BM / WROWS, WN = BN / WCOLS;
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int TPR = F8_BK / 4;          // loader threads per row (float4 each) = 16
     constexpr int RPP = NT / TPR;           // rows per loader pass
-    constexpr int PA = BM / RPP, PB = BN / RPP;
+    constexpr int PA = BM / RPP, PB = WQ ? 1 : BN / RPP;
+    constexpr int RPPQ = NT / 4;            // pre-quantised W: 4 threads per 64-byte row chunk, rows per pass
+    constexpr int PBQ = WQ ? BN / RPPQ : 1;
     constexpr int STAGE = (BM + BN) * F8_ROWQ;      // uint4 per operand stage (A rows then W rows)
-    static_assert(TM >= 1 && TN >= 1 && PA >= 1 && PB >= 1, "tile");
-    static_assert(BM % RPP == 0 && BN % RPP == 0, "loader passes");
+    static_assert(TM >= 1 && TN >= 1 && PA >= 1 && (WQ || BN / RPP >= 1) && (!WQ || BN / RPPQ >= 1), "tile");
+    static_assert(BM % RPP == 0 && (WQ ? BN % RPPQ == 0 : BN % RPP == 0), "loader passes");
 
     __shared__ uint4 lds[2 * STAGE];
     __shared__ unsigned lsc[2][(BM + BN) * 2];      // e8m0 scale (low byte) per (row, k block)
@@ -120,6 +124,17 @@ __global__ __launch_bounds__(64 * WROWS * WCOLS, 2) void conv_gemm_f8_kernel(CGP
         wvalid[q] = n < p.N;
         wbase[q] = (unsigned)(wvalid[q] ? n : 0) * (unsigned)p.K + lcol;
     }
+    // pre-quantised W: thread (row tid / 4, quarter tid % 4) copies 16 bytes of its row's 64-byte chunk
+    const int qrow = tid >> 2, qq = tid & 3;
+    unsigned qbase[PBQ], qsbase[PBQ];
+    bool qvalid[PBQ];
+#pragma unroll
+    for (int q = 0; q < PBQ; ++q) {
+        const int n = n0 + qrow + RPPQ * q;
+        qvalid[q] = n < p.N;
+        qbase[q] = (unsigned)(qvalid[q] ? n : 0) * (unsigned)p.K + 16u * qq;                 // byte offset into Wq
+        qsbase[q] = (unsigned)(qvalid[q] ? n : 0) * (unsigned)(p.K >> 5);                    // byte offset into Wsc
+    }
     const int vIH = p.vIH, vIW = p.vIW;
     // running (tap, channel) position of the next chunk to prefetch: [group of p.kgroup channels][tap][chunk within the group]
     int pf_cg, pf_sub, pf_ty, pf_tx;
@@ -136,6 +151,8 @@ __global__ __launch_bounds__(64 * WROWS * WCOLS, 2) void conv_gemm_f8_kernel(CGP
     }
 
     float4 rbuf_a[PA], rbuf_b[PB];
+    uint4 rbuf_q[PBQ];
+    unsigned rbuf_s[PBQ];
     float ln_s1[PA], ln_s2[PA];
 #pragma unroll
     for (int q = 0; q < PA; ++q) { ln_s1[q] = 0.f; ln_s2[q] = 0.f; }
@@ -143,6 +160,8 @@ __global__ __launch_bounds__(64 * WROWS * WCOLS, 2) void conv_gemm_f8_kernel(CGP
     const __amdgpu_buffer_rsrc_t srd_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7ffffff0, 0x00020000);
     const __amdgpu_buffer_rsrc_t srd_a2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A2 ? p.A2 : p.A), 0, 0x7ffffff0, 0x00020000);
     const __amdgpu_buffer_rsrc_t srd_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7ffffff0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_q = __builtin_amdgcn_make_buffer_rsrc((void*)(WQ ? p.Wq : (const unsigned char*)p.W), 0, 0x7ffffff0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_s = __builtin_amdgcn_make_buffer_rsrc((void*)(WQ ? p.Wsc : (const unsigned char*)p.W), 0, 0x7ffffff0, 0x00020000);
     auto as_f4 = [](f8u32x4 v) {
         return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
     };
@@ -172,10 +191,20 @@ __global__ __launch_bounds__(64 * WROWS * WCOLS, 2) void conv_gemm_f8_kernel(CGP
             const unsigned off = (base + (unsigned)((iy >> p.up) * p.IW + (ix >> p.up)) * ld + (unsigned)c0) * 4u;
             ra[q] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(second ? srd_a2 : srd_a, ok ? off : F8_OOB, 0, 0));
         }
+        if constexpr (WQ) {
 #pragma unroll
-        for (int q = 0; q < PB; ++q)
-            rb[q] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(
-                srd_w, (wvalid[q] & !dead) ? (wbase[q] + k0) * 4u : F8_OOB, 0, 0));
+            for (int q = 0; q < PBQ; ++q) {
+                const bool ok = qvalid[q] & !dead;
+                const f8u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(srd_q, ok ? qbase[q] + k0 : F8_OOB, 0, 0);
+                rbuf_q[q] = make_uint4(v.x, v.y, v.z, v.w);
+                rbuf_s[q] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(srd_s, ok ? qsbase[q] + (k0 >> 5) : F8_OOB, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < PB; ++q)
+                rb[q] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(
+                    srd_w, (wvalid[q] & !dead) ? (wbase[q] + k0) * 4u : F8_OOB, 0, 0));
+        }
     };
 
     // one fetched float4 -> 4 fp8 bytes of its LDS row (+ the block's scale, written by the block's first lane)
@@ -205,8 +234,20 @@ __global__ __launch_bounds__(64 * WROWS * WCOLS, 2) void conv_gemm_f8_kernel(CGP
             }
             put_row(st, sc, lrow + RPP * q, v);
         }
+        if constexpr (WQ) {
 #pragma unroll
-        for (int q = 0; q < PB; ++q) put_row(st, sc, BM + lrow + RPP * q, rb[q]);
+            for (int q = 0; q < PBQ; ++q) {
+                const int row = BM + qrow + RPPQ * q;
+                st[row * F8_ROWQ + qq] = rbuf_q[q];
+                if (qq == 0) {
+                    sc[row * 2] = rbuf_s[q] & 0xffu;
+                    sc[row * 2 + 1] = (rbuf_s[q] >> 8) & 0xffu;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < PB; ++q) put_row(st, sc, BM + lrow + RPP * q, rb[q]);
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -406,8 +447,41 @@ template <int BM, int BN, int WR, int WC>
 static int f8_launch(const CGParams& p, bool plain, hipStream_t s) {
     dim3 grid(aed_cdiv(p.N, BN), aed_cdiv(p.M, BM), p.ksplit);
     dim3 block(64 * WR * WC);
-    if (plain) hipLaunchKernelGGL((conv_gemm_f8_kernel<BM, BN, WR, WC, true>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((conv_gemm_f8_kernel<BM, BN, WR, WC, false>), grid, block, 0, s, p);
+    if (p.Wq) {
+        if (plain) hipLaunchKernelGGL((conv_gemm_f8_kernel<BM, BN, WR, WC, true, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((conv_gemm_f8_kernel<BM, BN, WR, WC, false, true>), grid, block, 0, s, p);
+    } else {
+        if (plain) hipLaunchKernelGGL((conv_gemm_f8_kernel<BM, BN, WR, WC, true, false>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((conv_gemm_f8_kernel<BM, BN, WR, WC, false, false>), grid, block, 0, s, p);
+    }
+    return 0;
+}
+
+// ---- weights -> MX-FP8 once, at engine build (aed_mx_quantize_rows): the same f8_quant4 the loader applies in flight
+__global__ __launch_bounds__(256) void mx_quantize_rows_kernel(const float* __restrict__ src, unsigned* __restrict__ q,
+                                                               unsigned char* __restrict__ sc, long long total4, int k4) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long ld = idx < total4 ? idx : total4 - 1;          // whole 8-lane groups are valid or not (total4 % 8 == 0)
+    const float4 v = reinterpret_cast<const float4*>(src)[ld];
+    int sb;
+    const unsigned w = f8_quant4(v, sb);
+    if (idx < total4) {
+        q[idx] = w;
+        const long long row = idx / k4;
+        const int c4 = (int)(idx - row * k4);
+        if ((c4 & 7) == 0) sc[row * (k4 >> 3) + (c4 >> 3)] = (unsigned char)sb;
+    }
+}
+
+extern "C" int aed_mx_quantize_rows(const float* src, void* q, void* scales, long long rows, int K, void* stream) {
+    AED_REQUIRE(src && q && scales && rows > 0 && K > 0 && K % 32 == 0, "aed_mx_quantize_rows: K=%d must be a positive multiple of 32", K);
+    AED_REQUIRE((uintptr_t)src % 16 == 0 && (uintptr_t)q % 4 == 0, "aed_mx_quantize_rows: unaligned operand");
+    const long long total4 = rows * (K / 4);
+    const long long blocks = (total4 + 255) / 256;
+    AED_REQUIRE(blocks < (1LL << 31), "aed_mx_quantize_rows: too many elements for one launch");
+    hipLaunchKernelGGL(mx_quantize_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, (unsigned*)q,
+                       (unsigned char*)scales, total4, K / 4);
+    AED_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
@@ -429,6 +503,12 @@ int launch_conv_gemm_f8(const aed_op* op, hipStream_t s) {
     CGParams p;
     int rc = cg_fill_params(op, p, F8_BK);
     if (rc) return rc;
+    if (op->flags & 128) {          // pre-quantised weights: p[7] = e4m3 bytes [N][K], p[9] = e8m0 scales [N][K/32]
+        p.Wq = (const unsigned char*)op->p[7];
+        p.Wsc = (const unsigned char*)op->p[9];
+        AED_REQUIRE(p.Wq && p.Wsc && (uintptr_t)p.Wq % 16 == 0 && (long long)p.N * p.K < (1LL << 31),
+                    "conv_gemm_f8: flag bit 7 needs 16-byte aligned pre-quantised weights in p[7] / p[9]");
+    }
     if (p.ksplit > (p.K + 31) / 32) p.ksplit = (p.K + 31) / 32;     // launch_splitk_reduce clamps with 32-wide chunks
     if (cfg == 0) {
         const int cus = aed_num_cus();

@@ -121,6 +121,28 @@ def x6_tile(M, N, tile, ksplit, cus=None):
     return tile
 
 
+FP8_PREQUANT = 1        # fp8 experiment: 1 = weights quantised once at engine build (aed_mx_quantize_rows), 0 = in the loader (A/B)
+
+
+def mx_quantized_weights(w, N, K):
+    """(e4m3 bytes [N, K], e8m0 scale bytes [N, K/32]) of a weight matrix on the device, computed once per weight TENSOR OBJECT
+    (cached as an attribute of it: engines of several batch shapes share the packed weights; a freed-and-reused address
+    cannot alias because the cache dies with the tensor)."""
+    hit = getattr(w, "_aed_mxq", None)
+    if hit is not None and hit[2] == (w.data_ptr(), N, K):
+        return hit[0], hit[1]
+    q = torch.empty((N, K), dtype=torch.uint8, device=w.device)
+    sc = torch.empty((N, K // 32), dtype=torch.uint8, device=w.device)
+    with torch.cuda.device(w.device):
+        L.check(L.lib().aed_mx_quantize_rows(w.data_ptr(), q.data_ptr(), sc.data_ptr(), N, K, L.current_stream_ptr()),
+                "aed_mx_quantize_rows")
+    try:
+        w._aed_mxq = (q, sc, (w.data_ptr(), N, K))
+    except AttributeError:                       # pragma: no cover
+        pass
+    return q, sc
+
+
 class Tape:
     def __init__(self, device):
         self.device = torch.device(device)
@@ -303,6 +325,12 @@ class Tape:
                         [x, w, bias, out, res, rowvec, None, None, x2, kbias], name=name,
                         flops=2 * M * N * K if alg_flops is None else alg_flops, exec_flops=2 * M * N * K,
                         nbytes=4 * (B * IH * IW * Cin + N * K + M * n_out), flags=flags)
+        if flags & 64 and FP8_PREQUANT and Cin % 64 == 0 and kbias is None and torch.is_tensor(w) and w.is_cuda:
+            # fp8 experiment: the (frozen) weights are quantised to MX-FP8 ONCE, here, and the record points at the bytes
+            q, sc = mx_quantized_weights(w, N, K)
+            self.keep += [q, sc]
+            self.ops[idx].p[7], self.ops[idx].p[9] = q.data_ptr(), sc.data_ptr()
+            self.ops[idx].flags |= 128
         if ksplit > 1:
             self._ws_need = max(self._ws_need, ksplit * M * N)
             self._ws_ops.append(idx)

@@ -50,7 +50,9 @@ enum aed_opcode {
                                  bit 6 (EXPERIMENT, tapes built under tape.arith_mode("fp8")): contract on the MX-FP8 matrix
                                  cores (csrc/conv_gemm_f8.hip: OCP microscaling e4m3, one e8m0 scale per 32 k of a row,
                                  quantised in the loader, v_mfma_scale_f32_32x32x64_f8f6f4, fp32 accumulate).  NOT a parity
-                                 path (a few 1e-2 relative per GEMM); ops that kernel does not take run bits 2|3         */
+                                 path (a few 1e-2 relative per GEMM); ops that kernel does not take run bits 2|3;
+                                 bit 7: with bit 6, the weights are pre-quantised: p[7] = e4m3 bytes [N][K], p[9] = e8m0
+                                 scale bytes [N][K/32] (aed_mx_quantize_rows); p[1] stays the fp32 weights (fallback)   */
     AED_OP_GN_STATS = 2,      /* GroupNorm partial sums (K4)                                   */
     AED_OP_GN_APPLY = 3,      /* GroupNorm normalise + affine (+SiLU) (K4)                     */
     AED_OP_LAYERNORM = 4,     /* RETIRED in v4 (returns an error): LayerNorm is fused into the consuming GEMM (K8)  */
@@ -183,6 +185,12 @@ int aed_reverse_step_with_custom_noise(const float* xt, const float* eps_u, cons
 int aed_sample_xts_from_x0(const float* x0, const float* noise, const float* sqrt_abar,
                            const float* sqrt_1m_abar, float* xts_out, int n_t, int64_t numel,
                            void* stream);
+
+/* EXPERIMENT (fp8 path of BASELINE config 5; no reference counterpart -- the reference's DiT call, models.py:1331-1354, is fp32):
+ * rows of an fp32 matrix [rows][K] (K % 32 == 0) -> OCP MX-FP8: e4m3 bytes q[rows][K] and one e8m0 scale byte per 32 k,
+ * scales[rows][K/32]; scale = 2^(floor(log2(block amax)) - 8), element = RNE_e4m3(clamp(x / scale, +-448)).  Weights quantised
+ * once with this feed AED_OP_CONV_GEMM records with flag bits 6|7 (p[7] = q, p[9] = scales); csrc/conv_gemm_f8.hip.          */
+int aed_mx_quantize_rows(const float* src, void* q, void* scales, long long rows, int K, void* stream);
 
 /* ----------------------------------------------------------------------------------------
  * Stable Audio Open (StableAudWrapper, models.py:1051-1354)

@@ -219,3 +219,35 @@ def test_fp8_edit_passes_the_experiment_acceptance_criteria_against_the_fp32_exa
     assert torch.isfinite(b["w_same"]).all()
     assert d_lat < 0.5 * d_edit, (d_lat, d_edit)
     assert d_mel < 0.5 * d_mel_edit, (d_mel, d_mel_edit)
+
+
+def test_weight_quantiser_is_bit_identical_to_the_cpu_emulation_and_the_prequantised_path_is_used():
+    """aed_mx_quantize_rows (what engines built under arith_mode("fp8") call once per weight) against oracle/mxfp8.py -- the bytes
+    reinterpreted as e4m3 times the e8m0 scales equal the emulation's dequantised values EXACTLY; records built with it carry
+    flag bit 7 and give the same result as in-loader quantisation of the same weights (identical operands, identical MFMAs)."""
+    N, K, M = 200, 512, 300
+    g = torch.Generator().manual_seed(4)
+    w = torch.randn(N, K, generator=g) * torch.exp(torch.randn(N, 1, generator=g))
+    w[3, 64:96] = 0                                               # an all-zero block
+    x = torch.randn(M, K, generator=g)
+    wd = w.to(DEV)
+    q, sc = tape_mod.mx_quantized_weights(wd, N, K)
+    torch.cuda.synchronize()
+    deq = q.view(torch.float8_e4m3fn).float().cpu().reshape(N, K // 32, 32) * \
+        torch.ldexp(torch.ones(()), sc.cpu().to(torch.int32) - 127).reshape(N, K // 32, 1)
+    assert torch.equal(deq.reshape(N, K), mxfp8.mx_dequantized(w))
+    outs = []
+    for pre in (1, 0):
+        tape_mod.FP8_PREQUANT = pre
+        try:
+            tp = Tape(DEV)
+            out = tp.alloc(M, N)
+            with tape_mod.arith_mode("fp8"):
+                tp.linear(tp.hold(x.to(DEV)), wd, None, out, M=M, K=K, N=N, tile=1)
+            assert bool(tp.ops[0].flags & 128) == bool(pre)
+            _run(tp)
+            outs.append(out.cpu().clone())
+        finally:
+            tape_mod.FP8_PREQUANT = 1
+    assert torch.equal(outs[0], outs[1])
+    assert rel(outs[0], mxfp8.mx_linear(x, w)) < 2e-4

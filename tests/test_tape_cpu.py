@@ -396,8 +396,14 @@ def test_arith_mode_marks_only_the_lds_staged_gemms():
     assert tape_mod.x6_tile(204800, 64, 2, 1) == 2
     assert tape_mod.x6_tile(204800, 768, 1, 1) == 9 and tape_mod.x6_tile(51200, 640, 1, 1) == 8     # whole 256-wide tiles only
     with pytest.raises(KeyError):
-        with tape_mod.arith_mode("fp8"):
+        with tape_mod.arith_mode("fp4"):
             pass
+    # the fp8 EXPERIMENT marks the same records with bit 6 on top of the split-bf16 bits (the fallback of shapes its kernel
+    # does not take); on a CPU tape nothing is pre-quantised (no bit 7)
+    with tape_mod.arith_mode("fp8"):
+        f8 = build()
+    for b, c in zip(x6.ops, f8.ops):
+        assert c.flags == (b.flags | 64 if b.flags & 4 else 0) and list(b.i) == list(c.i)
 
 
 def test_swept_x6_table_decides_kernel_and_tile_per_shape(monkeypatch):

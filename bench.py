@@ -822,11 +822,15 @@ def sub_benchmarks(elapsed_s):
             ("config4_pc_extract_apply", [py, os.path.join(ROOT, "tools", "bench_config4.py")], 300),
             ("config5_stable_audio", [py, os.path.join(ROOT, "tools", "bench_stable_audio.py"), "--steps", "1",
                                            "--warmup", "1"], 300),
+            # EXPERIMENT, not a parity path: the same clip with the DiT's GEMMs on the MX-FP8 matrix cores (BASELINE config 5 names an
+            # "fp8 MFMA path"); its `parity_T200` reads as the deviation from the fp32 CPU oracle
+            ("config5_stable_audio_fp8_experiment", [py, os.path.join(ROOT, "tools", "bench_stable_audio.py"), "--arith", "fp8",
+                                                      "--steps", "1", "--warmup", "1"], 200),
             # the round-1..3 arithmetic (fp32-input MFMAs everywhere) through the same pipeline, for the A/B in one driver run
             ("pipeline_arith_f32", [py, os.path.join(ROOT, "bench.py"), "--arith", "f32", "--steps", "6", "--warmup", "2",
                                     "--no-extras", "--no-cpu-baseline", "--no-batched"], 150)]
     # the A/B leg only starts while the whole run is still short (the default run stays within ~6.5 minutes)
-    start_by = {"pipeline_arith_f32": 330}
+    start_by = {"pipeline_arith_f32": 330, "config5_stable_audio_fp8_experiment": 360}
     out = {}
     for key, cmd, limit in jobs:
         if elapsed_s > start_by.get(key, 600):  # keep the whole default run bounded

@@ -390,8 +390,9 @@ class Tape:
         # soon as there is a workgroup per CU of the LANE (measured, profiles/r04_attn_x6_ab.jsonl: 1024 tokens at batch 2 on a
         # 64-CU stream 86 -> 51 us, on 128 CUs 48 -> 34 us, on the whole chip 30 -> 35 us; 256 tokens: fp32 wins everywhere)
         if arith & 4 and variant == 0 and D in (32, 48, 64) and Nk > 64 and \
+                self._ptr(q) % 16 == 0 and self._ptr(k) % 16 == 0 and \
                 math.ceil(Nq / 128) * H * B >= REGIME_CUS.get(getattr(_regime, "name", None), CU_COUNT):
-            variant = 3
+            variant = 3         # (the kernel's float4 fragment loads need 16-byte aligned q / k; a forced variant does not fall back)
         self._add(L.OP_ATTENTION, [B, H, Nq, Nk, D, ldq, ldk, ldv, ldo, ld_bias, bsq, bsk, bsv, bso, variant], [scale],
                   [q, k, v, bias, out], name=name, flops=4 * B * H * Nq * Nk * D,
                   nbytes=4 * B * H * D * (2 * Nq + 2 * Nk), flags=arith & 4)

@@ -89,7 +89,9 @@ def test_edit_lanes_widen_on_drain_and_stay_bit_identical_tiny(monkeypatch):
         assert torch.equal(w, w2), (i, float((w - w2).abs().max()))
         assert torch.equal(a, a2) and torch.equal(o, o2), i
     rep = pipe.report()
-    assert rep["widened_on_drain"], rep["widened_on_drain"]      # the last clip's loop moved to its widened queue
+    # the last clip's loop moved to its widened queue -- or, if the front stage had already drained when that job STARTED (a race
+    # of microseconds on this tiny model), ran on the whole chip from its first step: either way nothing idles in the drain
+    assert rep["widened_on_drain"] or rep["device_ms"].get("back_chip"), (rep["widened_on_drain"], list(rep["device_ms"]))
     pipe.close()
 
 

@@ -389,6 +389,13 @@ def test_clip_pipeline_plans_equal_serial_edit_clip(cpu_stack, monkeypatch):
         split = ClipPipeline(m, plan="partition", edit_cus=128, edit_lanes=2, timestep_group=3)
         assert [w.lane.cus for w in split.workers] == [list(range(128, 256)), list(range(64)), list(range(64, 128)),
                                                        list(range(128, 256))]
+        # drain widening (round 4): each disjoint edit lane owns a second queue over its CUs + its half of the inversion partition;
+        # lanes that share the edit partition (no legal split) have none; the switch is optional
+        back = [w for w in split.workers if w.stage == "back"]
+        assert [w.wide.cus for w in back] == [list(range(64)) + list(range(128, 192)), list(range(64, 128)) + list(range(192, 256))]
+        assert all(w.wide is None for w in pipe.workers)
+        assert all(w.wide is None for w in ClipPipeline(m, plan="partition", edit_cus=128, edit_lanes=2, timestep_group=3,
+                                                        widen_on_drain=False).workers)
         # 64-CU lanes and the 128-CU inversion partition take the tile tables swept on streams of that size (round 4)
         assert split.edit_lane_cus == 64 and split.workers[1].regime == "cus64" and split.workers[0].regime == "cus128"
         quad = ClipPipeline(m, plan="lanes", lanes=4, lane_cus=64, timestep_group=3)       # four mini-chips, whole clips each

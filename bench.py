@@ -538,7 +538,14 @@ def main():
         out.update(extra)
         if subs:
             out.update(subs)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    if grouped:
+        # leave the process group cleanly (RCCL warns about leaked resources otherwise); never fatal after the line is out
+        try:
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+        except Exception as e:          # noqa: BLE001
+            log(f"process group teardown: {e!r}")
 
 
 def _measure_groups(groups):

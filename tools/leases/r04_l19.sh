@@ -2,7 +2,7 @@
 # Round 4, lease 19: the torchrun launch path (one-rank RCCL group: on-device weight broadcast + gather) on the final tree
 O=gpurun_out/r04t; mkdir -p $O
 export PYTHONPATH=$PWD HSA_ENABLE_IPC_MODE_LEGACY=0
-timeout 240 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29641 bench.py --gpus 1 --steps 6 --warmup 2 --no-extras --no-cpu-baseline --no-batched > $O/bench_torchrun1.json 2> $O/bench_torchrun1.err; echo "torchrun rc=$? $(date +%T)"
+timeout 240 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29641 bench.py --gpus 1 --steps 3 --warmup 1 --no-extras --no-cpu-baseline --no-batched > $O/bench_torchrun1.json 2> $O/bench_torchrun1.err; echo "torchrun rc=$? $(date +%T)"
 python - "$O/bench_torchrun1.json" <<'PY'
 import json,sys
 try:

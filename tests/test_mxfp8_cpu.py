@@ -40,3 +40,34 @@ def test_mx_linear_deviation_is_percent_level_not_parity():
     got = mxfp8.mx_linear(a, w)
     rel = float((got - ref).norm() / ref.norm())
     assert 5e-3 < rel < 8e-2, rel                                        # a few percent: this arithmetic is an experiment
+
+
+def test_tape_interpreter_states_the_fp8_flag_like_the_kernel_launcher():
+    """oracle/tape_interp.py on AED_OP_CONV_GEMM records with flag bit 6: shapes the device kernel takes (Cin % 64 == 0, LDS-staged
+    tile) contract MX-FP8 operands -- LayerNorm statistics from the RAW rows, activation before the quantisation, K in (tap, channel)
+    order --, shapes it does not take stay fp32.  (CPU semantics of the experiment; the kernel itself is tested on the GPU.)"""
+    import torch.nn.functional as F
+
+    from audioeditingcode_amd import tape as tape_mod
+    from audioeditingcode_amd.tape import Tape
+    from oracle import tape_interp
+    g = torch.Generator().manual_seed(0)
+    M, K, N = 96, 128, 64
+    x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g)
+    tp = Tape("cpu")
+    out, out32, conv_out = tp.alloc(M, N), tp.alloc(M, N), tp.alloc(2, 6, 5, 64)
+    xi = torch.randn(2, 6, 5, 64, generator=g)
+    wc = torch.randn(64, 3, 3, 64, generator=g) / 24.0
+    with tape_mod.arith_mode("fp8"):
+        tp.linear(tp.hold(x), tp.hold(w), tp.hold(b), out, M=M, K=K, N=N, in_act=1, tile=1)          # SiLU on A, then quantise
+        tp.linear(tp.hold(x[:, :32].contiguous()), tp.hold(w[:, :32].contiguous()), None, out32, M=M, K=32, N=N, tile=4)
+        tp.conv(tp.hold(xi), tp.hold(wc.reshape(64, -1).contiguous()), None, conv_out, B=2, IH=6, IW=5, Cin=64, OH=6, OW=5, N=64,
+                KH=3, KW=3, pad_h=1, pad_w=1, tile=4)
+    assert all(op.flags & 64 for op in tp.ops)
+    tape_interp.run_tape(tp)
+    assert torch.allclose(out.double(), mxfp8.mx_linear(F.silu(x), w) + b.double(), rtol=1e-6, atol=1e-6)
+    assert torch.allclose(out32.double(), x[:, :32].double() @ w[:, :32].double().T, rtol=1e-6, atol=1e-6)      # Cin = 32: fp32
+    assert torch.allclose(conv_out.double(), mxfp8.mx_conv2d_nhwc(xi, wc), rtol=1e-6, atol=1e-6)
+    exact = F.silu(x).double() @ w.double().T + b.double()
+    dev = float((out.double() - exact).norm() / exact.norm())
+    assert 5e-3 < dev < 8e-2, dev

@@ -120,7 +120,14 @@ class LoopPlumbing:
             if use_graph and steps > 1 and not getattr(self, "eager_steps", False):
                 g = plan.get("graph") if plan is not None else None
                 if g is None:
-                    g = Tape.graph_capture(body)
+                    # a clip pipeline's codec worker issues on the front lane's stream from ANOTHER thread (thread-local capture
+                    # mode does not keep its launches out of a capturing stream): capture under the pipeline's lock
+                    lock = getattr(self, "capture_lock", None)
+                    if lock is None:
+                        g = Tape.graph_capture(body)
+                    else:
+                        with lock:
+                            g = Tape.graph_capture(body)
                     if plan is not None:
                         plan["graph"] = g
                 ev0.record(stream)

@@ -208,6 +208,7 @@ class PipelineWrapper(torch.nn.Module):
         ed.lane_stream = self.__dict__.get("_lane_stream")
         ed.eager_steps = bool(self.__dict__.get("_lane_eager"))       # lanes issue their steps launch by launch
         ed.lane_chooser = self.__dict__.get("_lane_chooser")          # per-chunk lane choice of a pipeline's edit loop
+        ed.capture_lock = self.__dict__.get("_capture_lock")          # graph captures vs another thread's launches on the lane
         ed.arith = self.arith
         if hasattr(self, "arith_min_batch"):           # smallest U-Net batch whose engine takes `arith` (default: every engine)
             ed.ARITH_MIN_BATCH = int(self.arith_min_batch)

@@ -38,7 +38,8 @@ import time
 import torch
 
 from . import tape as tape_mod
-from .ddm_inversion.inversion_utils import inversion_reverse_process, prepare_forward, run_forward
+from .ddm_inversion.inversion_utils import (conditioning_from_text, inversion_reverse_process, prepare_forward,
+                                             run_forward)
 from .streams import PartitionStream
 
 DEFAULT_EDIT_CUS = 128          # CUs of the edit-loop partition (the two stages' per-clip times cross near 128 of 256)
@@ -99,7 +100,7 @@ class ClipPipeline:
 
     def __init__(self, model, plan="partition", edit_cus=None, edit_lanes=1, lanes=None, launch="graph",
                  timestep_group=100, overlap_prep=True, lane_cus=None, separate_queues=None, codec_stage=None,
-                 widen_on_drain=True):
+                 widen_on_drain=True, edit_group=1, group_sizes=None, group_wait_s=0.0):
         if getattr(model, "kind", None) == "stable_audio":
             raise NotImplementedError("ClipPipeline drives the mel-latent families (AudioLDM / AudioLDM2 / TANGO)")
         if plan not in ("partition", "lanes"):
@@ -108,6 +109,21 @@ class ClipPipeline:
             raise ValueError("launch must be 'eager' or 'graph'")
         self.model, self.plan, self.launch = model, plan, launch
         self.timestep_group = int(timestep_group)
+        # edit_group > 1 ("group plan", round 5): an edit lane steps up to `edit_group` clips IN LOCKSTEP -- one U-Net call per
+        # diffusion step at batch 2g for the g clips whose inversions are ready when the lane becomes free (the per-rank shape
+        # of BASELINE config 3, SURVEY 8e: "processed as one batch ... with cond+uncond stacked").  The batch-2 edit step is
+        # latency-bound (572 launches of ~25 us whatever their size: profiles/r04_lane_perop_cus64.json); at batch 16 the same
+        # lane runs 8 clip-steps in 3.5x the time of one (profiles/r05_batch_scaling.md).  Every clip's arithmetic is still its
+        # own rows of the batch; against the clip edited alone the values agree to fp32 rounding (other tiles / split-K orders
+        # per batch shape), not bit for bit -- tests and bench.py assert the tolerance instead of identity for this plan.
+        self.edit_group = max(1, int(edit_group))
+        if self.edit_group > 1 and plan != "partition":
+            raise ValueError("edit_group > 1 needs the partition plan")
+        sizes = sorted({int(g) for g in (group_sizes or [1 << k for k in range(self.edit_group.bit_length())])
+                        if 1 <= int(g) <= self.edit_group} | {1})
+        self.group_sizes = sizes                # U-Net batch 2g engines exist for exactly these g (built by warm_up)
+        self.group_log = []                     # sizes of the groups the last edit_clips formed
+        self.group_wait_s = float(group_wait_s)  # how long a free lane waits for a FULL group before taking what is ready
         dev = model.device
         acquire = getattr(self.lane_type, "acquire", None)
 
@@ -161,14 +177,16 @@ class ClipPipeline:
             # compete for the same CUs one workgroup at a time: 600 ms per clip, and the inversion slows as well).  The next
             # clip's set-up stays on the front lane too: three busy hardware queues, each on a dispatch pipe of its own
             # (streams.py).  With one edit lane the codec stays in the back stage on an unmasked stream (round 3).
-            self.codec_stage = n > 1 if codec_stage is None else bool(codec_stage)
+            self.codec_stage = (n > 1 or self.edit_group > 1) if codec_stage is None else bool(codec_stage)
+            if self.edit_group > 1 and not self.codec_stage:
+                raise ValueError("the group plan (edit_group > 1) hands every edited latent to the codec stage")
             self.stages = [("front", ("front",), front), ("back", ("back",), back)]
             if self.codec_stage:
                 front[0].prep = None
                 self.stages.append(("codec", ("codec",), [_Worker("codec", 0, self._view(), front[0].lane, None)]))
             self.queue_log = []
             if separate_queues is None:
-                separate_queues = n > 1
+                separate_queues = n > 1 or self.edit_group > 1
             if separate_queues and hasattr(self.lane_type, "respin") and dev.type == "cuda":
                 # every lane that is busy at the same time needs its own dispatch pipe (streams.py)
                 from .streams import separate_queues as _separate
@@ -194,6 +212,9 @@ class ClipPipeline:
                     kept = _separate([front[0].lane] + [w.wide for w in back], log=self.drain_queue_log)
                     for w, ps in zip(back, kept[1:]):
                         w.wide = ps
+            if widen_on_drain and self.edit_group > 1 and n == 1:
+                # one group lane: when the front stage has drained, the running group loop continues on the lane's unmasked queue
+                back[0].wide = back[0].full
         else:
             n = DEFAULT_LANES if lanes is None else int(lanes)
             if n < 1:
@@ -228,6 +249,13 @@ class ClipPipeline:
                 for w, ps in zip(ws, _separate([w.lane for w in ws], log=self.queue_log)):
                     w.lane = ps
         self._build_lock = threading.Lock()     # an un-warmed worker builds engines (and lazily folds shared weights)
+        # The codec worker issues on the FRONT lane's stream from its own thread.  hipStreamBeginCapture(ThreadLocal) does not keep
+        # another thread's launches out of a capturing stream: a late graph capture of the front worker (a new loop shape after
+        # warm-up, an LRU plan eviction) must not interleave with a codec job.  Every lane view carries this lock;
+        # LoopPlumbing._run_graph holds it while capturing, _codec while issuing.
+        self._capture_lock = threading.Lock()
+        for w in self.workers:
+            w.view._capture_lock = self._capture_lock
         self.stats = []
         self.widened = set()                    # edit lanes that moved to their widened queue during the last edit_clips
 
@@ -387,6 +415,40 @@ class ClipPipeline:
         with self._stream_ctx(cs):
             return self._decode(v, w_edit, f["x0"])
 
+    def _back_group(self, w, st, job, fs):
+        """The edit loops of len(fs) clips in LOCKSTEP (inversion_utils.py:221-315 for each of them): one U-Net call per
+        diffusion step over the rows [uncond x g | target x g] (editing.EditEngine.edit with n = g: the layout of BASELINE
+        config 3's per-rank batch).  Returns one codec payload per clip."""
+        v, a = w.view, job["a"]
+        Z, g = int(a["tstart"]), len(fs)
+        for f in fs:
+            st.wait_event(f["done"])
+            for t in (f["x0"], f["zs"], f["wts"]):
+                if t.is_cuda:
+                    t.record_stream(st)
+        if w.wide is not None and st is w.lane.stream:
+            def chooser():          # the widened lane once the front stage has issued AND finished its last inversion
+                with job["lock"]:
+                    ev = job["front_event"]
+                    drained = job["stage_done"][0] and (ev is None or ev.query())
+                if drained:
+                    self.widened.add(w.k)
+                return w.wide.stream if drained else None
+            v._lane_chooser = chooser
+        try:
+            ed = v.editor(fs[0]["wts"].shape[-2], fs[0]["wts"].shape[-1])
+            x_z = ed.to_nhwc(torch.stack([f["wts"][Z] for f in fs]))                  # x_tstart of every clip   [g, H, W, C]
+            zs = ed.to_nhwc(torch.stack([f["zs"][:Z] for f in fs], 1))                # their noise maps         [Z, g, H, W, C]
+            cond_tgt = conditioning_from_text(v, v.encode_text(a["tgt"])).repeat(g)
+            cond_neg = conditioning_from_text(v, v.encode_text(a["neg"], negative=True))
+            w_edit = ed.to_nchw(ed.edit(x_z.unsqueeze(0).expand(Z + 1, *x_z.shape), zs, Z, cond_tgt, cond_neg, a["cfg_tar"],
+                                        eta=float(a["eta"])))
+        finally:
+            v._lane_chooser = None
+        edited = self.event_type()
+        edited.record(st)           # (_run_graph made st wait for whichever stream the last chunk of the loop ran on)
+        return [dict(x0=f["x0"], w_edit=w_edit[k:k + 1], done=edited) for k, f in enumerate(fs)]
+
     @staticmethod
     def _decode(v, w_edit, x0):
         x0_dec = v.vae_decode(w_edit)
@@ -402,7 +464,8 @@ class ClipPipeline:
         for t in (e["w_edit"], e["x0"]):
             if t.is_cuda:
                 t.record_stream(st)
-        return self._decode(w.view, e["w_edit"], e["x0"])
+        with self._capture_lock:                    # never issue into a stream another thread is capturing on (see __init__)
+            return self._decode(w.view, e["w_edit"], e["x0"])
 
     # ------------------------------------------------------------------ workers
     def _pick_lane(self, w, job, stage_idx):
@@ -430,7 +493,66 @@ class ClipPipeline:
         w.warm = True
         return payload
 
+    def _process_group(self, w, job, fs, lane):
+        """A group of front-stage payloads through the back half on `lane` (group plan)."""
+        guard = self._build_lock if not w.warm else contextlib.nullcontext()
+        with guard, tape_mod.tile_regime(w.regime), torch.inference_mode(), self._on(w, lane) as st:
+            out = self._back_group(w, st, job, fs)
+        return out
+
+    def _run_group_worker(self, w, stage_idx, job):
+        """Back-stage worker of the group plan: takes every clip whose inversion is ready -- up to `edit_group`, rounded down to
+        a size an engine exists for (`group_sizes`) -- and steps them in lockstep.  Greedy on purpose: with a slow front stage
+        the groups stay small (latency), with a fast one they grow until the lane keeps up (throughput)."""
+        q = job["queues"][stage_idx]
+        pending, stopped = [], False
+        while True:
+            if not pending:
+                if stopped:
+                    return
+                got = q.get()
+                if got is _STOP:
+                    return
+                pending.append(got)
+            deadline = time.perf_counter() + self.group_wait_s
+            while len(pending) < self.edit_group and not stopped:
+                try:
+                    left = deadline - time.perf_counter()
+                    got = q.get(timeout=left) if left > 0 else q.get_nowait()
+                except queue.Empty:
+                    break
+                if got is _STOP:
+                    stopped = True
+                else:
+                    pending.append(got)
+            if job["error"] is not None:
+                return
+            g = max(s for s in self.group_sizes if s <= len(pending))
+            batch, pending = pending[:g], pending[g:]
+            self.group_log.append(g)
+            with job["lock"]:
+                job["busy"][stage_idx] += 1
+            t0 = time.perf_counter()
+            try:
+                outs = self._process_group(w, job, [f for _, f in batch], self._pick_lane(w, job, stage_idx))
+                w.warm = True
+            except BaseException as e:                          # noqa: BLE001 -- reported by edit_clips
+                with job["lock"]:
+                    if job["error"] is None:
+                        job["error"] = (batch[0][0], e)
+                return
+            finally:
+                with job["lock"]:
+                    job["busy"][stage_idx] -= 1
+            t1 = time.perf_counter()
+            for (i, _), payload in zip(batch, outs):
+                job["times"].append(dict(clip=i, stage=w.stage, worker=w.k, start=t0 - job["t0"], end=t1 - job["t0"],
+                                         group=g))
+                job["queues"][stage_idx + 1].put((i, payload))
+
     def _run_worker(self, w, stage_idx, halves, job):
+        if self.edit_group > 1 and halves == ("back",):
+            return self._run_group_worker(w, stage_idx, job)
         gate = job["gate"]
         v = w.view
         if "front" in halves:
@@ -529,6 +651,7 @@ class ClipPipeline:
                                                           cfg_tar, T, tstart, eta))
         self.stats, self._times = [], job["times"]
         self.widened = set()
+        self.group_log = []
         if not job["items"]:
             return []
         self._base = None
@@ -554,6 +677,15 @@ class ClipPipeline:
         payload = None
         for s, (_, halves, ws) in enumerate(self.stages):
             outs = []
+            if self.edit_group > 1 and halves == ("back",):
+                # one engine + loop plan + step graph per group size (U-Net batch 2g); the clip is simply repeated
+                for w in ws:
+                    job = self._job([item], [seed], prepare, a)
+                    for g in self.group_sizes:
+                        outs = self._process_group(w, job, [payload] * g, w.lane)
+                    w.warm = True
+                payload = outs[0]
+                continue
             for w in ws:
                 job = self._job([item], [seed], prepare, a)
                 v = w.view
@@ -592,6 +724,7 @@ class ClipPipeline:
                     device_ms={k: dict(n=len(v), avg=sum(v) / len(v)) for k, v in acc.items()},
                     queue_separation=getattr(self, "queue_log", None), timeline=timeline,
                     widened_on_drain=sorted(getattr(self, "widened", ())),
+                    edit_group=self.edit_group, group_sizes=self.group_sizes, groups_formed=list(self.group_log),
                     drain_queue_separation=getattr(self, "drain_queue_log", None),
                     clip_latency_ms_avg=(sum(lats) / len(lats)) if lats else None,
                     clip_latency_ms_max=max(lats) if lats else None)

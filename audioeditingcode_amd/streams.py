@@ -54,6 +54,7 @@ class PartitionStream:
         ps = cls._cache.get(key)
         if ps is None:
             ps = cls._cache[key] = cls(dev, cus=cus, total=total)
+            ps.index = int(index)
         return ps
 
     def __init__(self, device, cus=None, total=None, priority=0):
@@ -81,7 +82,10 @@ class PartitionStream:
 
     def respin(self, k):
         """Another hardware queue with this stream's CU mask (the driver may place it on a different dispatch pipe)."""
-        return type(self).acquire(self.device, cus=self.cus, total=self.total, index=1000 + int(k))
+        # keyed by the ORIGINAL queue's index as well: two lanes that share a CU mask (index 0 and 1) must not respin into the
+        # same cached queue (they would silently serialise on one hardware queue)
+        return type(self).acquire(self.device, cus=self.cus, total=self.total,
+                                  index=1000 + 16 * (getattr(self, "index", 0) % 1000) + int(k))
 
     def census(self, n_blocks=2048, spin_clocks=200000):
         """Physical CUs this stream's workgroups land on: sorted list of (xcc, se, sh, cu)."""

@@ -8,7 +8,7 @@ torchvision, torchaudio, librosa, wandb, soundfile, progressbar); name-only stub
 modules are injected exactly as SURVEY.md 8(c)/Appendix B describes.  What each
 fixture pins is listed in tests/golden/README.md.
 
-Usage:  python oracle/make_golden.py [loops|pc|pc_cli|audio|hifigan|unet|vae|stable_audio|text|all]
+Usage:  python oracle/make_golden.py [loops|pc|pc_cli|audio|hifigan|unet|unet_graph|vae|stable_audio|text|all]
 """
 import importlib.util
 import os
@@ -521,6 +521,175 @@ def gen_unet():
     print("unet twin", tuple(out.shape), float(out.abs().mean()), "params", sum(p.numel() for p in net.parameters()))
 
 
+# --------------------------------------------------------------------------- the reference's INLINE U-Net forward graphs
+def gen_unet_graph():
+    """Pins SURVEY row A8's graph level: the reference's own `PipelineWrapper.unet_forward` (models.py:160-393) and
+    `AudioLDM2Wrapper.unet_forward` (models.py:691-899) are EXECUTED here, unbound, on a stand-in `self.model.unet` that
+    exposes the diffusers attribute surface those two functions touch (time_proj / time_embedding / class_embedding /
+    conv_in / down_blocks[i](...) -> (sample, res_samples) / mid_block / up_blocks[i].resnets + __call__ / conv_norm_out /
+    conv_act / conv_out / num_upsamplers / config).  The stand-in BLOCKS compute with oracle/unet.py's block functions (pinned
+    by the in-tree twin, unet_twin_c32.npz); everything BETWEEN the blocks -- the time / class-embedding prelude, mask -> bias
+    conversion, which residuals an up block receives (`down_block_res_samples[-len(resnets):]`), replace_h_space /
+    mid_block_additional_residual / replace_skip_conns / zero_out_resconns (int and list) semantics, the forward_upsample_size
+    rule and the returned (sample, h_space, extracted_res_conns) -- is the reference's code running.  Weights are
+    weights.random_state_dict(unet_param_shapes(tiny family), seed) so consumers regenerate them; the fixture holds inputs
+    and outputs only."""
+    UOut = install_stubs()
+    sys.path.insert(0, REF)
+    import models as ref_models
+    import torch.nn.functional as F
+    from audioeditingcode_amd import configs, weights
+    from oracle import unet as ou
+
+    class Block:
+        """One diffusers down / mid / up block as the reference calls it (keyword surface of models.py:303-372, :806-885)."""
+
+        def __init__(self, cfg, sd, kind, i):
+            self.cfg, self.sd, self.kind, self.i = cfg, sd, kind, i
+            boc = cfg["block_out_channels"]
+            nb = len(boc)
+            self.lpb = cfg.get("layers_per_block", 2)
+            self.groups, self.eps = cfg.get("norm_num_groups", 32), cfg.get("norm_eps", 1e-5)
+            heads = ou._per_block(cfg.get("num_attention_heads") or cfg.get("attention_head_dim", 8), nb)
+            ctx_pb, self.multi = ou._ctx_list(cfg)
+            lvl = {"down": i, "mid": nb - 1, "up": nb - 1 - i}[kind]
+            self.heads, self.dims = heads[lvl], ctx_pb[lvl]
+            types = {"down": cfg["down_block_types"], "up": cfg["up_block_types"]}.get(kind)
+            self.has_cross_attention = True if kind == "mid" else "CrossAttn" in types[i]
+            self.prefix = "mid_block" if kind == "mid" else f"{kind}_blocks.{i}"
+            self.last = i == nb - 1
+            self.resnets = [None] * (self.lpb + 1 if kind == "up" else self.lpb)      # the reference reads len(...) only
+            self.linear, self.depth = cfg.get("use_linear_projection", False), cfg.get("transformer_layers_per_block", 1)
+
+        def _site(self, k0, x, ehs, bias, ehs1, bias1):
+            for j, cdim in enumerate(self.dims):
+                if cdim is None:
+                    ctx, b, dbl = None, None, True
+                elif self.multi and j > 1:
+                    ctx, b, dbl = ehs1, bias1, False
+                else:
+                    ctx, b, dbl = ehs, bias, False
+                x = ou.transformer2d(self.sd, f"{self.prefix}.attentions.{k0 + j}", x, ctx, self.heads, self.groups, b, dbl,
+                                     self.linear, self.depth)
+            return x
+
+        def __call__(self, hidden_states=None, temb=None, res_hidden_states_tuple=None, upsample_size=None,
+                     encoder_hidden_states=None, attention_mask=None, cross_attention_kwargs=None,
+                     encoder_attention_mask=None, encoder_hidden_states_1=None, encoder_attention_mask_1=None):
+            assert attention_mask is None and cross_attention_kwargs is None
+            h, sd = hidden_states, self.sd
+            site = lambda k0, x: self._site(k0, x, encoder_hidden_states, encoder_attention_mask,      # noqa: E731
+                                            encoder_hidden_states_1, encoder_attention_mask_1)
+            if self.kind == "mid":
+                h = ou.resnet(sd, "mid_block.resnets.0", h, temb, self.groups, self.eps)
+                h = site(0, h)
+                return ou.resnet(sd, "mid_block.resnets.1", h, temb, self.groups, self.eps)
+            if self.kind == "down":
+                outs = ()
+                for j in range(self.lpb):
+                    h = ou.resnet(sd, f"{self.prefix}.resnets.{j}", h, temb, self.groups, self.eps)
+                    if self.has_cross_attention:
+                        h = site(j * len(self.dims), h)
+                    outs += (h,)
+                if not self.last:
+                    h = ou._conv(sd, f"{self.prefix}.downsamplers.0.conv", h, stride=2, padding=1)
+                    outs += (h,)
+                return h, outs
+            res = tuple(res_hidden_states_tuple)
+            for j in range(self.lpb + 1):
+                h = torch.cat([h, res[-1]], dim=1)
+                res = res[:-1]
+                h = ou.resnet(sd, f"{self.prefix}.resnets.{j}", h, temb, self.groups, self.eps)
+                if self.has_cross_attention:
+                    h = site(j * len(self.dims), h)
+            if not self.last:                  # diffusers Upsample2D: nearest, scale 2 unless an output size is forwarded
+                h = F.interpolate(h, scale_factor=2.0, mode="nearest") if upsample_size is None else \
+                    F.interpolate(h, size=tuple(upsample_size), mode="nearest")
+                h = ou._conv(sd, f"{self.prefix}.upsamplers.0.conv", h)
+            return h
+
+    def stand_in_unet(cfg, sd):
+        boc = cfg["block_out_channels"]
+        nb = len(boc)
+        lin = lambda pfx: (lambda x: ou._lin(sd, pfx, x))                                         # noqa: E731
+        return SimpleNamespace(
+            config=SimpleNamespace(center_input_sample=False, class_embed_type=cfg.get("class_embed_type"),
+                                   class_embeddings_concat=bool(cfg.get("class_embeddings_concat")), addition_embed_type=None,
+                                   encoder_hid_dim_type=None, in_channels=cfg["in_channels"]),
+            num_upsamplers=nb - 1,
+            time_proj=lambda t: ou.timestep_embedding(t, boc[0], cfg.get("flip_sin_to_cos", True), cfg.get("freq_shift", 0)),
+            time_embedding=lambda t_emb, cond=None: ou._lin(sd, "time_embedding.linear_2",
+                                                            F.silu(ou._lin(sd, "time_embedding.linear_1", t_emb))),
+            class_embedding=lin("class_embedding") if cfg.get("class_embed_type") is not None else None,
+            time_embed_act=None, encoder_hid_proj=None, add_embedding=None,
+            conv_in=lambda x: ou._conv(sd, "conv_in", x),
+            down_blocks=[Block(cfg, sd, "down", i) for i in range(nb)], mid_block=Block(cfg, sd, "mid", 0),
+            up_blocks=[Block(cfg, sd, "up", i) for i in range(nb)],
+            conv_norm_out=lambda x: ou._gn(sd, "conv_norm_out", x, cfg.get("norm_num_groups", 32), cfg.get("norm_eps", 1e-5)),
+            conv_act=F.silu, conv_out=lambda x: ou._conv(sd, "conv_out", x))
+
+    rec = {}
+    g = torch.Generator().manual_seed(11)
+    rn = lambda *s: torch.randn(*s, generator=g)                                                  # noqa: E731
+    for fam_name, fn, seed in (("audioldm", ref_models.PipelineWrapper.unet_forward, 21),
+                               ("tango", ref_models.PipelineWrapper.unet_forward, 22),
+                               ("audioldm2", ref_models.AudioLDM2Wrapper.unet_forward, 23)):
+        fam = configs.tiny_family(fam_name)
+        cfg = fam["unet"]
+        sd = weights.random_state_dict(weights.unet_param_shapes(cfg), seed=seed)
+        me = SimpleNamespace(model=SimpleNamespace(unet=stand_in_unet(cfg, sd)))
+        boc = cfg["block_out_channels"]
+        B = 2
+        for size_name, (H, W) in (("even", (16, 8)), ("odd", (20, 6))):       # 20 x 6 is not a multiple of 8: forward_upsample_size
+            x = rn(B, 8, H, W)
+            t = 481
+            if fam_name == "audioldm":
+                cond = dict(encoder_hidden_states=None, class_labels=F.normalize(rn(B, fam["ctx"]["clap_dim"]), dim=-1))
+            elif fam_name == "tango":
+                mask = torch.ones(B, 5, dtype=torch.long)
+                mask[1, 3:] = 0
+                cond = dict(encoder_hidden_states=rn(B, 5, fam["ctx"]["t5_dim"]), encoder_attention_mask=mask)
+            else:
+                mask = torch.ones(B, 6, dtype=torch.long)
+                mask[0, 4:] = 0
+                cond = dict(encoder_hidden_states=rn(B, 8, fam["ctx"]["gpt2_dim"]), class_labels=rn(B, 6, fam["ctx"]["t5_dim"]),
+                            encoder_attention_mask=mask)
+            with torch.no_grad():
+                out, h_space, skips = fn(me, x, t, **cond)
+            key = f"{fam_name}.{size_name}"
+            rec[f"{key}.x"], rec[f"{key}.t"] = x.numpy(), np.int64(t)
+            for k, v in cond.items():
+                if v is not None:
+                    rec[f"{key}.cond.{k}"] = v.numpy()
+            rec[f"{key}.plain.eps"], rec[f"{key}.plain.h_space"] = out.sample.numpy(), h_space.numpy()
+            for i, lst in skips.items():
+                for j, s_ in enumerate(lst):
+                    rec[f"{key}.plain.skip.{i}.{j}"] = s_.numpy()
+            if size_name == "odd":
+                continue
+            # hooks (same inputs): values a caller could pass (pc_drift / the h-space scripts of the reference)
+            hs_new = rn(*h_space.shape) * 0.5
+            add = rn(*h_space.shape) * 0.1
+            rep = {1: [rn(*s_.shape) * 0.3 for s_ in skips[1]]}
+            hooks = dict(replace_h_space=dict(replace_h_space=hs_new), mid_add=dict(mid_block_additional_residual=add),
+                         replace_skips=dict(replace_skip_conns=rep), zero_int=dict(zero_out_resconns=3),
+                         zero_list=dict(zero_out_resconns=[0, 2]),
+                         combined=dict(replace_h_space=hs_new, mid_block_additional_residual=add, zero_out_resconns=[1]))
+            rec[f"{key}.hook.h_space_new"], rec[f"{key}.hook.mid_add"] = hs_new.numpy(), add.numpy()
+            for j, r_ in enumerate(rep[1]):
+                rec[f"{key}.hook.replace.1.{j}"] = r_.numpy()
+            for hname, kw in hooks.items():
+                with torch.no_grad():
+                    o2, h2, s2 = fn(me, x, t, **cond, **kw)
+                rec[f"{key}.{hname}.eps"], rec[f"{key}.{hname}.h_space"] = o2.sample.numpy(), h2.numpy()
+                rec[f"{key}.{hname}.skip_abs_sums"] = np.array([[float(s_.abs().sum()) for s_ in s2[i]] for i in sorted(s2)])
+            print("unet graph", key, tuple(out.sample.shape), "h_space", tuple(h_space.shape),
+                  "skips", {i: len(v) for i, v in skips.items()}, float(out.sample.abs().mean()))
+        rec[f"{fam_name}.seed"] = np.int64(seed)
+    np.savez_compressed(os.path.join(OUT, "unet_forward_graph.npz"), **rec)
+    print("unet_forward_graph.npz keys", len(rec), "bytes", os.path.getsize(os.path.join(OUT, "unet_forward_graph.npz")))
+
+
 def gen_vae():
     _load_twin_pkg()
     va = types.ModuleType("audioldm.variational_autoencoder")
@@ -753,8 +922,8 @@ if __name__ == "__main__":
     # each generator runs in a fresh interpreter when "all" (the stubs of one break another)
     if what == "all":
         import subprocess
-        for w in ("loops", "pc", "pc_cli", "audio", "hifigan", "unet", "vae", "stable_audio", "text"):
+        for w in ("loops", "pc", "pc_cli", "audio", "hifigan", "unet", "unet_graph", "vae", "stable_audio", "text"):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), w])
     else:
-        {"loops": gen_loops, "pc": gen_pc, "pc_cli": gen_pc_cli, "audio": gen_audio, "hifigan": gen_hifigan, "unet": gen_unet, "vae": gen_vae,
+        {"loops": gen_loops, "pc": gen_pc, "pc_cli": gen_pc_cli, "audio": gen_audio, "hifigan": gen_hifigan, "unet": gen_unet, "unet_graph": gen_unet_graph, "vae": gen_vae,
          "stable_audio": gen_stable_audio, "text": gen_text}[what]()

@@ -116,9 +116,10 @@ class _Pipe:
     made = []
 
     def __init__(self, model, plan="partition", edit_cus=None, edit_lanes=1, lanes=None, launch="graph", timestep_group=100,
-                 overlap_prep=True):
+                 overlap_prep=True, edit_group=1, group_wait_s=0.0):
         assert launch in ("eager", "graph") and plan in ("partition", "lanes")
         self.plan, self.total, self.edit_cus, self.edit_lanes = plan, 256, edit_cus, edit_lanes
+        self.edit_group, self.group_sizes = edit_group, [1]
         self.edit_lane_cus, self.codec_stage = edit_cus, False
         if plan == "partition":
             self.workers = [_W("front", _Model([2 * timestep_group]))] + [_W("back", _Model([2])) for _ in range(edit_lanes)]

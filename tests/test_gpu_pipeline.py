@@ -149,6 +149,60 @@ def test_partition_pipeline_full_size_audioldm2_bit_identical_and_finite():
     pipe.close()
 
 
+def test_group_plan_steps_several_clips_in_lockstep_tiny():
+    """Group plan (round 5): the back stage steps the edit loops of up to `edit_group` clips in lockstep (U-Net batch 2g), on
+    ONE 96-CU lane, greedy and with a forced full group; every clip agrees with the clip edited alone to fp32 rounding; the
+    codec stage sees every clip once; the drain moves the running group loop to the unmasked queue."""
+    T, tstart, G = 10, 6, 5
+    m = models.load_model("tiny/audioldm2", DEV, T, seed=0)
+    wavs = [synthetic_clip(seconds=1.25, seed=7 + i) for i in range(6)]
+    to_mel = lambda view, wav: load_audio((wav, 16000), view.get_fn_STFT(), device=DEV, stft=True)[0]     # noqa: E731
+    mels = [to_mel(m, w) for w in wavs]
+    seeds = [40 + i for i in range(6)]
+    ref = _serial_b(m, mels, T, tstart, seeds, G)
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())                        # noqa: E731
+    for wait_s, expect in ((60.0, [4, 2]), (0.0, None)):
+        pipe = ClipPipeline(m, plan="partition", edit_cus=96, edit_group=4, timestep_group=G, group_wait_s=wait_s)
+        assert [w.stage for w in pipe.workers] == ["front", "back", "codec"] and pipe.group_sizes == [1, 2, 4]
+        pipe.warm_up(wavs[0], *ARGS, T, tstart, prepare=to_mel)
+        got = pipe.edit_clips(wavs, *ARGS, T, tstart, seeds=seeds, prepare=to_mel)
+        rep = pipe.report()
+        assert sum(rep["groups_formed"]) == 6 and set(rep["groups_formed"]) <= {1, 2, 4}, rep["groups_formed"]
+        if expect is not None:
+            assert rep["groups_formed"] == expect
+        assert rep["device_ms"]["codec_lane"]["n"] == 6
+        for i, ((a, o, w), (a2, o2, w2)) in enumerate(zip(got, ref)):
+            assert torch.isfinite(w).all() and rel(w, w2) < 2e-5 and rel(a, a2) < 2e-4, (i, rel(w, w2), rel(a, a2))
+            assert torch.equal(o, o2), i
+        pipe.close()
+
+
+def test_group_plan_full_size_audioldm2_groups_of_four_vs_alone():
+    """BASELINE config 2's model at a short schedule: 4 clips whose edit loops run as ONE U-Net batch of 8 on a 96-CU lane
+    (inversion on the other 160 CUs) against the same clips one per call through the same pipeline (groups of 1) and against
+    plain main_run.edit_clip: fp32 rounding only (other tiles / summation orders per batch shape)."""
+    T, tstart, G = 8, 4, 4
+    m = models.load_model("cvssp/audioldm2", DEV, T, allow_synthetic=True)
+    mels = [load_audio((synthetic_clip(seconds=10.0, seed=3 + i), 16000), m.get_fn_STFT(), device=DEV, stft=True)[0]
+            for i in range(4)]
+    seeds = [7, 8, 9, 10]
+    ref = _serial_b(m, mels, T, tstart, seeds, G)
+    pipe = ClipPipeline(m, plan="partition", edit_cus=96, edit_group=4, group_sizes=[1, 4], timestep_group=G, group_wait_s=120.0)
+    pipe.warm_up(mels[0], *ARGS, T, tstart)
+    got = pipe.edit_clips(mels, *ARGS, T, tstart, seeds=seeds)
+    assert pipe.report()["groups_formed"] == [4]
+    alone = [pipe.edit_clips([x0], *ARGS, T, tstart, seeds=[s])[0] for x0, s in zip(mels, seeds)]
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())                        # noqa: E731
+    for i, ((a, o, w), (a1, o1, w1), (a2, o2, w2)) in enumerate(zip(got, alone, ref)):
+        assert torch.isfinite(w).all() and torch.isfinite(a).all()
+        assert rel(w, w1) < 5e-5 and rel(a, a1) < 5e-4, (i, rel(w, w1), rel(a, a1))
+        assert rel(w, w2) < 5e-3, (i, rel(w, w2))
+        assert torch.equal(o, o1) and torch.equal(o, o2), i
+    ed = pipe.workers[1].view.editor(256, 16)
+    assert sorted(eng.B for eng in ed._unets.values()) == [2, 8]           # the lockstep engine is a batch-8 U-Net
+    pipe.close()
+
+
 def test_cu_masked_streams_census_and_results():
     """aed_stream_create_cu_mask: a contiguous range of 8k mask bits is k CUs on each of the 8 XCDs (aed_cu_census reads
     the hardware's XCC / SE / CU ids); a hipGraph replayed on a masked stream gives the same values as on a plain one."""

@@ -194,3 +194,90 @@ def test_arith_mode_flags_attention_records_and_the_launcher_takes_the_split_ker
         torch.cuda.synchronize()
         outs.append(out.cpu())
     assert torch.equal(outs[0], outs[1])
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Adversarial operand statistics: every parity test above draws Gaussians.  The six-term split drops the
+# piece products a_mid.b_lo, a_lo.b_mid, a_lo.b_lo (<= 2^-23 |a||b| each): the claim "as close to fp64 as the fp32 MFMA chain"
+# must also hold for heavy tails, operands spread over 40 binades, catastrophic cancellation (post-GroupNorm rows with a large
+# common mode against zero-sum weight rows) and peaked softmax rows.  Error measures: relative L2 and the componentwise
+# backward-style error max |err| / sum_k |a_k||b_k| (what a dot-product error bound is stated in).
+def _adversarial_operands(stat, M, K, N, g):
+    if stat == "heavy_tailed":                      # Student-t, 2 degrees of freedom (infinite variance), clipped at +-1e4
+        t = lambda *s: (torch.randn(*s, generator=g) / (torch.randn(*s, generator=g) ** 2 / 2 + torch.randn(*s, generator=g) ** 2 / 2).sqrt()).clamp(-1e4, 1e4)   # noqa: E731
+        return t(M, K), t(N, K) / K ** 0.5
+    if stat == "exponent_spread":                   # every element its own binade in 2^[-20, 20]
+        e = lambda *s: torch.randn(*s, generator=g) * torch.exp2(torch.randint(-20, 21, s, generator=g).float())   # noqa: E731
+        return e(M, K), e(N, K)
+    if stat == "cancellation":                      # rows = common mode 1000 + unit noise; zero-sum weight rows
+        x = 1000.0 + torch.randn(M, K, generator=g)
+        w = torch.randn(N, K, generator=g)
+        return x, (w - w.mean(1, keepdim=True)) / K ** 0.5
+    if stat == "bf16_floor":                        # activations 2^-16 above the bf16 NORMAL floor: the lowest piece of a value is a
+        return torch.randn(M, K, generator=g) * 2.0 ** -110, torch.randn(N, K, generator=g) * 2.0 ** 20   # bf16 denormal
+    raise KeyError(stat)
+
+
+@pytest.mark.parametrize("stat", ["heavy_tailed", "exponent_spread", "cancellation", "bf16_floor"])
+def test_split_bf16_gemm_under_adversarial_operand_statistics(stat):
+    M, K, N = 2048, 640, 256
+    g = torch.Generator().manual_seed(17)
+    x, w = _adversarial_operands(stat, M, K, N, g)
+    ref = x.double() @ w.double().T
+    mag = x.double().abs() @ w.double().abs().T                                     # sum_k |a_k||b_k| per output
+    outs = {}
+    for arith in ("f32", "bf16x6"):
+        tp = Tape(DEV)
+        xd, wd = tp.hold(x.to(DEV)), tp.hold(w.contiguous().to(DEV))
+        out = tp.alloc(M, N)
+        with tape_mod.arith_mode(arith):
+            tp.linear(xd, wd, None, out, M=M, K=K, N=N, tile=1)
+        assert bool(tp.ops[0].flags & 4) == (arith == "bf16x6")
+        tp.run()
+        torch.cuda.synchronize()
+        outs[arith] = out.cpu().double()
+    rel = lambda a: float((a - ref).norm() / ref.norm())                             # noqa: E731
+    back = lambda a: float(((a - ref).abs() / mag.clamp_min(1e-300)).max())          # noqa: E731
+    e32, e6, b32, b6 = rel(outs["f32"]), rel(outs["bf16x6"]), back(outs["f32"]), back(outs["bf16x6"])
+    print(f"\n[x6 adversarial] {stat}: rel L2 vs fp64 fp32-kernel {e32:.2e} / split-bf16 {e6:.2e}; "
+          f"max |err| / sum|a||b| fp32-kernel {b32:.2e} / split-bf16 {b6:.2e}")
+    assert torch.isfinite(outs["bf16x6"]).all()
+    if stat == "bf16_floor":
+        # Documented limit: below ~2^-110 the third piece of a value leaves bf16's normal range (the format
+        # keeps fp32's exponent, so this is 2^-16 above the floor of fp32 itself); the result then carries ~2^-17 relative
+        # instead of 2^-24.  No tensor of the path lives there (activations are O(1e-3 .. 1e3)); the bound asserted is that limit.
+        assert b6 < 2.0 ** -14, b6
+        return
+    # same bound as the fp32 kernel: K fp32 accumulations of exact products (unit roundoff 2^-24, statistical growth)
+    assert b32 < 64 * 2.0 ** -24 and b6 < 64 * 2.0 ** -24, (b32, b6)
+    assert b6 < 2.0 * b32 + 2.0 ** -24, (b6, b32)
+    assert e6 < 2.0 * e32 + 1e-7, (e6, e32)
+
+
+def test_split_bf16_attention_with_peaked_softmax_rows():
+    """q and k scaled x8: score standard deviation ~64, every softmax row is one-hot to fp32 precision and the exponent
+    argument's ABSOLUTE error is what reaches the output -- the regime trained attention layers approach and Gaussian
+    operands never do.  The split-bf16 kernel must stay within a small factor of the fp32 kernel against fp64."""
+    B, H, N, D = 3, 8, 1024, 32
+    C = H * D
+    g = torch.Generator().manual_seed(29)
+    q, k, v = (torch.randn(B, N, C, generator=g) for _ in range(3))
+    q, k = 8.0 * q, 8.0 * k
+    qh, kh, vh = (t.reshape(B, N, H, D).transpose(1, 2).double() for t in (q, k, v))
+    p = torch.softmax(qh @ kh.transpose(-1, -2) * D ** -0.5, -1)
+    assert float(p.max(-1).values.median()) > 0.99                                     # the rows ARE peaked
+    ref = (p @ vh).transpose(1, 2).reshape(B, N, C)
+    outs = {}
+    for variant in (0, 3):
+        tp = Tape(DEV)
+        out = tp.alloc(B, N, C)
+        tp.attention(q.to(DEV), k.to(DEV), v.to(DEV), out, B=B, H=H, Nq=N, Nk=N, D=D, ldq=C, ldk=C, ldv=C, ldo=C, bsq=N * C,
+                     bsk=N * C, bsv=N * C, bso=N * C, scale=D ** -0.5, variant=variant)
+        tp.run()
+        torch.cuda.synchronize()
+        outs[variant] = out.cpu().double()
+    rel = lambda a: float((a - ref).norm() / ref.norm())                               # noqa: E731
+    e32, e6 = rel(outs[0]), rel(outs[3])
+    print(f"\n[attention x6, peaked softmax] rel L2 vs fp64: fp32 kernel {e32:.2e}, split-bf16 {e6:.2e}")
+    assert torch.isfinite(outs[3]).all()
+    assert e6 < 3 * e32 + 1e-6 and e6 < 1e-3, (e6, e32)

@@ -294,3 +294,27 @@ def test_oracle_reproduces_the_reference_main_run_script():
     np.testing.assert_allclose(wT.numpy(), g["c_wT"], **tol)
     we = oloops.ddim_sample(w, wT, _cond(["a cat meowing"]), _cond([""]), 12.0, skip=3)
     np.testing.assert_allclose(we.numpy(), g["c_w_edit"], **tol)
+
+
+def test_oracle_unet_matches_the_references_inline_forward_graphs():
+    """SURVEY A8, graph level: oracle/unet.py's forward against the reference's OWN `PipelineWrapper.unet_forward`
+    (models.py:160-393) and `AudioLDM2Wrapper.unet_forward` (:691-899) executed on stand-in diffusers blocks
+    (oracle/make_golden.py unet_graph): plain, replace_h_space, mid_block_additional_residual, replace_skip_conns,
+    zero_out_resconns (int and list), and a size that forces forward_upsample_size -- eps, h_space and every extracted
+    residual, for the three families."""
+    import unet_graph_cases as ugc
+    g = ugc.load()
+    rel = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-12))                # noqa: E731
+    n = 0
+    for fam in ugc.FAMILIES:
+        f, sd = ugc.family(g, fam)
+        for fam_, size, hook in ugc.cases():
+            if fam_ != fam:
+                continue
+            x, t, cond = ugc.inputs(g, fam, size)
+            with torch.no_grad():
+                got = ounet.unet_forward(f["unet"], sd, x, torch.tensor(t), **ugc.oracle_kwargs(fam, cond),
+                                         **ugc.hook_kwargs(g, fam, hook))
+            ugc.check(fam, size, hook, got, ugc.expected(g, fam, size, hook), 2e-6, rel)
+            n += 1
+    assert n == 24

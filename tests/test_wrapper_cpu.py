@@ -91,6 +91,23 @@ def test_unet_forward_hooks_on_cpu(cpu_stack):
     assert rel(out2.sample, ref) > 1e-2                                    # the hooks did change the output
 
 
+def test_product_unet_forward_matches_the_references_inline_graphs_on_cpu(cpu_stack):
+    """The product's `unet_forward` (three wrappers, hook arguments included) on the CPU tape interpreter against the fixture
+    written by the reference's own inline forward graphs (tests/unet_graph_cases.py; models.py:160-393, :691-899)."""
+    import unet_graph_cases as ugc
+    g = ugc.load()
+    classes = {"audioldm": _CpuAudioLDM, "tango": _CpuTango, "audioldm2": _CpuAudioLDM2}
+    for fam in ugc.FAMILIES:
+        m = classes[fam](model_id=f"tiny/{fam}", device="cpu", seed=int(g[f"{fam}.seed"]))
+        for fam_, size, hook in ugc.cases():
+            if fam_ != fam:
+                continue
+            x, t, cond = ugc.inputs(g, fam, size)
+            out, h, skips = m.unet_forward(x, torch.tensor(t), **cond, **ugc.hook_kwargs(g, fam, hook))
+            skips = {i: [s.clone() for s in skips[i]] for i in range(4)}
+            ugc.check(fam, size, hook, (out.sample, h, skips), ugc.expected(g, fam, size, hook), 1e-4, rel)
+
+
 def test_pc_functions_on_the_real_wrapper_on_cpu(cpu_stack):
     """forward_directional / get_eigenvectors through the wrapper's own `unet_forward_pair` (one 2*n_ev batch)."""
     T = 6
@@ -449,6 +466,56 @@ def test_clip_pipeline_plans_equal_serial_edit_clip(cpu_stack, monkeypatch):
             assert torch.equal(a, a2) and torch.equal(w, w2)
         assert torch.equal(torch.randn(2), after)           # and the generator ends where the serial loop leaves it
         assert "sample_xts_from_x0" not in lanes.workers[0].view.__dict__      # the gated draw hook is removed again
+    finally:
+        torch.set_num_threads(threads)
+
+
+def test_clip_pipeline_group_plan_on_cpu(cpu_stack, monkeypatch):
+    """Group plan (round 5): the back stage steps the edit loops of several clips in LOCKSTEP (U-Net batch 2g) -- every clip
+    equals the clip edited alone to fp32 rounding (its rows of the batch are its own arithmetic; the batch shape only changes
+    tile / summation choices), groups are formed from the engine sizes that exist, every clip reaches the codec stage once."""
+    log = []
+    ClipPipeline = _fake_hip_for_pipeline(monkeypatch, log)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(2)
+    try:
+        T, tstart = 3, 2
+        m = _model(T)
+        mels = [load_audio((synthetic_clip(seconds=0.32, seed=7 + i), 16000), m.get_fn_STFT(), device="cpu", stft=True)[0]
+                for i in range(5)]
+        args = (["a dog barking"], ["a cat meowing"], [""], [3.0], [12.0], T, tstart)
+        serial = []
+        for i, x0 in enumerate(mels):
+            torch.manual_seed(40 + i)
+            serial.append(edit_clip(m, x0, *args, schedule="batched", timestep_group=3))
+        with pytest.raises(ValueError):
+            ClipPipeline(m, plan="lanes", edit_group=2)
+        with pytest.raises(ValueError):
+            ClipPipeline(m, plan="partition", edit_cus=96, edit_group=2, codec_stage=False, timestep_group=3)
+        # a free lane waits (here: as long as it takes) for a full group of 2; the fifth clip goes alone
+        pipe = ClipPipeline(m, plan="partition", edit_cus=96, edit_group=2, timestep_group=3, group_wait_s=60.0)
+        assert [w.stage for w in pipe.workers] == ["front", "back", "codec"] and pipe.codec_stage and pipe.group_sizes == [1, 2]
+        assert pipe.workers[1].wide is pipe.workers[1].full          # drain: the group loop moves to the lane's unmasked queue
+        assert ClipPipeline(m, plan="partition", edit_cus=96, edit_group=8, timestep_group=3).group_sizes == [1, 2, 4, 8]
+        assert ClipPipeline(m, plan="partition", edit_cus=96, edit_group=6, group_sizes=[3, 6, 9], timestep_group=3).group_sizes \
+            == [1, 3, 6]
+        pipe.warm_up(mels[0], *args)
+        assert all(w.warm for w in pipe.workers)
+        ed = pipe.workers[1].view.editor(mels[0].shape[-2] // 4, mels[0].shape[-1] // 4)
+        assert sorted(k[1] for k in ed._plans if k[0] == "edit") == [1, 2]          # one loop plan per group size
+        got = pipe.edit_clips(mels, *args, seeds=[40 + i for i in range(5)])
+        rep = pipe.report()
+        assert rep["groups_formed"] == [2, 2, 1] and rep["edit_group"] == 2
+        for i, ((a, o, w), (a2, o2, w2)) in enumerate(zip(got, serial)):
+            assert rel(w, w2) < 2e-5 and rel(a, a2) < 2e-4, (i, rel(w, w2), rel(a, a2))
+            assert torch.equal(o, o2)                                # the original's vocoding does not pass the edit loop
+        # greedy (no wait): whatever is ready goes; every clip is edited exactly once whatever the grouping was
+        greedy = ClipPipeline(m, plan="partition", edit_cus=96, edit_group=4, timestep_group=3)
+        greedy.warm_up(mels[0], *args)
+        got = greedy.edit_clips(mels, *args, seeds=[40 + i for i in range(5)])
+        assert sum(greedy.report()["groups_formed"]) == 5 and set(greedy.report()["groups_formed"]) <= {1, 2, 4}
+        for (a, o, w), (a2, o2, w2) in zip(got, serial):
+            assert rel(w, w2) < 2e-5
     finally:
         torch.set_num_threads(threads)
 

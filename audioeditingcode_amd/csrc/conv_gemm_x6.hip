@@ -41,8 +41,13 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 int launch_conv_gemm_x6(const aed_op* op, hipStream_t s);
 
-constexpr int X6_BK = 16;           // fp32 k per chunk
-constexpr int X6_ROWQ = 7;          // uint4 (16 B) per LDS row: 3 pieces x 2 + 1 pad
+constexpr int X6_BK = 16;           // fp32 k per chunk of the original form (one bf16 MFMA k-block per barrier)
+// Round 5: BK = 32 ("wide chunks", op flag bit 8) -- two k-blocks per LDS stage and barrier.  After a barrier a wave must read its
+// fragments from LDS before its first MFMA can issue (~150-250 cycles in which BOTH waves of a SIMD of a 512-thread workgroup
+// idle the matrix pipe, visible in the ISA as ds_read x 12 -> s_waitcnt -> v_mfma); 48 instead of 24 MFMAs per wave between
+// barriers halve that bubble's share.  LDS row = [hi BK k | mid BK k | lo BK k | 16 B pad]: 112 B at BK 16, 208 B at BK 32 (52
+// dwords: the 16 rows of a ds_read_b128 lane group still land on 16 distinct 4-bank windows); two stages of the 256x128 /
+// 128x256 tiles are 159 744 B of the CU's 163 840.
 
 // (x0, x1) -> packed bf16 pieces {hi, mid, lo}; x == hi + mid + lo exactly (element 0 in the low half).  Scalar subtractions:
 // v_pk_add_f32 issues badly next to MFMAs (MI355X_MICROARCH.md, filler prices; measured -10 %)
@@ -76,15 +81,19 @@ __device__ __forceinline__ void x6_hints() {
 // SCHED: 0 = leave the instruction order to the compiler; 1 = VALU-between-MFMA interleave hints in the main loop (x6_hints)
 // NTERMS: 6 = the product arithmetic; 3 = only the terms of relative size >= 2^-8 (DIAGNOSTIC: tells how much of the kernel time
 // is matrix-pipe time; ~4e-6 rel error, never used by a product path)
-template <int BM, int BN, int WROWS, int WCOLS, int DEPTH, bool PLAIN, int SCHED, int NTERMS>
+template <int BM, int BN, int WROWS, int WCOLS, int DEPTH, bool PLAIN, int SCHED, int NTERMS, int BK = X6_BK>
 __global__ __launch_bounds__(64 * WROWS * WCOLS, 2) void conv_gemm_x6_kernel(CGParams p) {
     constexpr int NT = 64 * WROWS * WCOLS;
     constexpr int WM = BM / WROWS, WN = BN / WCOLS;
     constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int TPR = X6_BK / 4;          // loader threads per row (float4 each)
+    constexpr int TPR = BK / 4;             // loader threads per row (float4 each)
     constexpr int RPP = NT / TPR;           // rows per loader pass
     constexpr int PA = BM / RPP, PB = BN / RPP;
+    constexpr int PQ = BK / 8;              // uint4 per piece of a row (8 bf16 each)
+    constexpr int X6_ROWQ = 3 * PQ + 1;     // uint4 (16 B) per LDS row: 3 pieces + 1 pad
+    constexpr int KB = BK / 16;             // bf16 MFMA k-blocks per chunk
     constexpr int STAGE = (BM + BN) * X6_ROWQ;      // uint4 per operand stage (A rows then W rows)
+    static_assert(BK == 16 || BK == 32, "chunk width");
     static_assert(TM >= 1 && TN >= 1 && PA >= 1 && PB >= 1, "tile");
     static_assert(BM % RPP == 0 && BN % RPP == 0, "loader passes");
 
@@ -147,7 +156,7 @@ __global__ __launch_bounds__(64 * WROWS * WCOLS, 2) void conv_gemm_x6_kernel(CGP
     // running (tap, channel) position of the next chunk to prefetch: prefetch() is called with consecutive kc
     // [group of p.kgroup channels][tap][chunk within the group] (cg_params.h): pf_cg = first channel of the group
     int pf_cg, pf_sub, pf_ty, pf_tx;
-    const int gq = p.kgroup / X6_BK;          // chunks per (group, tap)
+    const int gq = p.kgroup / BK;             // chunks per (group, tap)
     {
         const int per_group = p.KH * p.KW * gq;
         const int g = kc_begin / per_group;
@@ -174,7 +183,7 @@ __global__ __launch_bounds__(64 * WROWS * WCOLS, 2) void conv_gemm_x6_kernel(CGP
         return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
     };
     auto prefetch = [&](int kc, float4 (&ra)[PA], float4 (&rb)[PB]) {
-        int c0 = pf_cg + pf_sub * X6_BK;
+        int c0 = pf_cg + pf_sub * BK;
         const int dy = pf_ty * p.dil_h, dx = pf_tx * p.dil_w;
         const unsigned k0 = (unsigned)((pf_ty * p.KW + pf_tx) * p.Cin + c0);     // W column of this chunk
         pf_sub += 1;
@@ -211,10 +220,10 @@ __global__ __launch_bounds__(64 * WROWS * WCOLS, 2) void conv_gemm_x6_kernel(CGP
         unsigned h0, m0_, l0, h1, m1, l1;
         x6_split_pair(v.x, v.y, h0, m0_, l0);
         x6_split_pair(v.z, v.w, h1, m1, l1);
-        uint2* dst = reinterpret_cast<uint2*>(st + row * X6_ROWQ) + lq;      // piece pl starts at uint2 index 4 * pl
+        uint2* dst = reinterpret_cast<uint2*>(st + row * X6_ROWQ) + lq;      // piece pl starts at uint2 index 2 * PQ * pl
         dst[0] = make_uint2(h0, h1);
-        dst[4] = make_uint2(m0_, m1);
-        dst[8] = make_uint2(l0, l1);
+        dst[2 * PQ] = make_uint2(m0_, m1);
+        dst[4 * PQ] = make_uint2(l0, l1);
     };
 
     auto stage_write = [&](uint4* st, const float4 (&ra)[PA], const float4 (&rb)[PB]) {
@@ -248,22 +257,23 @@ __global__ __launch_bounds__(64 * WROWS * WCOLS, 2) void conv_gemm_x6_kernel(CGP
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     const int fi = lane & 31;        // fragment row (A: m, W: n)
-    const int fh = lane >> 5;        // which 8 of the 16 k
+    const int fh = lane >> 5;        // which 8 of a k-block's 16 k
     const int a_frag = (wr * WM + fi) * X6_ROWQ + fh;
     const int b_frag = (BM + wc * WN + fi) * X6_ROWQ + fh;
 
     bf16x8 af[TM][3], bw[TN][3];
-    auto load_frags = [&](const uint4* st, bf16x8 (&fa)[TM][3], bf16x8 (&fb)[TN][3]) {
+    // fragments of k-block kb of the staged chunk: piece pl of a row starts at uint4 PQ * pl, its k-block kb at + 2 * kb
+    auto load_frags = [&](const uint4* st, int kb, bf16x8 (&fa)[TM][3], bf16x8 (&fb)[TN][3]) {
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl)
-                fa[a][pl] = __builtin_bit_cast(bf16x8, st[a_frag + a * 32 * X6_ROWQ + 2 * pl]);
+                fa[a][pl] = __builtin_bit_cast(bf16x8, st[a_frag + a * 32 * X6_ROWQ + PQ * pl + 2 * kb]);
 #pragma unroll
         for (int b = 0; b < TN; ++b)
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl)
-                fb[b][pl] = __builtin_bit_cast(bf16x8, st[b_frag + b * 32 * X6_ROWQ + 2 * pl]);
+                fb[b][pl] = __builtin_bit_cast(bf16x8, st[b_frag + b * 32 * X6_ROWQ + PQ * pl + 2 * kb]);
     };
     // the six piece products with i + j <= 2, smallest first
     auto do_mfmas = [&](const bf16x8 (&fa)[TM][3], const bf16x8 (&fb)[TN][3]) {
@@ -282,7 +292,7 @@ __global__ __launch_bounds__(64 * WROWS * WCOLS, 2) void conv_gemm_x6_kernel(CGP
             // a wave hides ~5 single-issue instructions per 32-cycle MFMA: spread the split of the chunk being staged (5.5 VALU
             // per element + addresses) between the MFMAs.  VALU groups only: asking for LDS-write / load groups as well makes
             // the solver give up and emit all VALU first.
-            constexpr int NM = TM * TN * NTERMS;
+            constexpr int NM = TM * TN * NTERMS * KB;
             x6_hints<0, NM, NM * (((PA + PB) * 22 + 40 + NM - 1) / NM)>();
         }
     };
@@ -301,10 +311,15 @@ __global__ __launch_bounds__(64 * WROWS * WCOLS, 2) void conv_gemm_x6_kernel(CGP
         for (int d = 0; d < DEPTH; ++d) {
             const int kc = kc0 + d;
             const int sl = (d + 1) % DEPTH;     // chunk kc+1 sits in this register slot
-            load_frags(lds + cur * STAGE, af, bw);
+            load_frags(lds + cur * STAGE, 0, af, bw);
             stage_write(lds + (cur ^ 1) * STAGE, rbuf_a[sl], rbuf_b[sl]);
             prefetch(kc + 1 + DEPTH, rbuf_a[sl], rbuf_b[sl]);
             do_mfmas(af, bw);
+            if constexpr (KB == 2) {            // second k-block of the wide chunk: fragments read under the first block's MFMAs
+                bf16x8 af2[TM][3], bw2[TN][3];
+                load_frags(lds + cur * STAGE, 1, af2, bw2);
+                do_mfmas(af2, bw2);
+            }
             hints();
             __syncthreads();
             cur ^= 1;
@@ -453,11 +468,11 @@ __global__ __launch_bounds__(64 * WROWS * WCOLS, 2) void conv_gemm_x6_kernel(CGP
         }
 }
 
-template <int BM, int BN, int WR, int WC, int DEPTH, bool DIAG>
+template <int BM, int BN, int WR, int WC, int DEPTH, bool DIAG, int BK = X6_BK>
 static int x6_launch(const CGParams& p, bool plain, int sched, int terms, hipStream_t s) {
     dim3 grid(aed_cdiv(p.N, BN), aed_cdiv(p.M, BM), p.ksplit);
     dim3 block(64 * WR * WC);
-#define X6_GO(PL, SC, NT_) hipLaunchKernelGGL((conv_gemm_x6_kernel<BM, BN, WR, WC, DEPTH, PL, SC, NT_>), grid, block, 0, s, p)
+#define X6_GO(PL, SC, NT_) hipLaunchKernelGGL((conv_gemm_x6_kernel<BM, BN, WR, WC, DEPTH, PL, SC, NT_, BK>), grid, block, 0, s, p)
     if (terms == 3) {
         if constexpr (DIAG) {
             if (plain) { X6_GO(true, 1, 3); return 0; }
@@ -497,8 +512,10 @@ int launch_conv_gemm_x6(const aed_op* op, hipStream_t s) {
         }
         return launch_conv_gemm(op, s);
     }
+    // flag bit 8 (256): wide chunks (BK = 32) on the 512-thread tiles 8 / 9, where two stages fill the CU's LDS; needs 32 | Cin
+    const bool wide = (op->flags & 256) && (cfg == 8 || cfg == 9) && Cin % 32 == 0;
     CGParams p;
-    int rc = cg_fill_params(op, p, X6_BK);
+    int rc = cg_fill_params(op, p, wide ? 32 : X6_BK);
     if (rc) return rc;
     if (p.ksplit > (p.K + 31) / 32) p.ksplit = (p.K + 31) / 32;     // launch_splitk_reduce clamps with 32-wide chunks
     if (cfg == 0) {
@@ -519,8 +536,10 @@ int launch_conv_gemm_x6(const aed_op* op, hipStream_t s) {
         case 2: rc = x6_launch<128, 64, 2, 2, 2, false>(p, plain, sched, terms, s); break;
         case 3: rc = x6_launch<64, 128, 2, 2, 2, false>(p, plain, sched, terms, s); break;
         case 4: rc = x6_launch<64, 64, 2, 2, 2, false>(p, plain, sched, terms, s); break;
-        case 8: rc = x6_launch<256, 128, 4, 2, 2, true>(p, plain, sched, terms, s); break;
-        case 9: rc = x6_launch<128, 256, 2, 4, 2, false>(p, plain, sched, terms, s); break;
+        case 8: rc = wide && terms == 6 ? x6_launch<256, 128, 4, 2, 2, false, 32>(p, plain, sched, terms, s)
+                                        : x6_launch<256, 128, 4, 2, 2, true>(p, plain, sched, terms, s); break;
+        case 9: rc = wide && terms == 6 ? x6_launch<128, 256, 2, 4, 2, false, 32>(p, plain, sched, terms, s)
+                                        : x6_launch<128, 256, 2, 4, 2, false>(p, plain, sched, terms, s); break;
         default: AED_REQUIRE(false, "conv_gemm_x6: bad tile cfg %d", cfg);
     }
     if (rc) return rc;

@@ -328,13 +328,64 @@ __global__ __launch_bounds__(256) void gn_small_reg_kernel(const float* __restri
         *reinterpret_cast<float4*>(yb + (size_t)rowv[u] * ldy + 4 * jv[u]) = w;
     }
 }
+// Any channel count per group (TANGO at full size: 320 / 32 = 10 and, after the up-block concat, 960 / 32 = 30 channels per
+// group -- not float4 granules; every kernel above loads float4 slices of a group).  One block per (group, batch item), scalar
+// loads with a per-element source select, the same fp64 reduction of fp32 partial sums and the same affine / SiLU expression
+// as gn_small_kernel.  Correctness path: the widths of the benchmark families never reach it.
+__global__ __launch_bounds__(256) void gn_generic_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ y, int HW,
+                                                           int C, int G, int ldx, int ldy, float eps, int act,
+                                                           const float* __restrict__ x2, int C1, int ldx2) {
+    __shared__ double rs[4], rss[4];
+    const int tid = threadIdx.x, g = blockIdx.x, b = blockIdx.y;
+    const int cpg = C / G;
+    const size_t rb = (size_t)b * HW;
+    const int total = HW * cpg;
+    auto src = [&](int e) -> const float* {
+        const int row = e / cpg, c = g * cpg + (e - row * cpg);
+        return (x2 != nullptr && c >= C1) ? x2 + (rb + row) * ldx2 + (c - C1) : x + (rb + row) * ldx + c;
+    };
+    float s = 0.f, ss = 0.f;
+    for (int e = tid; e < total; e += 256) {
+        const float v = *src(e);
+        s += v;
+        ss += v * v;
+    }
+    double ds = (double)s, dss = (double)ss;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { ds += __shfl_xor(ds, o, 64); dss += __shfl_xor(dss, o, 64); }
+    if ((tid & 63) == 0) { rs[tid >> 6] = ds; rss[tid >> 6] = dss; }
+    __syncthreads();
+    ds = (rs[0] + rs[1]) + (rs[2] + rs[3]);
+    dss = (rss[0] + rss[1]) + (rss[2] + rss[3]);
+    const double n = (double)HW * (double)cpg;
+    const double mean = ds / n;
+    double var = dss / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps)), mu = (float)mean;
+    for (int e = tid; e < total; e += 256) {
+        const int row = e / cpg, c = g * cpg + (e - row * cpg);
+        float w = (*src(e) - mu) * rstd * gamma[c] + beta[c];
+        if (act == AED_ACT_SILU) w = w / (1.0f + expf(-w));
+        y[(rb + row) * ldy + c] = w;
+    }
+}
+
 // slots: p0=x p1=gamma p2=beta p3=y p4=x2(or null) ; i0=B i1=HW i2=C i3=G i4=ldx i5=ldy i6=act i7=1: never register-resident (A/B)
 //        i8=C1 i9=ldx2 (two-source rows, see gn_src) ; f0=eps
 int launch_gn_small(const aed_op* op, hipStream_t s) {
     const int32_t* i = op->i;
     AED_REQUIRE(op->p[0] && op->p[1] && op->p[2] && op->p[3], "gn_small: null pointer");
-    AED_REQUIRE(i[2] % (4 * i[3]) == 0 && i[4] % 4 == 0 && i[5] % 4 == 0, "gn_small: C=%d G=%d", i[2], i[3]);
-    AED_REQUIRE(!op->p[4] || (i[8] > 0 && i[8] < i[2] && i[8] % 4 == 0 && i[9] % 4 == 0), "gn_small: bad two-source split");
+    AED_REQUIRE(i[3] > 0 && i[2] % i[3] == 0, "gn_small: C=%d G=%d", i[2], i[3]);
+    AED_REQUIRE(!op->p[4] || (i[8] > 0 && i[8] < i[2]), "gn_small: bad two-source split");
+    if (i[2] % (4 * i[3]) != 0 || i[4] % 4 != 0 || i[5] % 4 != 0 || (op->p[4] && (i[8] % 4 != 0 || i[9] % 4 != 0))) {
+        // channels per group (or a row stride) that is not a float4 granule: the scalar kernel
+        hipLaunchKernelGGL(gn_generic_kernel, dim3(i[3], i[0]), dim3(256), 0, s, (const float*)op->p[0], (const float*)op->p[1],
+                           (const float*)op->p[2], (float*)op->p[3], i[1], i[2], i[3], i[4], i[5], op->f[0], i[6],
+                           (const float*)op->p[4], i[8], i[9]);
+        AED_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
     const int total4 = i[1] * (i[2] / i[3] / 4);        // float4 per (group, batch item) slice
 #define GN_ARGS (const float*)op->p[0], (const float*)op->p[1], (const float*)op->p[2], (float*)op->p[3], i[1], i[2], i[3], \
                 i[4], i[5], op->f[0], i[6], (const float*)op->p[4], i[8], i[9]

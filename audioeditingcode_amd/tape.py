@@ -356,7 +356,9 @@ class Tape:
         # (< 32 B contiguous at >= 2048 rows: every 128-byte line is fetched for 16 useful bytes and the 64 blocks crawl;
         # measured 25-48 us at the U-Net's level 0 against ~2 x 5 us for the coalesced stats + apply pair)
         sliver = (C // G) < 8 and HW >= 2048 and not GN_FORCE_SMALL
-        if HW * (C // G) <= 65536 and B * G >= 32 and B * HW * C <= (1 << 22) and not sliver:
+        # channels per group that are not a float4 granule (TANGO at full size: 10 and 30): the single-launch op's scalar kernel
+        odd = (C // G) % 4 != 0 or ldx % 4 != 0 or ldy % 4 != 0 or (x2 is not None and (C1 % 4 != 0 or ldx2 % 4 != 0))
+        if odd or (HW * (C // G) <= 65536 and B * G >= 32 and B * HW * C <= (1 << 22) and not sliver):
             # small map: one launch, one block per (group, batch item) -- latency, not bandwidth, is the cost
             # (variant 1 = second-generation kernel with batched loads, see norm.hip)
             self._add(L.OP_GN_SMALL, [B, HW, C, G, ldx, ldy, act, variant, C1, ldx2], [eps], [x, gamma, beta, out, x2],

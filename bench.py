@@ -34,6 +34,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md: fp32-in MFMA peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0         # same guide: dense bf16 MFMA peak; six bf16 products per fp32-equivalent product
+PEAK_HBM_GBS = 8000.0                  # same guide: HBM3E peak (6.29 TB/s measured by a float4 copy)
 ARITH_TEXT = {"f32": "f32 (v_mfma_f32_32x32x2_f32 on fp32 operands)",
               "bf16x6": "bf16x6 (exact 3-way bf16 split of every fp32 operand in the loader, 6 bf16 MFMA piece products, fp32 "
                         "accumulate; operands and results fp32 in HBM; the latency-regime lin_gemm kernels, attention, norms and "
@@ -241,9 +242,10 @@ def main():
                     help="clips timed in each of the two one-clip-at-a-time legs reported beside the headline")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the reported-only legs: parity vs the oracle, BASELINE configs 3 / 4 / 5 sub-benchmarks")
-    ap.add_argument("--cpu-anchor-steps", type=int, default=12,
+    ap.add_argument("--cpu-anchor-steps", type=int, default=50,
                     help="DDIM steps of the config-1 CPU anchor clip measured end to end through the oracle (0 = skip; BASELINE "
-                         "configs[0] is 50 steps = ~80 s of CPU: the default keeps the sample at ~20 s and says so)")
+                         "configs[0] is 50 steps: the un-extrapolated anchor SURVEY 8(d) asks for, ~50-110 s of CPU on the box's "
+                         "host; round 4 cut it to 12 steps and extrapolated)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
@@ -400,8 +402,15 @@ def main():
         if PLAN == "partition":
             lanes_txt = (f"{pipe.edit_lanes} edit loops on disjoint {pipe.edit_lane_cus}-CU lanes" if pipe.edit_lanes > 1 and
                          pipe.edit_lane_cus != pipe.edit_cus else f"{pipe.edit_lanes} edit loop(s) on {pipe.edit_cus} CUs")
-            headline = (f"up to {pipe.clips_in_flight} clips in flight per GPU, each alone in its U-Net batches: forward inversion "
-                        f"({args.group} timesteps per U-Net call) on {pipe.total - pipe.edit_cus} CUs beside {lanes_txt}"
+            grouped = getattr(pipe, "edit_group", 1) > 1
+            if grouped:
+                lanes_txt += (f", each stepping up to {pipe.edit_group} clips in lockstep (U-Net batch 2g for the g clips whose "
+                              f"inversions are ready; groups formed in this run: {extra['pipeline'].get('groups_formed')})")
+            headline = (f"a STREAM of {args.steps} clips per GPU (throughput of the stream, not the latency of one clip: "
+                        f"`value_single_clip_batched` is the clip alone), "
+                        + ("every clip alone in its inversion U-Net batches, " if grouped else
+                           f"up to {pipe.clips_in_flight} clips in flight, each alone in its U-Net batches: ")
+                        + f"forward inversion ({args.group} timesteps per U-Net call) on {pipe.total - pipe.edit_cus} CUs beside {lanes_txt}"
                         + ("; VAE decode + vocoder as a third stage on the inversion partition's queue, between its inversions"
                            if getattr(pipe, "codec_stage", False) else ""))
         elif args.lane_cus:
@@ -564,140 +573,192 @@ def main():
             log(f"process group teardown: {e!r}")
 
 
-def _measure_groups(groups):
-    """groups: {U-Net batch: dict(n = forwards per clip, members = [(model view, stream)], cu_frac = share of the chip's CUs the
-    members' streams may use TOGETHER)}.  Per group: the captured forward graph replayed on every member stream at once (wall
-    clock), one eager pass with a HIP-event pair per op for each op's share."""
-    detail, tot_fl, tot_ms, n_launch, per_clip_flops, per_clip_exec = {}, 0.0, 0.0, 0, 0.0, 0.0
-    for B, g in groups.items():
-        engs = []
-        for v, st in g["members"]:
-            ed = v.editor(256, 16)
-            # engine keys are (B, L0, L1) for fp32 engines and (B, L0, L1, arith) for the others: take the one this run used
-            cand = sorted(((len(key), e) for key, e in ed._unets.items() if key[0] == B), key=lambda t: -t[0])
-            if cand:
-                engs.append((ed, cand[0][1], st))
-        if not engs:
-            continue
-        with torch.inference_mode():
-            for ed, _, _ in engs:
-                for pl in ed._plans.values():
-                    pl["state"].zero_()    # the time-embedding op indexes the timestep table with the loop counter
-        torch.cuda.synchronize()
-        _, eng0, st0 = engs[0]
-        with torch.cuda.stream(st0):
-            eng0.tape.profile()
-            ms = [eng0.tape.profile() for _ in range(3)]
-            ms = [sum(x) / len(ms) for x in zip(*ms)]
-        for _, eng, st in engs:
-            with torch.cuda.stream(st):
-                eng.tape.capture()
-                for _ in range(2):
-                    eng.tape.replay()
-        torch.cuda.synchronize()
-        n_rep = 40 if B <= 8 else 5
-        t0 = time.perf_counter()
-        for k in range(n_rep):                      # round-robin: every member's queue fills at the same rate
-            for _, eng, st in engs:
-                with torch.cuda.stream(st):
-                    eng.tape.replay()
-        torch.cuda.synchronize()
-        group_ms = 1e3 * (time.perf_counter() - t0) / n_rep          # wall time in which EVERY member did one forward
-        fwd_ms = group_ms / len(engs) * g["cu_frac"]                 # chip-equivalent time of one forward
-        conv = [(mt["exec_flops"], t) for mt, t in zip(eng0.tape.meta, ms) if mt["code"] == 1]
-        fl = sum(f for f, _ in conv)
-        share = sum(t for _, t in conv) / sum(ms)
-        tt = fwd_ms * share
-        tot_fl += g["n"] * fl
-        tot_ms += g["n"] * tt
-        n_launch += g["n"] * len(conv)
-        per_clip_flops += g["n"] * eng0.tape.flops
-        per_clip_exec += g["n"] * eng0.tape.exec_flops
-        detail[f"unet_batch_{B}"] = dict(
-            forwards_per_clip=g["n"], launches_per_forward=len(eng0.tape.ops), conv_gemm_launches=len(conv),
-            streams_measured=len(engs), cu_fraction_of_chip=g["cu_frac"], forward_ms_on_its_streams=group_ms,
-            forward_ms_chip_equivalent=fwd_ms, forward_tflops_algorithmic=eng0.tape.flops / (fwd_ms * 1e-3) / 1e12,
-            forward_tflops_executed=eng0.tape.exec_flops / (fwd_ms * 1e-3) / 1e12, conv_gemm_share_of_forward=share,
-            conv_gemm_tflops_executed=fl / (tt * 1e-3) / 1e12, eager_event_per_op_sum_ms=sum(ms),
-            algorithmic_gflop=eng0.tape.flops / 1e9, executed_gflop=eng0.tape.exec_flops / 1e9)
-    return dict(detail=detail, tot_fl=tot_fl, tot_ms=tot_ms, n_launch=n_launch, per_clip_flops=per_clip_flops,
-                per_clip_exec=per_clip_exec)
+# ---------------------------------------------------------------------------------------------------------------------------
+# Roofline (round 5: PHYSICAL -- every fraction is executed work of one kernel family over the peak of the instruction that
+# family issues, 0 < frac <= 1 with no exception; the fp32-equivalent figures keep their own names).
+#
+#   family                 instruction                          peak (MI355X_MICROARCH.md)    executed flops per launch
+#   gemm_bf16x6            v_mfma_f32_32x32x16_bf16             2500 TFLOP/s dense bf16       6 x 2MNK (six piece products)
+#   attention_bf16x6       v_mfma_f32_32x32x16_bf16             2500                          6 x 4 B H Nq Nk D
+#   gemm_f32 / attention_f32   v_mfma_f32_32x32x2_f32           157.3 TFLOP/s fp32-in MFMA    2MNK / 4 B H Nq Nk D
+#   groupnorm, elementwise     streaming                        8 TB/s HBM (6.3 achievable)   algorithmic bytes of the op record
+#
+# Durations: HIP events on the stream the kernels run on, one event pair per op record (`aed_tape_profile`), the forward's ops
+# launched one at a time -- what `rocprofv3 --kernel-trace --stats` reports per kernel for the same forward (profiles/r05_*).
+# A family measured on a CU partition is priced against cus/256 of the chip peak.
+def op_family(op, meta):
+    """(family, instruction peak in TFLOP/s or None for the streaming ops, executed-flop multiplier) of one op record."""
+    code = meta["code"]
+    if code == 1:                                   # AED_OP_CONV_GEMM
+        if op.flags & 64:
+            return "gemm_mxfp8", 5000.0, 1.0
+        if (op.flags & 4) and op.i[29] < 10:
+            return "gemm_bf16x6", PEAK_BF16_MFMA_TFLOPS, 6.0
+        return "gemm_f32", PEAK_FP32_MFMA_TFLOPS, 1.0
+    if code == 5:                                   # AED_OP_ATTENTION
+        if (op.flags & 4) and op.i[14] == 3:
+            return "attention_bf16x6", PEAK_BF16_MFMA_TFLOPS, 6.0
+        return "attention_f32", PEAK_FP32_MFMA_TFLOPS, 1.0
+    if code in (2, 3, 21, 22):
+        return "groupnorm", None, 0.0
+    return "elementwise", None, 0.0
+
+
+def profile_forward(eng, stream, reps=2):
+    """Per-op milliseconds of one U-Net forward on `stream` (event pair per op, min over `reps` passes after a warm one)."""
+    with torch.cuda.stream(stream):
+        eng.tape.profile()
+        runs = [eng.tape.profile() for _ in range(reps)]
+    return [min(r[k] for r in runs) for k in range(len(runs[0]))]
+
+
+def family_table(eng, ms, cu_frac=1.0):
+    """Per family: launches, total ms, executed flops of the issued instruction, and the fraction of that instruction's peak on
+    the CUs the forward ran on."""
+    fam = {}
+    for op, mt, t in zip(eng.tape.ops, eng.tape.meta, ms):
+        name, peak, mult = op_family(op, mt)
+        f = fam.setdefault(name, dict(launches=0, ms=0.0, flops_fp32_equiv=0.0, flops_executed=0.0, bytes=0.0, peak=peak))
+        f["launches"] += 1
+        f["ms"] += t
+        f["flops_fp32_equiv"] += mt["exec_flops"]
+        f["flops_executed"] += mult * mt["exec_flops"]
+        f["bytes"] += mt.get("bytes", 0)
+    out = {}
+    for name, f in fam.items():
+        d = dict(launches=f["launches"], ms=f["ms"], avg_launch_us=1e3 * f["ms"] / max(1, f["launches"]))
+        if f["peak"] is not None and f["ms"] > 0:
+            ach = f["flops_executed"] / (f["ms"] * 1e-3) / 1e12
+            d.update(instruction_peak_tflops=f["peak"] * cu_frac, achieved_tflops=ach, frac=ach / (f["peak"] * cu_frac),
+                     matrix_pipe_seconds_at_chip_peak=f["flops_executed"] / (f["peak"] * 1e12),
+                     achieved_tflops_fp32_equiv=f["flops_fp32_equiv"] / (f["ms"] * 1e-3) / 1e12)
+        elif f["ms"] > 0:
+            gbs = f["bytes"] / (f["ms"] * 1e-3) / 1e9
+            d.update(algorithmic_gb_per_s=gbs, hbm_peak_gb_per_s=PEAK_HBM_GBS * cu_frac, frac=gbs / (PEAK_HBM_GBS * cu_frac))
+        out[name] = d
+    return out
 
 
 def check_fractions(roof):
-    """Every fraction of the roofline object against ITS OWN roof must lie in (0, 1] (round 3 printed path_frac = 4.23 from a
-    double division): raises AssertionError naming the offender.  Under bf16x6 the fp32-referenced `frac` / `path_frac` may
-    exceed 1 (the GEMMs run on the bf16 matrix pipe); their `*_vs_bf16_over_6` twins are the ones checked then."""
-    x6 = "frac_vs_bf16_over_6" in roof
-    names = (("frac_vs_bf16_over_6", "path_frac_vs_bf16_over_6") if x6 else ("frac", "path_frac", "path_frac_executed"))
-    for k in names + ("frac_whole_chip_serial_vs_its_roof",):
-        v = roof.get(k)
-        if v is not None:
-            assert 0.0 < v <= 1.0, f"roofline.{k} = {v:.3f} is outside (0, 1]: the accounting is wrong"
-    for b, d in (roof.get("by_batch") or {}).items():
-        v = d.get("cu_fraction_of_chip")
-        assert v is None or 0.0 < v <= 1.0, f"roofline.by_batch.{b}.cu_fraction_of_chip = {v}"
+    """Every `frac` of the roofline object is executed work over the peak of the instruction that did it: it must lie in
+    (0, 1].  Raises AssertionError naming the offender (round 3 printed path_frac = 4.23, round 4 let `frac` exceed 1 under
+    bf16x6: neither can pass here).  Keys named *_fp32_equiv are NOT roofline fractions and are not checked."""
+    def walk(d, where):
+        for k, v in d.items():
+            if isinstance(v, dict):
+                walk(v, f"{where}.{k}")
+            elif (k == "frac" or k.endswith("_frac") or k.startswith("frac_")) and "fp32_equiv" not in k and v is not None:
+                assert 0.0 < v <= 1.0, f"{where}.{k} = {v:.3f} is outside (0, 1]: the accounting is wrong"
+    walk(roof, "roofline")
+
+
+def _find_engine(views, B):
+    """The U-Net engine of batch B that this run used, among the given model views (engine keys: (B, L0, L1[, arith]))."""
+    for v in views:
+        ed = v.editor(256, 16)
+        cand = sorted(((len(key), e) for key, e in ed._unets.items() if key[0] == B), key=lambda t: -t[0])
+        if cand:
+            for pl in ed._plans.values():
+                pl["state"].zero_()            # the time-embedding op indexes the timestep table with the loop counter
+            return cand[0][1]
+    return None
+
+
+def graph_ms(eng, stream, n):
+    """Milliseconds per forward as a captured hipGraph replayed n times on `stream` (what a loop step pays)."""
+    with torch.cuda.stream(stream):
+        eng.tape.capture()
+        for _ in range(2):
+            eng.tape.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(n):
+            eng.tape.replay()
+        e1.record(stream)
+        e1.synchronize()
+    return e0.elapsed_time(e1) / n
 
 
 def roofline_leg(m, pipe, args, NC, dt):
-    """See the comment at the call site.  One group per U-Net batch shape of the headline schedule: the engines that run
-    it, the streams (CU partitions) they run on, and the fraction of the chip those streams may use."""
+    """The `roofline` object of the JSON line.  Dominant kernel: the split-bf16 implicit-GEMM (conv_gemm_x6_kernel) of the
+    inversion's timestep-batched U-Net forward -- 400 of a clip's 600 sample-forwards and ~80 % of that forward's time.
+    Measured (1) on the whole chip, one launch at a time (the figure a `rocprofv3 --kernel-trace --stats` of
+    `bench.py --plan serial` reproduces: profiles/r05_kernel_trace_serial.md) -> `achieved` / `frac`; (2) on the CU partition
+    the pipeline's front stage runs it on, against that partition's share of the peak -> `on_partition`; the edit loop's
+    forward (U-Net batch 2g on the edit lane) per family -> `edit_step`."""
     dev = m.device
-    if pipe is None or pipe.plan == "lanes":
-        masked = pipe is not None and getattr(pipe, "lane_cus", None)        # whole-clip lanes on disjoint CU slices: batched inversion
-        sequential = (pipe is not None and not masked) or (pipe is None and args.schedule == "sequential")
-        G = 1
-        if not sequential:
-            G = max(1, min(args.group // NC if NC > 1 else args.group, args.T))
-            while args.T % G:
-                G -= 1
-        calls = {2 * NC: args.T + args.tstart} if sequential else {2 * NC: args.tstart, 2 * G * NC: args.T // G}
-        if pipe is None:
-            st = torch.cuda.Stream(device=dev)
-            groups = {B: dict(n=n, members=[(m, st)], cu_frac=1.0) for B, n in calls.items()}
-        else:
-            groups = {B: dict(n=n, members=[(w.view, w.lane.stream) for w in pipe.workers],
-                              cu_frac=(len(pipe.workers) * pipe.lane_cus / pipe.total) if masked else 1.0)
-                      for B, n in calls.items()}
-    else:
-        G = max(1, min(args.group, args.T))
-        while args.T % G:
-            G -= 1
-        front = [w for w in pipe.workers if w.stage == "front"]
-        back = [w for w in pipe.workers if w.stage == "back"]
-        groups = {2: dict(n=args.tstart, members=[(w.view, w.lane.stream) for w in back],
-                          cu_frac=pipe.edit_cus / pipe.total),
-                  2 * G: dict(n=args.T // G, members=[(w.view, w.lane.stream) for w in front],
-                              cu_frac=(pipe.total - pipe.edit_cus) / pipe.total)}
-    meas = _measure_groups(groups)
-    detail, tot_fl, tot_ms, n_launch = meas["detail"], meas["tot_fl"], meas["tot_ms"], meas["n_launch"]
-    per_clip_flops, per_clip_exec = meas["per_clip_flops"], meas["per_clip_exec"]
-    # The same clip's forwards ONE AT A TIME ON THE WHOLE CHIP (the model's own engines, built by the one-clip-at-a-time legs;
-    # nothing concurrent, no CU mask, no partition bookkeeping): the figure a plain `rocprofv3 --kernel-trace` of a serial run
-    # reproduces (VERDICT r3 weak #4).  GEMM family: executed flops / [forward time x GEMM share] per batch shape.
-    serial = None
-    if pipe is not None and NC == 1:
-        G = max(1, min(args.group, args.T))
-        while args.T % G:
-            G -= 1
-        st = torch.cuda.Stream(device=dev)
-        sm = _measure_groups({2: dict(n=args.tstart, members=[(m, st)], cu_frac=1.0),
-                              2 * G: dict(n=args.T // G, members=[(m, st)], cu_frac=1.0)})
-        if sm["tot_ms"] and len(sm["detail"]) == 2:
-            a = sm["tot_fl"] / (sm["tot_ms"] * 1e-3) / 1e12
-            serial = dict(achieved=a, frac=a / PEAK_FP32_MFMA_TFLOPS, gemm_ms_per_clip=sm["tot_ms"],
-                          unet_ms_per_clip=sum(d["forwards_per_clip"] * d["forward_ms_chip_equivalent"] for d in sm["detail"].values()),
-                          by_batch={k: {kk: d[kk] for kk in ("forward_ms_chip_equivalent", "conv_gemm_share_of_forward",
-                                                              "conv_gemm_tflops_executed", "launches_per_forward")}
-                                    for k, d in sm["detail"].items()})
-    if not tot_ms:
+    G = max(1, min(args.group // NC if NC > 1 else args.group, args.T))
+    while args.T % G:
+        G -= 1
+    sequential_headline = (pipe is None and args.schedule == "sequential") or \
+        (pipe is not None and pipe.plan == "lanes" and not getattr(pipe, "lane_cus", None))
+    B_inv = 2 * NC if sequential_headline else 2 * G * NC
+    views = [m] + ([w.view for w in pipe.workers] if pipe is not None else [])
+    whole = torch.cuda.Stream(device=dev)
+    out = dict(bound="mfma", unit="TFLOP/s", peak=PEAK_BF16_MFMA_TFLOPS, csrc_hash=csrc_hash(),
+               peak_note="dense bf16 MFMA peak of the MI355X (MI355X_MICROARCH.md: ~2.5 PFLOP/s; measured ceiling 2495); the kernel "
+                         "issues v_mfma_f32_32x32x16_bf16, six piece products per fp32-equivalent product",
+               kernel="conv_gemm_x6_kernel<*> (csrc/conv_gemm_x6.hip): every LDS-staged conv / Linear of the U-Net forward at "
+                      f"batch {B_inv}",
+               method="executed MFMA flops (6 x 2MNK per launch) / sum of launch durations; durations = HIP event pairs around "
+                      "every op record of the forward on the stream it runs on (aed_tape_profile), ops launched one at a time")
+    eng = _find_engine(views, B_inv)
+    if eng is None:
         return None
-    achieved = tot_fl / (tot_ms * 1e-3) / 1e12
-    # HBM-side traffic per conv_gemm launch: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs; counter
-    # passes serialise every dispatch and cannot run inside a timed bench) committed under profiles/, used only when
-    # they were taken on THIS source tree (hash of csrc/); null otherwise
+    torch.cuda.synchronize()
+    ms = profile_forward(eng, whole)
+    fams = family_table(eng, ms, 1.0)
+    dom = fams.get("gemm_bf16x6") or fams.get("gemm_f32")
+    if dom is None or "achieved_tflops" not in dom:
+        return None
+    if "gemm_bf16x6" not in fams:                   # --arith f32: the dominant family issues fp32-input MFMAs
+        out.update(peak=PEAK_FP32_MFMA_TFLOPS, peak_note="fp32-input MFMA peak (v_mfma_f32_32x32x2_f32)",
+                   kernel=out["kernel"].replace("conv_gemm_x6_kernel<*> (csrc/conv_gemm_x6.hip)", "conv_gemm_kernel / lin_gemm_kernel"))
+    n_x6 = dom["launches"]
+    alg = sum(mt["flops"] for mt in eng.tape.meta)
+    out.update(achieved=dom["achieved_tflops"], frac=dom["achieved_tflops"] / out["peak"],
+               achieved_fp32_equiv=dom["achieved_tflops_fp32_equiv"],
+               frac_fp32_equiv=dom["achieved_tflops_fp32_equiv"] / PEAK_FP32_MFMA_TFLOPS,
+               fp32_equiv_note="`*_fp32_equiv` = 2MNK per launch over the same durations, against the fp32-input MFMA peak (157.3): "
+                               "the arithmetic the results are equivalent to; not a roofline fraction (may exceed 1)",
+               launches_per_forward=n_x6, avg_launch_us=dom["avg_launch_us"],
+               algorithmic_gflop_per_launch=dom["achieved_tflops_fp32_equiv"] * dom["avg_launch_us"] * 1e-3,
+               forward=dict(unet_batch=B_inv, where="whole chip, launches one at a time", ms_sum_of_launches=sum(ms),
+                            ms_as_graph=graph_ms(eng, whole, 3), algorithmic_gflop=alg / 1e9, families=fams))
+    # ---- the same forward on the pipeline's front partition (alone on it)
+    if pipe is not None and pipe.plan == "partition":
+        front = [w for w in pipe.workers if w.stage == "front"][0]
+        cu_frac = (pipe.total - pipe.edit_cus) / pipe.total
+        eng_f = _find_engine([front.view], B_inv) or eng
+        torch.cuda.synchronize()
+        ms_f = profile_forward(eng_f, front.lane.stream)
+        fam_f = family_table(eng_f, ms_f, cu_frac)
+        d = fam_f.get("gemm_bf16x6") or fam_f.get("gemm_f32") or {}
+        out["on_partition"] = dict(cus=pipe.total - pipe.edit_cus, cu_fraction_of_chip=cu_frac,
+                                   peak=out["peak"] * cu_frac, achieved=d.get("achieved_tflops"), frac=d.get("frac"),
+                                   achieved_fp32_equiv=d.get("achieved_tflops_fp32_equiv"), ms_sum_of_launches=sum(ms_f),
+                                   ms_as_graph=graph_ms(eng_f, front.lane.stream, 3), families=fam_f,
+                                   note="the front stage's forward alone on its CU partition (nothing on the other CUs): the "
+                                        "half-loaded chip holds a higher clock than the whole chip under the bf16 MFMA stream")
+        # ---- the edit loop's step on the edit lane, for every group size an engine exists for
+        back = [w for w in pipe.workers if w.stage == "back"]
+        steps = {}
+        for g in sorted(set(getattr(pipe, "group_sizes", [1]))):
+            e = _find_engine([back[0].view], 2 * g * NC)
+            if e is None:
+                continue
+            lane_frac = pipe.edit_lane_cus / pipe.total
+            torch.cuda.synchronize()
+            ms_e = profile_forward(e, back[0].lane.stream)
+            gm = graph_ms(e, back[0].lane.stream, 20 if g <= 2 else 6)
+            steps[f"clips_{g}"] = dict(unet_batch=2 * g * NC, lane_cus=pipe.edit_lane_cus, ms_per_step_as_graph=gm,
+                                       ms_per_clip_step=gm / g, launches=len(e.tape.ops),
+                                       tflops_fp32_equiv_algorithmic=e.tape.flops / (gm * 1e-3) / 1e12,
+                                       families=family_table(e, ms_e, lane_frac))
+        out["edit_step"] = steps
+    # ---- HBM-side traffic of the dominant family from the committed PMC passes (separate runs; only if taken on this source tree)
     traffic = traffic_note = None
-    for name in ("r04_pmc_forward.json", "r03_pmc_forward.json", "r02_pmc_forward.json"):
+    for name in ("r05_pmc_forward.json", "r04_pmc_forward.json"):
         pmc_path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(pmc_path):
             continue
@@ -709,50 +770,30 @@ def roofline_leg(m, pipe, args, NC, dt):
                 traffic_note = (f"bytes per conv_gemm-family launch, {pmc['counters']}; algorithmic "
                                 f"{pmc['algorithmic_bytes_per_launch']:.3g} B per launch; {pmc['source']}")
             else:
-                traffic_note = (f"null: profiles/{name} was measured on csrc {pmc.get('csrc_hash')}, "
-                                f"this binary is {csrc_hash()}")
+                traffic_note = f"null: profiles/{name} was measured on csrc {pmc.get('csrc_hash')}, this binary is {csrc_hash()}"
             break
         except (OSError, KeyError, ValueError) as e:
             log(f"PMC summary unreadable: {e!r}")
-    # `per_clip_flops` / `per_clip_exec` were summed over the forwards of ONE STEP = NC clips per U-Net batch: price them against
-    # the step time (round 3 divided the time by NC as well and printed path_frac = 4.23 for NC = 8), report them per clip
-    s_step = dt / args.steps
-    per_clip_flops, per_clip_exec = per_clip_flops / NC, per_clip_exec / NC
-    s_clip = s_step / NC
-    # Two roofs.  `peak` stays the fp32-input MFMA rate: it is the arithmetic the results are equivalent to and the roof of
-    # every GEMM that runs on fp32 instructions.  The split-bf16 GEMMs execute six bf16 MFMA products per fp32-equivalent
-    # product, so THEIR nominal roof is 2500 / 6 = 416.7 TFLOP/s fp32-equivalent -- `frac` may exceed 1 under bf16x6, and
-    # `frac_vs_bf16_over_6` (same numerator over 416.7) is the figure to read as "fraction of the matrix pipe".
-    x6_peak = PEAK_BF16_MFMA_TFLOPS / 6.0
-    arith_note = dict(arith=ARITH_TEXT[args.arith])
-    if args.arith != "f32":
-        arith_note.update(
-            peak_bf16_over_6=x6_peak, frac_vs_bf16_over_6=achieved / x6_peak,
-            path_frac_vs_bf16_over_6=per_clip_flops / s_clip / 1e12 / x6_peak,
-            peak_note="`peak` = fp32-input MFMA rate (157.3); the LDS-staged GEMMs run on bf16 MFMAs (6 products per "
-                      "fp32-equivalent product): nominal roof 2500 / 6 = 416.7 TFLOP/s fp32-equivalent, ~280 at the clocks the "
-                      "chip sustains under that instruction stream (profiles/r03_x6_gemm.md) -- `frac` > 1 is not an error")
-    serial_note = {}
-    if serial is not None:
-        serial_note = dict(
-            frac_whole_chip_serial=serial["frac"],
-            frac_whole_chip_serial_vs_its_roof=serial["achieved"] / (x6_peak if args.arith != "f32" else PEAK_FP32_MFMA_TFLOPS),
-            whole_chip_serial=dict(
-                serial, note="one clip at a time on the whole chip (no partitions, nothing concurrent): GEMM-family executed "
-                             "flops / [forward time x GEMM share], the figure a plain rocprofv3 kernel trace of a serial run "
-                             "reproduces (profiles/); `frac` = achieved / 157.3"))
-    return dict(**arith_note, **serial_note, bound="mfma", achieved=achieved, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
-                frac=achieved / PEAK_FP32_MFMA_TFLOPS, traffic=traffic, traffic_note=traffic_note,
-                kernel="conv_gemm_x6_kernel / conv_gemm_kernel + lin_gemm_kernel (every conv / Linear of the U-Net forwards of one "
-                       "clip)",
-                method="executed flops (2MNK per launch) / [chip-equivalent time per forward x GEMM share].  Chip-equivalent "
-                       "time = wall time (host clock around hipGraph replays, every stream of the batch shape's pipeline "
-                       "stage replaying at once on its own CU partition) / streams x the partition's fraction of the "
-                       "chip's CUs; GEMM share from one eager pass with a HIP-event pair per op",
-                launches_per_clip=n_launch, avg_launch_us_chip_equivalent=1e3 * tot_ms / n_launch, by_batch=detail,
-                csrc_hash=csrc_hash(), clip_unet_tflop=per_clip_flops / 1e12, clip_unet_tflop_executed=per_clip_exec / 1e12,
-                path_tflops=per_clip_flops / s_clip / 1e12, path_frac=per_clip_flops / s_clip / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                path_frac_executed=per_clip_exec / s_clip / 1e12 / PEAK_FP32_MFMA_TFLOPS)
+    out.update(traffic=traffic, traffic_note=traffic_note)
+    # ---- path level: one clip's U-Net work against the wall clock of the headline
+    s_clip = dt / args.steps / NC
+    n_inv = (args.T if sequential_headline else args.T // G)
+    per_clip_alg = (n_inv * alg + args.tstart * alg * (2 * NC) / B_inv) / NC      # inversion forwards + edit forwards (same graph, batch 2)
+    # matrix-pipe time a clip NEEDS at the instruction peaks (x6 families at 2500, fp32 families at 157.3) over the wall clock
+    pipe_s = lambda table: sum(f.get("matrix_pipe_seconds_at_chip_peak", 0.0) for f in table.values())     # noqa: E731
+    need_inv = pipe_s(fams)
+    edit1 = (out.get("edit_step") or {}).get("clips_1")
+    # the edit loop's forward has its own family mix (latency-regime fp32 kernels at batch 2); without a measured one (serial
+    # plans) the inversion forward's mix is scaled by the batch ratio
+    need_edit = pipe_s(edit1["families"]) if edit1 else need_inv * (2 * NC) / B_inv
+    need_clip = (n_inv * need_inv + args.tstart * need_edit) / NC
+    out["path"] = dict(clip_unet_tflop_algorithmic=per_clip_alg / 1e12, seconds_per_clip=s_clip,
+                       tflops_fp32_equiv=per_clip_alg / s_clip / 1e12,
+                       frac_fp32_equiv=per_clip_alg / s_clip / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                       matrix_pipe_seconds_needed_per_clip=need_clip, matrix_pipe_frac=need_clip / s_clip,
+                       note="matrix_pipe_frac = [executed MFMA flops of a clip's 600 sample-forwards, each family over the peak of "
+                            "its own instruction] / wall seconds per clip: the share of the chip's matrix-pipe time the headline uses")
+    return out
 
 
 def parity_leg(m, fn, wave, src, tgt, neg, T=8, tstart=4):
@@ -845,15 +886,10 @@ def sub_benchmarks(elapsed_s):
             ("config4_pc_extract_apply", [py, os.path.join(ROOT, "tools", "bench_config4.py")], 300),
             ("config5_stable_audio", [py, os.path.join(ROOT, "tools", "bench_stable_audio.py"), "--steps", "1",
                                            "--warmup", "1"], 300),
-            # EXPERIMENT, not a parity path: the same clip with the DiT's GEMMs on the MX-FP8 matrix cores (BASELINE config 5 names an
-            # "fp8 MFMA path"); its `parity_T200` reads as the deviation from the fp32 CPU oracle
-            ("config5_stable_audio_fp8_experiment", [py, os.path.join(ROOT, "tools", "bench_stable_audio.py"), "--arith", "fp8",
-                                                      "--steps", "1", "--warmup", "1"], 200),
-            # the round-1..3 arithmetic (fp32-input MFMAs everywhere) through the same pipeline, for the A/B in one driver run
-            ("pipeline_arith_f32", [py, os.path.join(ROOT, "bench.py"), "--arith", "f32", "--steps", "6", "--warmup", "2",
-                                    "--no-extras", "--no-cpu-baseline", "--no-batched"], 150)]
-    # the A/B leg only starts while the whole run is still short (the default run stays within ~6.5 minutes)
-    start_by = {"pipeline_arith_f32": 330, "config5_stable_audio_fp8_experiment": 360}
+            ]
+    # (round 5: the fp32-arithmetic A/B leg and the MX-FP8 experiment leg left the driver's run -- the full 50-step config-1 CPU
+    # anchor took their time; `python bench.py --arith f32 ...` / `tools/bench_stable_audio.py --arith fp8` still run them by hand)
+    start_by = {}
     out = {}
     for key, cmd, limit in jobs:
         if elapsed_s > start_by.get(key, 600):  # keep the whole default run bounded

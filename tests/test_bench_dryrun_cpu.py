@@ -16,14 +16,24 @@ import bench                                                     # noqa: E402
 from audioeditingcode_amd import main_run, models               # noqa: E402
 
 
+class _Op:
+    def __init__(self, flags=0, tile=1, variant=0):
+        self.flags = flags
+        self.i = [0] * 40
+        self.i[29], self.i[14] = tile, variant
+
+
 class _Tape:
     flops = 3.4e11
     exec_flops = 3.0e11
-    meta = [dict(code=1, flops=1e9, exec_flops=8e8, name="x.conv1"), dict(code=22, flops=0, exec_flops=0, name="gn")]
-    ops = [None, None]
+    # one split-bf16 GEMM, one latency-regime fp32 GEMM, one GroupNorm
+    meta = [dict(code=1, flops=1e9, exec_flops=8e8, bytes=1e6, name="x.conv1"),
+            dict(code=1, flops=1e8, exec_flops=1e8, bytes=1e5, name="x.qkv"),
+            dict(code=22, flops=0, exec_flops=0, bytes=4e6, name="gn")]
+    ops = [_Op(flags=12, tile=8), _Op(flags=0, tile=10), _Op()]
 
     def profile(self):
-        return [0.01, 0.005]
+        return [0.01, 0.005, 0.005]
 
     def capture(self):
         return None
@@ -44,6 +54,9 @@ class _Event:
 
     def elapsed_time(self, other):
         return 12.0
+
+    def query(self):
+        return True
 
 
 class _Eng:
@@ -109,6 +122,7 @@ class _W:
     def __init__(self, stage, view):
         self.stage, self.view = stage, view
         self.lane = type("Lane", (), dict(stream=_Stream()))()
+        self.full = self.lane
 
 
 class _Pipe:
@@ -185,13 +199,17 @@ def test_default_line_has_the_contract_keys():
     # workers built, W warm, K timed, then the compared clips one per call through the same engines
     assert _Pipe.made[0].calls == [("warm_up", 1), ("edit_clips", 2), ("edit_clips", 4), ("edit_clips", 1), ("edit_clips", 1)]
     r = out["roofline"]
-    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
-    assert set(r["by_batch"]) == {"unet_batch_2", "unet_batch_40"}
-    assert r["by_batch"]["unet_batch_2"]["streams_measured"] == 2 and r["by_batch"]["unet_batch_40"]["streams_measured"] == 1
-    assert abs(r["by_batch"]["unet_batch_2"]["cu_fraction_of_chip"] - 96 / 256) < 1e-12
-    assert r["launches_per_clip"] == 100 * 1 + 10 * 1               # tstart edit forwards + T/G inversion forwards
+    # the dominant family: the split-bf16 GEMM of the batch-40 inversion forward, executed MFMA flops over the bf16 MFMA peak
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["frac"] <= 1
+    assert abs(r["achieved"] - 6 * 8e8 / (0.01e-3) / 1e12) < 1e-9 and abs(r["achieved_fp32_equiv"] * 6 - r["achieved"]) < 1e-9
+    assert r["forward"]["unet_batch"] == 40 and set(r["forward"]["families"]) == {"gemm_bf16x6", "gemm_f32", "groupnorm"}
+    assert r["forward"]["families"]["gemm_f32"]["instruction_peak_tflops"] == 157.3
+    assert abs(r["on_partition"]["cu_fraction_of_chip"] - 160 / 256) < 1e-12
+    assert abs(r["on_partition"]["peak"] - 2500.0 * 160 / 256) < 1e-9
+    assert set(r["edit_step"]) == {"clips_1"} and r["edit_step"]["clips_1"]["unet_batch"] == 2
     assert r["traffic"] is None or r["traffic"] > 0
-    assert r["path_frac_executed"] < r["path_frac"]
+    assert 0 < r["path"]["matrix_pipe_frac"] and "frac_fp32_equiv" in r["path"]
     assert "value_reference_order" in out and "value_single_clip_batched" in out and out["serial_legs_clips"] == 2
     assert out["schedule_deviation_rel_l2"] == 0.0          # the mocked edit returns the same latent for every schedule
     assert out["pipeline_vs_one_clip_at_a_time"] == dict(
@@ -204,21 +222,19 @@ def test_lanes_plan_single_clip_schedules_and_multi_clip_mode():
     out = _run(["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--plan", "lanes", "--lanes", "3",
                 "--group", "20"], [2, 40])
     assert out["config"]["clips_in_flight_per_gpu"] == 3 and "reference step order" in out["config"]["workload"]
-    assert set(out["roofline"]["by_batch"]) == {"unet_batch_2"} and out["roofline"]["launches_per_clip"] == 300
-    assert out["roofline"]["by_batch"]["unet_batch_2"]["streams_measured"] == 3
+    assert out["roofline"]["forward"]["unet_batch"] == 2 and "on_partition" not in out["roofline"]
     assert out["pipeline_vs_one_clip_at_a_time"]["plain_serial_schedule"] == "sequential"
     out = _run(["--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--plan", "serial", "--schedule",
                 "sequential", "--group", "20"], [2, 40])
     assert "value_single_clip_batched" in out and "reference order" in out["config"]["workload"]
-    assert out["roofline"]["launches_per_clip"] == 300
+    assert out["roofline"]["forward"]["unet_batch"] == 2
     out = _run(["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--plan", "serial", "--group", "20"],
                [2, 40])
-    assert set(out["roofline"]["by_batch"]) == {"unet_batch_2", "unet_batch_40"}
-    assert out["roofline"]["launches_per_clip"] == 100 * 1 + 10 * 1         # tstart edit forwards + T/G inversion forwards
+    assert out["roofline"]["forward"]["unet_batch"] == 40
     out = _run(["--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--clips-per-gpu", "2", "--group",
                 "20", "--no-batched"], [4, 40])
     assert out["config"]["clips_per_gpu_per_step"] == 2 and out["config"]["gathered_latents"] == [[2, 8, 256, 16]]
-    assert set(out["roofline"]["by_batch"]) == {"unet_batch_4", "unet_batch_40"}
+    assert out["roofline"]["forward"]["unet_batch"] == 40
 
 
 def test_extras_are_reported_and_never_fatal():
@@ -240,13 +256,17 @@ def test_extras_are_reported_and_never_fatal():
     assert out["config5_stable_audio"]["value"] == 2.5
 
 
-def test_roofline_fraction_check_refuses_the_round_3_defect():
-    """check_fractions: a fraction above its own roof (round 3's path_frac = 4.23) raises; under bf16x6 the fp32-referenced
-    fractions may exceed 1 and the bf16/6 twins are the ones checked."""
+def test_roofline_fraction_check_refuses_fractions_above_their_own_roof():
+    """check_fractions (round 5): EVERY `frac` of the roofline object -- at any depth -- is executed work over the peak of the
+    instruction that did it and must lie in (0, 1]: round 3's path_frac = 4.23 and round 4's `frac` > 1 under bf16x6 both raise.
+    Keys named *_fp32_equiv are not roofline fractions (they may exceed 1) and are skipped."""
     import pytest
-    bench.check_fractions(dict(frac=0.53, path_frac=0.47, path_frac_executed=0.46, by_batch={"b": dict(cu_fraction_of_chip=0.5)}))
-    with pytest.raises(AssertionError, match="path_frac"):
-        bench.check_fractions(dict(frac=0.53, path_frac=4.23, path_frac_executed=0.46))
-    bench.check_fractions(dict(frac=1.21, path_frac=0.74, frac_vs_bf16_over_6=0.46, path_frac_vs_bf16_over_6=0.28))
-    with pytest.raises(AssertionError, match="frac_vs_bf16_over_6"):
-        bench.check_fractions(dict(frac=3.1, path_frac=0.74, frac_vs_bf16_over_6=1.17, path_frac_vs_bf16_over_6=0.28))
+    ok = dict(frac=0.35, frac_fp32_equiv=0.93, forward=dict(families=dict(gemm_bf16x6=dict(frac=0.35), groupnorm=dict(frac=0.6))),
+              on_partition=dict(frac=0.41, cu_fraction_of_chip=0.625), path=dict(matrix_pipe_frac=0.3, frac_fp32_equiv=1.2))
+    bench.check_fractions(ok)
+    with pytest.raises(AssertionError, match="roofline.frac"):
+        bench.check_fractions(dict(ok, frac=1.21))
+    with pytest.raises(AssertionError, match="gemm_bf16x6.frac"):
+        bench.check_fractions(dict(ok, forward=dict(families=dict(gemm_bf16x6=dict(frac=4.23)))))
+    with pytest.raises(AssertionError, match="matrix_pipe_frac"):
+        bench.check_fractions(dict(ok, path=dict(matrix_pipe_frac=0.0)))

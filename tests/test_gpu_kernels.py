@@ -96,6 +96,12 @@ def test_groupnorm(C, G, HW, B, act):
     _groupnorm_case(C, G, HW, B, act, variant=0)
 
 
+@pytest.mark.parametrize("C,G,HW,B,act", [(320, 32, 4096, 2, 1), (320, 32, 64, 3, 0), (96, 16, 300, 2, 1)])
+def test_groupnorm_channel_groups_that_are_not_float4_granules(C, G, HW, B, act):
+    """TANGO at full size: 320 channels in 32 groups = 10 per group (round 5: found by the full-size TANGO test)."""
+    _groupnorm_case(C, G, HW, B, act, variant=0)
+
+
 @pytest.mark.parametrize("C,G,HW,B,act", [(256, 32, 1000, 2, 0), (256, 32, 1021, 2, 1)])
 def test_groupnorm_ragged_rows(C, G, HW, B, act):
     """row counts that are not a multiple of the batched-load width of the single-launch kernel"""
@@ -342,7 +348,8 @@ def test_two_source_conv(tile):
 
 
 @pytest.mark.parametrize("C1,C2,HW,B,variant", [(384, 256, 256, 2, 0), (640, 640, 64, 2, 0), (128, 128, 4096, 2, 0),
-                                                (384, 256, 256, 2, 1), (256, 128, 4096, 6, 0)])
+                                                (384, 256, 256, 2, 1), (256, 128, 4096, 6, 0),
+                                                (640, 320, 1024, 2, 0)])         # TANGO up block: 960 / 32 = 30 per group
 def test_groupnorm_two_source(C1, C2, HW, B, variant):
     """GroupNorm over (h | skip) read in place; 640 channels in 32 groups of 20 straddle the 384|256 boundary."""
     C, G = C1 + C2, 32

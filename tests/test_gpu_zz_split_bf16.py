@@ -242,12 +242,9 @@ def test_split_bf16_gemm_under_adversarial_operand_statistics(stat):
     print(f"\n[x6 adversarial] {stat}: rel L2 vs fp64 fp32-kernel {e32:.2e} / split-bf16 {e6:.2e}; "
           f"max |err| / sum|a||b| fp32-kernel {b32:.2e} / split-bf16 {b6:.2e}")
     assert torch.isfinite(outs["bf16x6"]).all()
-    if stat == "bf16_floor":
-        # Documented limit: below ~2^-110 the third piece of a value leaves bf16's normal range (the format
-        # keeps fp32's exponent, so this is 2^-16 above the floor of fp32 itself); the result then carries ~2^-17 relative
-        # instead of 2^-24.  No tensor of the path lives there (activations are O(1e-3 .. 1e3)); the bound asserted is that limit.
-        assert b6 < 2.0 ** -14, b6
-        return
+    # (bf16_floor: below ~2^-110 the third piece of a value is a bf16 DENORMAL -- the format keeps fp32's exponent range, so this
+    # is 2^-16 above the floor of fp32 itself.  Measured on the MI355X (round 5): the bf16 MFMA keeps input denormals, the case
+    # holds the same bound as the others: 2.8e-7 against the fp32 kernel's 3.7e-7.)
     # same bound as the fp32 kernel: K fp32 accumulations of exact products (unit roundoff 2^-24, statistical growth)
     assert b32 < 64 * 2.0 ** -24 and b6 < 64 * 2.0 ** -24, (b32, b6)
     assert b6 < 2.0 * b32 + 2.0 ** -24, (b6, b32)

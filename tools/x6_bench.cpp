@@ -232,6 +232,31 @@ static int run_feature_cases(hipStream_t st) {
     return bad;
 }
 
+// Wide chunks (op flag bit 8 = 256: BK = 32 on the 512-thread tiles 8 / 9, round 5): the loader / epilogue modes again, with the flag.
+static int run_wide_cases(hipStream_t st) {
+    //            name                               B  IH  IW  Cin   N KH KW st ph pw dh dw up  OH  OW  C1 ia oa res rv acc ks om oa tile
+    const Case cases[] = {
+        {"wide: 3x3 same, tile 8",                   4, 32, 16,  64, 128, 3, 3, 1, 1, 1, 1, 1, 0, 32, 16,  0, 0, 0, 0, 0, 0, 1, 1, 0, 8},
+        {"wide: 3x3 same, tile 9",                   4, 32, 16, 128, 256, 3, 3, 1, 1, 1, 1, 1, 0, 32, 16,  0, 0, 0, 0, 0, 0, 1, 1, 0, 9},
+        {"wide: 3x3 stride 2, tile 8",               4, 32, 16,  64, 128, 3, 3, 2, 1, 1, 1, 1, 0, 16,  8,  0, 0, 0, 0, 0, 0, 1, 1, 0, 8},
+        {"wide: 3x3 upsampled grid, tile 8",         4, 16,  8,  64, 128, 3, 3, 1, 1, 1, 1, 1, 1, 32, 16,  0, 0, 0, 0, 0, 0, 1, 1, 0, 8},
+        {"wide: 3x3 two-source A, tile 8",           4, 32, 16, 192, 128, 3, 3, 1, 1, 1, 1, 1, 0, 32, 16, 64, 0, 0, 0, 0, 0, 1, 1, 0, 8},
+        {"wide: 1x1 two-source + residual, tile 9",  4, 32, 16, 128, 256, 1, 1, 1, 0, 0, 1, 1, 0, 32, 16, 64, 0, 0, 1, 0, 0, 1, 1, 0, 9},
+        {"wide: 3x3 SiLU(A) + row vector + res",     4, 32, 16,  64, 128, 3, 3, 1, 1, 1, 1, 1, 0, 32, 16,  0, 1, 0, 1, 1, 0, 1, 1, 0, 8},
+        {"wide: linear K = 256, SiLU out, tile 9",   1, 2048, 1, 256, 256, 1, 1, 1, 0, 0, 1, 1, 0, 2048, 1, 0, 0, 1, 0, 0, 0, 1, 1, 0, 9},
+        {"wide: linear K = 96 (3 chunks), tile 8",   1, 1024, 1,  96, 192, 1, 1, 1, 0, 0, 1, 1, 0, 1024, 1, 0, 0, 0, 0, 0, 0, 1, 1, 0, 8},
+        {"wide: 3x3 split-K 4, tile 8",              2, 16, 16, 256, 128, 3, 3, 1, 1, 1, 1, 1, 0, 16, 16,  0, 0, 0, 1, 0, 0, 4, 1, 0, 8},
+        {"wide: ragged M = 1000, N = 136, tile 8",   5, 20, 10,  32, 136, 3, 3, 1, 1, 1, 1, 1, 0, 20, 10,  0, 0, 0, 0, 0, 0, 1, 1, 0, 8},
+        {"wide: ragged, tile 9",                     5, 20, 10,  32, 136, 3, 3, 1, 1, 1, 1, 1, 0, 20, 10,  0, 0, 0, 0, 0, 0, 1, 1, 0, 9},
+        {"wide: Cin = 16 (stays on 16-wide chunks)", 2, 16, 16,  16,  64, 3, 3, 1, 1, 1, 1, 1, 0, 16, 16,  0, 0, 0, 0, 0, 0, 1, 1, 0, 8},
+        {"wide: dilated 3x3 (2,2), LeakyReLU(A)",    2, 24, 24,  64, 128, 3, 3, 1, 2, 2, 2, 2, 0, 24, 24,  0, 2, 0, 0, 0, 0, 1, 1, 0, 8},
+    };
+    int bad = 0;
+    for (const Case& c : cases) bad += run_case(c, st, 12 | 256);
+    fprintf(stderr, "wide-chunk cases: %d of %d failed\n", bad, (int)(sizeof(cases) / sizeof(cases[0])));
+    return bad;
+}
+
 // ---- replay: the AED_OP_CONV_GEMM records of a whole U-Net forward (tools/dump_gemm_ops.py), each in both arithmetics ------
 struct Rec {
     std::string name;
@@ -530,8 +555,10 @@ int main(int argc, char** argv) {
         return run_replay(argv[3], iters, rs, x6only);
     }
     const bool pmc = argc > 2 && !strcmp(argv[2], "pmc");       // counter passes: two shapes, three variants, no feature matrix
+    if (argc > 2 && !strcmp(argv[2], "wide")) return run_wide_cases(st) ? 1 : 0;
     const int bad_cases = pmc ? 0 : run_feature_cases(st);
     if (argc > 2 && !strcmp(argv[2], "cases")) return bad_cases ? 1 : 0;
+    const bool quick = argc > 2 && !strcmp(argv[2], "quick");   // shapes x {tile 8, tile 9} x {16-wide, 32-wide chunks} only
 
     int shape_no = 0;
     for (const Shape& s : shapes) {
@@ -624,11 +651,14 @@ int main(int argc, char** argv) {
                s.name, M, N, K, ok ? "true" : "false", ms0 * 1e3, flops / (ms0 * 1e-3) * 1e-12, e0);
         fflush(stdout);
         // {tile, flags}: 4 = split-bf16 contraction; | 8 = interleave hints (what tapes set); | 16 = three-term diagnostic
-        const int variants[][2] = {{1, 12}, {8, 12}, {9, 12}, {2, 12}, {3, 12}, {4, 12}, {0, 12}, {1, 4}, {8, 4}, {1, 28}, {8, 28}};
-        auto vname = [](int fl) { return fl == 12 ? "" : (fl == 4 ? " no-hints" : (fl == 28 ? " x3-diagnostic" : " ?")); };
+        const int variants[][2] = {{1, 12}, {8, 12}, {8, 12 | 256}, {9, 12}, {9, 12 | 256}, {2, 12}, {3, 12}, {4, 12}, {0, 12}, {1, 4},
+                                   {8, 4}, {1, 28}, {8, 28}};
+        auto vname = [](int fl) { return fl == 12 ? "" : (fl == 4 ? " no-hints" : (fl == 28 ? " x3-diagnostic" : (fl == 268 ? " wide-chunks" : " ?"))); };
         for (const auto& v : variants) {
+            if (quick && !(v[0] == 8 || v[0] == 9) ) continue;
+            if (quick && !(v[1] == 12 || v[1] == 268)) continue;
             if (pmc && !((v[0] == 1 || v[0] == 8) && (v[1] == 12 || v[1] == 28))) continue;
-            if (s.lnglu && (v[1] != 12 || v[0] == 2 || v[0] == 4)) continue;      // GEGLU needs 64-wide wave tiles       // the non-PLAIN kernels exist in the product forms only
+            if (s.lnglu && ((v[1] != 12 && v[1] != 268) || v[0] == 2 || v[0] == 4)) continue;      // GEGLU needs 64-wide wave tiles       // the non-PLAIN kernels exist in the product forms only
             HIPCHECK(hipMemset(d.C1, 0xff, nC * 4));
             fill_op(op, s, d, d.C1, v[1], v[0]);
             const float ms1 = time_op(op, st, iters, &ok);

@@ -460,6 +460,29 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 1) void conv_gemm
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(CGParams p) {
     size_t total = (size_t)p.M * p.N;
+    if ((p.N & 3) == 0) {
+        // four consecutive columns per thread, the slabs' loads issued back to back (round 5: the scalar loop below was a chain of
+        // dependent 4-byte loads -- 5-8 us for a 128 x 640 output, as long as the split GEMM it finishes).  Same summation
+        // order per element (z ascending), so the two paths are bit-identical.
+        const size_t q4 = total >> 2;
+        const float4* ws4 = reinterpret_cast<const float4*>(p.ws);
+        for (size_t e4 = (size_t)blockIdx.x * 256 + threadIdx.x; e4 < q4; e4 += (size_t)gridDim.x * 256) {
+            float4 v = ws4[e4];
+#pragma unroll 4
+            for (int z = 1; z < p.ksplit; ++z) {
+                const float4 w = ws4[(size_t)z * q4 + e4];
+                v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+            }
+            const size_t e = e4 << 2;
+            const int m = (int)(e / p.N);
+            const int n = (int)(e - (size_t)m * p.N);
+            store_out(p, m, n, v.x);
+            store_out(p, m, n + 1, v.y);
+            store_out(p, m, n + 2, v.z);
+            store_out(p, m, n + 3, v.w);
+        }
+        return;
+    }
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
         int m = (int)(e / p.N);
         int n = (int)(e - (size_t)m * p.N);
@@ -612,7 +635,7 @@ int launch_conv_gemm(const aed_op* op, hipStream_t s) {
     AED_CHECK_HIP(hipGetLastError());
     if (p.ksplit > 1) {
         size_t total = (size_t)p.M * p.N;
-        int grid = (int)((total + 255) / 256);
+        int grid = (int)((((p.N & 3) == 0 ? total >> 2 : total) + 255) / 256);
         if (grid > 2048) grid = 2048;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, s, p);
         AED_CHECK_HIP(hipGetLastError());
@@ -625,7 +648,7 @@ int launch_splitk_reduce(const aed_op* op, hipStream_t s) {
     int rc = cg_fill_params(op, p, 32);
     if (rc) return rc;
     size_t total = (size_t)p.M * p.N;
-    int grid = (int)((total + 255) / 256);
+    int grid = (int)((((p.N & 3) == 0 ? total >> 2 : total) + 255) / 256);
     if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, s, p);
     AED_CHECK_HIP(hipGetLastError());

@@ -1,8 +1,8 @@
 // conv_gemm_x6.hip -- the implicit-GEMM convolution / linear layer of conv_gemm.hip with SPLIT-BF16 arithmetic.
 //
-// EXPERIMENTAL (round 3): selected per op by flag bit 2 of an AED_OP_CONV_GEMM record (include/aed.h); only tapes built under
-// tape.arith_mode("bf16x6") set it, no default path does.  Same record, same operands, same epilogue -- only the
-// contraction differs.
+// The product's arithmetic for the LDS-staged GEMMs since round 4 (built in round 3): selected per op by flag bit 2 of an
+// AED_OP_CONV_GEMM record (include/aed.h); tapes built under tape.arith_mode("bf16x6") -- every U-Net / DiT / codec engine by
+// default -- set it.  Same record, same operands, same epilogue as conv_gemm.hip -- only the contraction differs.
 //
 // Why: the fp32-input MFMA (v_mfma_f32_32x32x2_f32) runs at the fp32 VECTOR rate, 1/16 of the bf16 MFMA
 // (MI355X_MICROARCH.md: 157 TF vs 2.5 PF).  An fp32 value is exactly the sum of three bf16 values (24 significand bits
@@ -514,8 +514,13 @@ int launch_conv_gemm_x6(const aed_op* op, hipStream_t s) {
     }
     // flag bit 8 (256): wide chunks (BK = 32) on the 512-thread tiles 8 / 9, where two stages fill the CU's LDS; needs 32 | Cin
     const bool wide = (op->flags & 256) && (cfg == 8 || cfg == 9) && Cin % 32 == 0;
+    // flag bit 9 (512): DEEP prefetch on the 256-thread tiles 2 / 3 / 4 -- four 32-wide chunks in flight in registers (DEPTH 4 x
+    // BK 32) instead of two 16-wide ones.  The latency regime (U-Net batch 2: a handful of workgroups per CU stream megabytes of
+    // weights through K loops of 20-360 chunks) is bound by bytes in flight per workgroup, not by the matrix pipe: 24 KB in
+    // flight at ~2 us of loaded HBM latency is 12 GB/s per workgroup (round 5, profiles/r05_small_m.md).
+    const bool deep = (op->flags & 512) && (cfg == 2 || cfg == 3 || cfg == 4) && Cin % 32 == 0 && !(op->flags & 16);
     CGParams p;
-    int rc = cg_fill_params(op, p, wide ? 32 : X6_BK);
+    int rc = cg_fill_params(op, p, (wide || deep) ? 32 : X6_BK);
     if (rc) return rc;
     if (p.ksplit > (p.K + 31) / 32) p.ksplit = (p.K + 31) / 32;     // launch_splitk_reduce clamps with 32-wide chunks
     if (cfg == 0) {
@@ -533,9 +538,12 @@ int launch_conv_gemm_x6(const aed_op* op, hipStream_t s) {
     if (p.geglu) AED_REQUIRE(cfg == 1 || cfg == 3 || cfg == 8 || cfg == 9, "conv_gemm_x6: the GEGLU epilogue needs 64-wide wave tiles (cfg %d)", cfg);
     switch (cfg) {
         case 1: rc = x6_launch<128, 128, 2, 2, 2, true>(p, plain, sched, terms, s); break;
-        case 2: rc = x6_launch<128, 64, 2, 2, 2, false>(p, plain, sched, terms, s); break;
-        case 3: rc = x6_launch<64, 128, 2, 2, 2, false>(p, plain, sched, terms, s); break;
-        case 4: rc = x6_launch<64, 64, 2, 2, 2, false>(p, plain, sched, terms, s); break;
+        case 2: rc = deep ? x6_launch<128, 64, 2, 2, 4, false, 32>(p, plain, sched, terms, s)
+                          : x6_launch<128, 64, 2, 2, 2, false>(p, plain, sched, terms, s); break;
+        case 3: rc = deep ? x6_launch<64, 128, 2, 2, 4, false, 32>(p, plain, sched, terms, s)
+                          : x6_launch<64, 128, 2, 2, 2, false>(p, plain, sched, terms, s); break;
+        case 4: rc = deep ? x6_launch<64, 64, 2, 2, 4, false, 32>(p, plain, sched, terms, s)
+                          : x6_launch<64, 64, 2, 2, 2, false>(p, plain, sched, terms, s); break;
         case 8: rc = wide && terms == 6 ? x6_launch<256, 128, 4, 2, 2, false, 32>(p, plain, sched, terms, s)
                                         : x6_launch<256, 128, 4, 2, 2, true>(p, plain, sched, terms, s); break;
         case 9: rc = wide && terms == 6 ? x6_launch<128, 256, 2, 4, 2, false, 32>(p, plain, sched, terms, s)

@@ -47,6 +47,28 @@ def init_distributed(backend=None, force=False):
     return rank, world, local
 
 
+def pin_rank_resources(local_rank: int, world: int, threads: int = None, affinity: bool = True):
+    """Host-side budget of one rank on a node that runs `world` of them.  Per rank the clip pipeline
+    keeps <= 5 host threads busy (front / back / codec workers, the noise-prefetch thread, the caller) and <= 5 HIP queues
+    (inversion lane, edit lane(s), whole-chip fill / drain queue, side stream); torch's intra-op CPU pool (the per-clip RNG
+    draws, the host-side scheduler tables) would otherwise default to ALL cores in every rank.  Caps torch's intra-op threads
+    at cores / world (at least 1, at most 16; `threads` overrides) and, where the OS allows it, pins the process to the
+    rank's contiguous slice of the visible cores.  Returns what it did (bench.py prints it in `config.rank_resources`)."""
+    cores = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    per = max(1, len(cores) // max(1, world))
+    n = int(threads) if threads else max(1, min(16, per))
+    torch.set_num_threads(n)
+    pinned = None
+    if affinity and world > 1 and hasattr(os, "sched_setaffinity") and len(cores) >= world:
+        mine = cores[local_rank * per:(local_rank + 1) * per]
+        try:
+            os.sched_setaffinity(0, mine)
+            pinned = [mine[0], mine[-1]]
+        except OSError:
+            pinned = None
+    return dict(torch_threads=n, cores_visible=len(cores), cores_per_rank=per, affinity=pinned)
+
+
 def shard_clips(n_clips: int, rank: int, world: int) -> List[int]:
     """Round-robin clip -> rank map (clip i runs on rank i mod W)."""
     return list(range(rank, n_clips, world))

@@ -100,7 +100,8 @@ class ClipPipeline:
 
     def __init__(self, model, plan="partition", edit_cus=None, edit_lanes=1, lanes=None, launch="graph",
                  timestep_group=100, overlap_prep=True, lane_cus=None, separate_queues=None, codec_stage=None,
-                 widen_on_drain=True, edit_group=1, group_sizes=None, group_wait_s=0.0):
+                 widen_on_drain=True, edit_group=1, group_sizes=None, group_wait_s=0.0, codec_queue="front", steal=False,
+                 steal_min_remaining=4):
         if getattr(model, "kind", None) == "stable_audio":
             raise NotImplementedError("ClipPipeline drives the mel-latent families (AudioLDM / AudioLDM2 / TANGO)")
         if plan not in ("partition", "lanes"):
@@ -124,6 +125,18 @@ class ClipPipeline:
         self.group_sizes = sizes                # U-Net batch 2g engines exist for exactly these g (built by warm_up)
         self.group_log = []                     # sizes of the groups the last edit_clips formed
         self.group_wait_s = float(group_wait_s)  # how long a free lane waits for a FULL group before taking what is ready
+        # steal (round 5): an edit lane whose queue is empty takes the next UNSTARTED clip and runs its whole chain -- forward
+        # inversion included -- on its own CUs.  Once the split-K tables made the batch-2 step 13 ms on a 64-CU lane, the lanes
+        # (1.3 s per clip each) wait for the front stage (0.84 s per clip); a lane's idle 0.4 s per cycle cannot host another
+        # edit loop, but summed over a run it is whole clips: front-fed clips cost a lane 1.3 s, a stolen one 2.7 s (two batch-200
+        # forwards at ~0.7 s on 64 CUs), the optimum of that mix is +14 % over the front-bound rate.  A
+        # lane's inversion engines are built under the FRONT stage's tile regime: same tiles, same split-K orders, so a clip's
+        # values do not depend on who inverted it (bit-identical; tests/test_gpu_pipeline.py).  Not before `steal_min_remaining`
+        # unstarted clips are left: the tail of a run belongs to the front stage (a stolen clip takes 2.7 s, the front's 0.84 s
+        # + a widened edit loop).
+        self.steal = bool(steal) and plan == "partition" and self.edit_group == 1
+        self.steal_min_remaining = int(steal_min_remaining)
+        self.stolen = []                        # clips the lanes inverted themselves in the last edit_clips
         dev = model.device
         acquire = getattr(self.lane_type, "acquire", None)
 
@@ -147,9 +160,10 @@ class ClipPipeline:
             # overlaps the inversion still running on the partition (otherwise ~50 ms of set-up per clip sit exposed
             # between two inversions: `assert min(y) >= -1` alone drains the lane before anything else is enqueued).
             front_regime = None
-            for name, lo, hi in (("cus128", 96, 160), ("cus64", 48, 80)):       # tables swept on a stream of about that size
+            for name, lo, hi in (("cus128", 96, 160), ("cus64", 24, 80)):       # tables swept on a stream of about that size
                 if lo <= self.total - self.edit_cus <= hi and name in tape_mod.REGIME_TABLES:
                     front_regime = name
+            self._front_regime = front_regime
             front = [_Worker("front", 0, self._view(), Lane(dev, cus=range(self.edit_cus, self.total), total=self.total),
                              self.full, regime=front_regime, prep=Lane(dev, index=17) if overlap_prep else None)]
             # the edit loop's batch-2 kernels on half the chip are no longer purely latency-bound: their tiles come from
@@ -165,7 +179,7 @@ class ClipPipeline:
             self.edit_lane_cus = per or self.edit_cus
             lane_cus = (lambda k: range(k * per, (k + 1) * per)) if per else (lambda k: range(self.edit_cus))
             regime = None
-            for name, lo, hi in (("cus128", 96, 160), ("cus64", 48, 80)):       # tables swept on a stream of about that size
+            for name, lo, hi in (("cus128", 96, 160), ("cus64", 24, 80)):       # tables swept on a stream of about that size
                 if lo <= self.edit_lane_cus <= hi and name in tape_mod.REGIME_TABLES:
                     regime = name
             back = [_Worker("back", k, self._view(), Lane(dev, cus=lane_cus(k), total=self.total, index=k),
@@ -181,9 +195,15 @@ class ClipPipeline:
             if self.edit_group > 1 and not self.codec_stage:
                 raise ValueError("the group plan (edit_group > 1) hands every edited latent to the codec stage")
             self.stages = [("front", ("front",), front), ("back", ("back",), back)]
+            if codec_queue not in ("front", "chip"):
+                raise ValueError("codec_queue must be 'front' (the inversion partition's queue) or 'chip' (an unmasked queue)")
+            self.codec_queue = codec_queue
             if self.codec_stage:
                 front[0].prep = None
-                self.stages.append(("codec", ("codec",), [_Worker("codec", 0, self._view(), front[0].lane, None)]))
+                # "chip" (round 5 A/B): the codec jobs on an UNMASKED queue of their own -- 44 ms of throughput kernels per clip
+                # leave the inversion queue (the critical stage once the edit lanes got faster) and take whatever CU is free
+                cq = front[0].lane if codec_queue == "front" else Lane(dev, index=70)
+                self.stages.append(("codec", ("codec",), [_Worker("codec", 0, self._view(), cq, None)]))
             self.queue_log = []
             if separate_queues is None:
                 separate_queues = n > 1 or self.edit_group > 1
@@ -199,12 +219,14 @@ class ClipPipeline:
             # the inversion partition; the edit loop is issued in chunks of a few steps and moves there once the front
             # stage is done (editing.LoopPlumbing._replay_in_chunks).  Same engines, same graphs, same values.
             inv = self.total - self.edit_cus
-            if widen_on_drain and per and n > 1 and inv % n == 0 and (inv // n) % 32 == 0:
-                wper = inv // n
+            if widen_on_drain and per and n > 1 and inv % 32 == 0 and inv // 32 >= n:
+                # the inversion partition is handed out in 32-CU units (a legal mask gives every shader engine of every XCD the
+                # same number of CUs): lane k gets units // n of them, the first units % n lanes one more
+                units, lo = inv // 32, self.edit_cus
                 for k, w in enumerate(back):
-                    w.wide = Lane(dev, cus=list(lane_cus(k)) + list(range(self.edit_cus + k * wper,
-                                                                         self.edit_cus + (k + 1) * wper)),
-                                  total=self.total, index=50 + k)
+                    take = 32 * (units // n + (1 if k < units % n else 0))
+                    w.wide = Lane(dev, cus=list(lane_cus(k)) + list(range(lo, lo + take)), total=self.total, index=50 + k)
+                    lo += take
                 if separate_queues and hasattr(self.lane_type, "respin") and dev.type == "cuda":
                     # busy together in the drain: the inversion queue (codec jobs) and the widened lanes
                     from .streams import separate_queues as _separate
@@ -232,7 +254,7 @@ class ClipPipeline:
                 if self.timestep_group < 2:
                     raise ValueError("masked lanes run the timestep-batched inversion (timestep_group >= 2)")
             regime = None
-            for name, lo, hi in (("cus128", 96, 160), ("cus64", 48, 80)):
+            for name, lo, hi in (("cus128", 96, 160), ("cus64", 24, 80)):
                 if self.lane_cus is not None and lo <= self.lane_cus <= hi and name in tape_mod.REGIME_TABLES:
                     regime = name
             cus_of = (lambda k: None) if self.lane_cus is None else \
@@ -472,6 +494,8 @@ class ClipPipeline:
         """The worker's partition -- or the whole chip while no other stage has work (fill / drain)."""
         if w.full is None or len(self.stages) == 1:
             return w.lane
+        if stage_idx == 0 and self.steal:
+            return w.lane               # the lanes invert clips of their own from the first moment: no whole-chip fill
         with job["lock"]:
             if stage_idx == 0:
                 idle = job["busy"][1] == 0 and job["queues"][1].qsize() == 0
@@ -485,7 +509,11 @@ class ClipPipeline:
         guard = self._build_lock if not w.warm else contextlib.nullcontext()
         with guard, tape_mod.tile_regime(w.regime), torch.inference_mode(), self._on(w, lane) as st:
             if "front" in halves:
-                payload = self._front(w, st, job, i)
+                if w.stage == "back":       # a stolen clip: the lane's inversion engines take the FRONT stage's tiles (same values)
+                    with tape_mod.tile_regime(getattr(self, "_front_regime", None)):
+                        payload = self._front(w, st, job, i)
+                else:
+                    payload = self._front(w, st, job, i)
             if "back" in halves:
                 payload = self._back(w, st, job, payload, with_codec=not getattr(self, "codec_stage", False))
             if "codec" in halves:
@@ -555,11 +583,13 @@ class ClipPipeline:
             return self._run_group_worker(w, stage_idx, job)
         gate = job["gate"]
         v = w.view
-        if "front" in halves:
+        stealing = self.steal and w.stage == "back"
+        if "front" in halves or stealing:
             v.sample_xts_from_x0 = self._gated_sample(v, job)
         last_stage = stage_idx == len(self.stages) - 1
         try:
             while True:
+                run = halves
                 if stage_idx == 0:
                     with job["lock"]:
                         i = job["next"]
@@ -568,7 +598,19 @@ class ClipPipeline:
                         return
                     payload = None
                 else:
-                    got = job["queues"][stage_idx].get()
+                    got = None
+                    while got is None:
+                        try:
+                            got = job["queues"][stage_idx].get(timeout=0.005 if stealing else None)
+                        except queue.Empty:
+                            with job["lock"]:       # nothing to edit: take an unstarted clip, unless the run's tail has begun
+                                i = job["next"]
+                                take = len(job["items"]) - i >= self.steal_min_remaining and job["error"] is None
+                                if take:
+                                    job["next"] += 1
+                            if take:
+                                got, run = (i, None), ("front",) + tuple(halves)
+                                self.stolen.append(i)
                     if got is _STOP or job["error"] is not None:
                         return
                     i, payload = got
@@ -577,12 +619,13 @@ class ClipPipeline:
                     job["busy"][stage_idx] += 1
                 t0 = time.perf_counter()
                 try:
-                    payload = self._process(w, stage_idx, halves, job, i, payload, self._pick_lane(w, job, stage_idx))
+                    payload = self._process(w, stage_idx, run, job, i, payload,
+                                            w.lane if "front" in run and stage_idx else self._pick_lane(w, job, stage_idx))
                 except BaseException as e:                          # noqa: BLE001 -- reported by edit_clips
                     with job["lock"]:
                         if job["error"] is None:
                             job["error"] = (i, e)
-                    if "front" in halves:
+                    if "front" in run:
                         gate.done(i, failed=not v._clip_drew)
                     return
                 finally:
@@ -652,6 +695,7 @@ class ClipPipeline:
         self.stats, self._times = [], job["times"]
         self.widened = set()
         self.group_log = []
+        self.stolen = []
         if not job["items"]:
             return []
         self._base = None
@@ -690,10 +734,11 @@ class ClipPipeline:
                 job = self._job([item], [seed], prepare, a)
                 v = w.view
                 v._clip_index, v._clip_seed, v._clip_drew = 0, seed, False
-                if "front" in halves:
+                run = ("front",) + tuple(halves) if (self.steal and w.stage == "back") else halves
+                if "front" in run:
                     v.sample_xts_from_x0 = self._gated_sample(v, job)
                 try:
-                    outs.append(self._process(w, s, halves, job, 0, payload, w.lane))
+                    outs.append(self._process(w, s, run, job, 0, payload, w.lane))
                 finally:
                     v.__dict__.pop("sample_xts_from_x0", None)
             payload = outs[0]
@@ -725,6 +770,7 @@ class ClipPipeline:
                     queue_separation=getattr(self, "queue_log", None), timeline=timeline,
                     widened_on_drain=sorted(getattr(self, "widened", ())),
                     edit_group=self.edit_group, group_sizes=self.group_sizes, groups_formed=list(self.group_log),
+                    steal=self.steal, clips_inverted_by_edit_lanes=sorted(self.stolen),
                     drain_queue_separation=getattr(self, "drain_queue_log", None),
                     clip_latency_ms_avg=(sum(lats) / len(lats)) if lats else None,
                     clip_latency_ms_max=max(lats) if lats else None)

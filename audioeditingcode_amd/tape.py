@@ -29,6 +29,7 @@ GN_VARIANT = 0          # 1: never use the register-resident single-launch Group
 GN_FORCE_SMALL = 0      # 1: always take the single-launch GroupNorm when it fits
 LIN_MODE = 1            # 1: small contractions go to the latency-regime kernels of lin_gemm.hip
 LATE_EPILOGUE = 0       # 1: lin_gemm fetches the residual after its reduction (measured slower)
+WIDE_CHUNKS = 1         # 1: split-bf16 3x3 convolutions on the 512-thread tiles take 32-wide K chunks (flag bit 8); 0 = A/B
 # measured (tile, ksplit) per (M, N, K, geglu), filled from tools/tile_sweep.py runs (see tile_table.py)
 try:
     from .tile_table import TILE_TABLE
@@ -62,6 +63,15 @@ X6_TABLES = {}
 for _reg, _mod in ((None, "tile_table_x6"), ("cus128", "tile_table_x6_cus128"), ("cus64", "tile_table_x6_cus64")):
     try:
         X6_TABLES[_reg] = dict(__import__(f"{__package__}.{_mod}", fromlist=["TILE_TABLE"]).TILE_TABLE)
+    except ImportError:
+        pass
+# Round 5: the lockstep batch shapes of the group plan (U-Net batches 4 / 8 / 16 on an edit lane; pipeline.ClipPipeline
+# edit_group), swept on 64- and 96-CU streams (profiles/r05_sweeps/).  Keys are (M, N, K, geglu): a shape that also occurs at
+# batch 2 / 200 keeps the entry of the table it was first swept for.
+for _reg, _mod in (("cus128", "tile_table_x6_cus128_groups"), ("cus64", "tile_table_x6_cus64_groups")):
+    try:
+        for _k, _v in __import__(f"{__package__}.{_mod}", fromlist=["TILE_TABLE"]).TILE_TABLE.items():
+            X6_TABLES.setdefault(_reg, {}).setdefault(_k, _v)
     except ImportError:
         pass
 REGIME_CUS = {"cus128": 128, "cus64": 64}       # CUs of the stream a regime's engines run on
@@ -321,6 +331,10 @@ class Tape:
         elif x6_ok and tile in (1, 2, 3, 4):
             flags |= arith
             i[29] = x6_tile(M, N, tile, ksplit)
+        if flags & 4 and i[29] in (8, 9) and KH * KW > 1 and Cin % 32 == 0 and (x2 is None or C1 % 32 == 0) and WIDE_CHUNKS:
+            # wide chunks (two bf16 k-blocks per LDS stage and barrier; csrc/conv_gemm_x6.hip, flag bit 8): +3-4 % on the long-K
+            # 3x3 convolutions at the inversion's batch, nothing on the short-K Linears (profiles/r05_x6_wide_chunks.md)
+            flags |= 256
         idx = self._add(L.OP_CONV_GEMM, i, [in_slope, out_p, out_div, ln_eps, sm_scale],
                         [x, w, bias, out, res, rowvec, None, None, x2, kbias], name=name,
                         flops=2 * M * N * K if alg_flops is None else alg_flops, exec_flops=2 * M * N * K,

@@ -220,6 +220,13 @@ def main():
                     help="partition plan: an edit lane steps up to this many clips in lockstep (U-Net batch 2g for the g clips whose "
                          "inversions are ready when the lane becomes free; pipeline.ClipPipeline `edit_group`); 1 = every clip alone "
                          "in its U-Net batches (rounds 3-4)")
+    ap.add_argument("--steal", action="store_true",
+                    help="partition plan: an edit lane with an empty queue inverts the next unstarted clip itself "
+                         "(pipeline.ClipPipeline `steal`)")
+    ap.add_argument("--no-steal", action="store_true", help="switch --steal off where it is the default")
+    ap.add_argument("--codec-queue", default="front", choices=["front", "chip"],
+                    help="partition plan with a codec stage: VAE decode + vocoder on the inversion partition's queue (default) or on "
+                         "an unmasked queue of their own")
     ap.add_argument("--group-wait-ms", type=float, default=0.0,
                     help="group plan: how long a free edit lane waits for a full group before it takes the clips that are ready")
     ap.add_argument("--arith", default="bf16x6", choices=["f32", "bf16x6"],
@@ -258,6 +265,8 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but {world} rank(s) are running (n_gpus must equal the ranks that ran)"
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
+    # N ranks share the host: cap torch's intra-op CPU threads per rank and pin each rank to its slice of the cores
+    rank_resources = adist.pin_rank_resources(local, world) if world > 1 else dict(torch_threads=torch.get_num_threads())
 
     # ---- weights: rank 0 materialises them, everyone else receives them over RCCL
     fam = configs.get_family(args.model_id)
@@ -326,11 +335,15 @@ def main():
         mel, _, _ = view.get_fn_STFT().mel_spectrogram(wave)
         return mel[0].T[:1024][None, None].contiguous()
 
+    dt_local = 0.0
+
     def finish(t0, lat):
         """Close the timed region: gather, sync, barrier, max over ranks; refuse NaN / all-zero results."""
         local_lat = torch.cat(lat, 0)
         gathered = adist.gather_to_rank0(local_lat)
         torch.cuda.synchronize()
+        nonlocal dt_local
+        dt_local = time.perf_counter() - t0         # this rank's own time (before the barrier): `per_rank_clips_per_s`
         adist.barrier()
         dt = adist.max_over_ranks(time.perf_counter() - t0, dev)
         if gathered is not None:            # a fast clip of NaNs is not a result
@@ -388,7 +401,8 @@ def main():
             pipe = ClipPipeline(m, plan=PLAN, edit_cus=args.edit_cus, edit_lanes=args.edit_lanes, lanes=args.lanes,
                                 launch=args.lane_launch, timestep_group=args.group, overlap_prep=not args.no_overlap_prep,
                                 **({"lane_cus": args.lane_cus} if args.lane_cus else {}),
-                                **({"edit_group": args.edit_group, "group_wait_s": 1e-3 * args.group_wait_ms}
+                                **({"edit_group": args.edit_group, "group_wait_s": 1e-3 * args.group_wait_ms,
+                                    "codec_queue": args.codec_queue, "steal": args.steal and not args.no_steal}
                                    if PLAN == "partition" else {}))
             dt, gathered = timed_pipeline(args.steps, args.warmup)
         except Exception as e:                                  # noqa: BLE001
@@ -402,13 +416,13 @@ def main():
         if PLAN == "partition":
             lanes_txt = (f"{pipe.edit_lanes} edit loops on disjoint {pipe.edit_lane_cus}-CU lanes" if pipe.edit_lanes > 1 and
                          pipe.edit_lane_cus != pipe.edit_cus else f"{pipe.edit_lanes} edit loop(s) on {pipe.edit_cus} CUs")
-            grouped = getattr(pipe, "edit_group", 1) > 1
-            if grouped:
+            group_plan = getattr(pipe, "edit_group", 1) > 1
+            if group_plan:
                 lanes_txt += (f", each stepping up to {pipe.edit_group} clips in lockstep (U-Net batch 2g for the g clips whose "
                               f"inversions are ready; groups formed in this run: {extra['pipeline'].get('groups_formed')})")
             headline = (f"a STREAM of {args.steps} clips per GPU (throughput of the stream, not the latency of one clip: "
                         f"`value_single_clip_batched` is the clip alone), "
-                        + ("every clip alone in its inversion U-Net batches, " if grouped else
+                        + ("every clip alone in its inversion U-Net batches, " if group_plan else
                            f"up to {pipe.clips_in_flight} clips in flight, each alone in its U-Net batches: ")
                         + f"forward inversion ({args.group} timesteps per U-Net call) on {pipe.total - pipe.edit_cus} CUs beside {lanes_txt}"
                         + ("; VAE decode + vocoder as a third stage on the inversion partition's queue, between its inversions"
@@ -425,6 +439,13 @@ def main():
                     + (f" ({args.group} timesteps per U-Net call)" if args.schedule == "batched" else " (reference order)"))
         log(f"{args.schedule}: {dt / args.steps:.3f} s/clip")
     value = world * NC * args.steps / dt
+    # per-rank rates (the driver computes scaling efficiency from `value`; these show whether one rank lags)
+    per_rank = None
+    if grouped:
+        mine = torch.tensor([NC * args.steps / max(dt_local, 1e-9)], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(allr, mine)
+        per_rank = [float(t.item()) for t in allr]
 
     # ---- the same clips ONE AT A TIME (same waveforms, same seeds): reference order, and the timestep-batched inversion.
     # Every one of the 600 sample-forwards of a clip is computed in all three schedules; batched only regroups the
@@ -557,6 +578,7 @@ def main():
                           "parallelism": f"clip-dp{world}" + ("" if pipe_info is None else f" x {PLAN} pipeline"),
                           "arith": ARITH_TEXT[args.arith], "codec_arith": getattr(m, "codec_arith", "f32"),
                           "weights_broadcast_s": t_bcast if grouped else 0.0,
+                          "per_rank_clips_per_s": per_rank, "rank_resources": rank_resources,
                           "process_group": (torch.distributed.get_backend() if grouped else None),
                           "gathered_latents": None if gathered is None else [list(g.shape) for g in gathered][:2]},
                "roofline": roof, "cpu_baseline": base, "parity": parity, "phases_ms_one_clip_alone": phases}
@@ -632,7 +654,7 @@ def family_table(eng, ms, cu_frac=1.0):
             d.update(instruction_peak_tflops=f["peak"] * cu_frac, achieved_tflops=ach, frac=ach / (f["peak"] * cu_frac),
                      matrix_pipe_seconds_at_chip_peak=f["flops_executed"] / (f["peak"] * 1e12),
                      achieved_tflops_fp32_equiv=f["flops_fp32_equiv"] / (f["ms"] * 1e-3) / 1e12)
-        elif f["ms"] > 0:
+        elif f["ms"] > 0 and f["bytes"] > 0:
             gbs = f["bytes"] / (f["ms"] * 1e-3) / 1e9
             d.update(algorithmic_gb_per_s=gbs, hbm_peak_gb_per_s=PEAK_HBM_GBS * cu_frac, frac=gbs / (PEAK_HBM_GBS * cu_frac))
         out[name] = d
@@ -658,8 +680,9 @@ def _find_engine(views, B):
         ed = v.editor(256, 16)
         cand = sorted(((len(key), e) for key, e in ed._unets.items() if key[0] == B), key=lambda t: -t[0])
         if cand:
-            for pl in ed._plans.values():
-                pl["state"].zero_()            # the time-embedding op indexes the timestep table with the loop counter
+            with torch.inference_mode():
+                for pl in ed._plans.values():
+                    pl["state"].zero_()        # the time-embedding op indexes the timestep table with the loop counter
             return cand[0][1]
     return None
 

@@ -40,13 +40,15 @@ enum aed_opcode {
     AED_OP_CONV_GEMM = 1,     /* implicit-GEMM conv / linear on fp32 MFMA (K5,K6,K11,K2,K3); optional two-source A
                                  (skip concat never materialised), fused LayerNorm, fused GEGLU gate (K8).
                                  flags bit 0: in-kernel timeline into p[7]; bit 1: late epilogue fetch (lin_gemm A/B);
-                                 bit 2 (EXPERIMENTAL; set only by tapes built under tape.arith_mode("bf16x6")): contract on
-                                 split-bf16 MFMAs -- every fp32 operand is cut exactly into three bf16 pieces in the
+                                 bit 2 (the product's arithmetic since round 4; tapes built under tape.arith_mode("bf16x6")):
+                                 contract on split-bf16 MFMAs -- every fp32 operand is cut exactly into three bf16 pieces in the
                                  loader and the six piece products of relative size >= 2^-16 are accumulated in fp32
                                  (csrc/conv_gemm_x6.hip; as close to fp64 as the fp32 chain: tools/bf16_split_study.py,
                                  profiles/r03_x6_gemm.md; shapes that kernel does not take run the fp32 path);
                                  bit 3: with bit 2, interleave hints in the main loop (tapes set it; off = A/B);
                                  bit 4: with bit 2, three-term DIAGNOSTIC arithmetic (~4e-6 rel error);
+                                 bit 8 (256): with bit 2 on the 512-thread tiles 8 / 9, 32-wide K chunks -- two bf16 MFMA k-blocks
+                                 per LDS stage and barrier (needs 32 | Cin; other records ignore it);
                                  bit 6 (EXPERIMENT, tapes built under tape.arith_mode("fp8")): contract on the MX-FP8 matrix
                                  cores (csrc/conv_gemm_f8.hip: OCP microscaling e4m3, one e8m0 scale per 32 k of a row,
                                  quantised in the loader, v_mfma_scale_f32_32x32x64_f8f6f4, fp32 accumulate).  NOT a parity

@@ -130,7 +130,7 @@ class _Pipe:
     made = []
 
     def __init__(self, model, plan="partition", edit_cus=None, edit_lanes=1, lanes=None, launch="graph", timestep_group=100,
-                 overlap_prep=True, edit_group=1, group_wait_s=0.0):
+                 overlap_prep=True, edit_group=1, group_wait_s=0.0, codec_queue="front", steal=False):
         assert launch in ("eager", "graph") and plan in ("partition", "lanes")
         self.plan, self.total, self.edit_cus, self.edit_lanes = plan, 256, edit_cus, edit_lanes
         self.edit_group, self.group_sizes = edit_group, [1]

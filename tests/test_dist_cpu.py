@@ -69,3 +69,81 @@ def test_broadcast_shard_gather_world2():
     ref = weights.random_state_dict(weights.unet_param_shapes(configs.tiny_family("audioldm2")["unet"]), seed=3)
     from audioeditingcode_amd.dist import state_checksum
     assert ck0 == state_checksum(ref)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# bench-level world-size invariance: what `bench.py --gpus N` does per rank -- receive the weights from
+# rank 0, build the wrapper from them, edit the rank's share of the clips (clip i -> rank i mod W, per-clip seeds), gather the
+# edited latents on rank 0 -- on the CPU stack (tapes executed by oracle/tape_interp.py), world 2 against world 1.
+CLIPS, T_, TSTART_ = 4, 3, 2
+
+
+def _edit_share(rank, world, state_dicts):
+    """Edit this rank's clips with the product's wrapper (CPU test subclass) and return their latents in clip order."""
+    from _pytest.monkeypatch import MonkeyPatch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import install_cpu_stack
+    from audioeditingcode_amd import dist as adist, models
+    from audioeditingcode_amd.main_run import edit_clip
+    from audioeditingcode_amd.utils import load_audio, synthetic_clip
+    mpatch = MonkeyPatch()
+    install_cpu_stack(mpatch)
+
+    class CpuAudioLDM2(models.AudioLDM2Wrapper):
+        def _require_device(self):           # test instrumentation only: the product class refuses a CPU device
+            pass
+    torch.set_num_threads(2)
+    m = CpuAudioLDM2(model_id="tiny/audioldm2", device="cpu", state_dicts=state_dicts)
+    m.load_scheduler()
+    m.model.scheduler.set_timesteps(T_, device=None)
+    out = []
+    for i in adist.shard_clips(CLIPS, rank, world):
+        x0 = load_audio((synthetic_clip(seconds=0.32, seed=7 + i), 16000), m.get_fn_STFT(), device="cpu", stft=True)[0]
+        torch.manual_seed(40 + i)
+        out.append(edit_clip(m, x0, ["a dog barking"], ["a cat meowing"], [""], [3.0], [12.0], T_, TSTART_,
+                             schedule="batched", timestep_group=3)[2])
+    mpatch.undo()
+    return torch.cat(out, 0)
+
+
+def _family_state_dicts(seed_base=0):
+    from audioeditingcode_amd import configs, weights
+    fam = configs.get_family("tiny/audioldm2")
+    shapes = dict(unet=weights.unet_param_shapes(fam["unet"]), vae=weights.vae_param_shapes(fam["vae"]),
+                  vocoder=weights.vocoder_param_shapes(fam["vocoder"]))
+    return shapes, {k: weights.random_state_dict(shapes[k], seed=seed_base + i) for i, k in enumerate(shapes)}
+
+
+def _bench_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from audioeditingcode_amd import dist as adist
+    r, w, local = adist.init_distributed(backend="gloo")
+    adist.pin_rank_resources(local, w, threads=2)                     # per-rank thread cap + CPU affinity (bench.py does the same)
+    shapes, sds = _family_state_dicts()
+    sds = {k: adist.broadcast_state_dict(sds[k] if r == 0 else None, shapes[k], "cpu", max_bucket=400_000) for k in shapes}
+    lat = _edit_share(r, w, sds)
+    gathered = adist.gather_to_rank0(lat)
+    adist.barrier()
+    q.put((r, None if gathered is None else [g.numpy() for g in gathered]))
+
+
+def test_bench_level_world_size_invariance_world2_vs_world1():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[1] is None and len(res[0]) == 2
+    sys.path.insert(0, ROOT)
+    _, sds = _family_state_dicts()
+    one = _edit_share(0, 1, sds)                                      # world 1: the same four clips in this process
+    two = torch.empty_like(one)
+    two[0::2], two[1::2] = torch.from_numpy(res[0][0]), torch.from_numpy(res[0][1])          # clip i ran on rank i mod 2
+    assert torch.isfinite(two).all() and torch.equal(one, two)       # every clip's result is independent of the world size

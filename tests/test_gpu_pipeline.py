@@ -203,6 +203,59 @@ def test_group_plan_full_size_audioldm2_groups_of_four_vs_alone():
     pipe.close()
 
 
+def test_work_stealing_is_bit_identical_to_one_clip_at_a_time_tiny(monkeypatch):
+    """steal=True (round 5): an edit lane with an empty queue inverts the next unstarted clip on its own CUs, with inversion
+    engines built under the FRONT stage's tile regime -- so a clip's values do not depend on who inverted it: 8 clips through
+    128 | 2 x 64 CUs with a front stage slowed down on purpose (the lanes DO steal) == the same clips one at a time, bit for bit."""
+    import time
+    T, tstart, G = 10, 6, 5
+    m = models.load_model("tiny/audioldm2", DEV, T, seed=0)
+    wavs = [synthetic_clip(seconds=1.25, seed=7 + i) for i in range(8)]
+    to_mel = lambda view, wav: load_audio((wav, 16000), view.get_fn_STFT(), device=DEV, stft=True)[0]     # noqa: E731
+    mels = [to_mel(m, w) for w in wavs]
+    seeds = [40 + i for i in range(8)]
+    ref = _serial_b(m, mels, T, tstart, seeds, G)
+    pipe = ClipPipeline(m, plan="partition", edit_cus=128, edit_lanes=2, timestep_group=G, steal=True, steal_min_remaining=3)
+    pipe.warm_up(wavs[0], *ARGS, T, tstart, prepare=to_mel)
+    orig_front = pipe._front
+
+    def slow_front(w, st, job, i):
+        if w.stage == "front":
+            time.sleep(0.25)
+        return orig_front(w, st, job, i)
+    monkeypatch.setattr(pipe, "_front", slow_front)
+    got = pipe.edit_clips(wavs, *ARGS, T, tstart, seeds=seeds, prepare=to_mel)
+    rep = pipe.report()
+    stolen = rep["clips_inverted_by_edit_lanes"]
+    assert rep["steal"] and len(stolen) >= 1 and all(c <= 8 - 3 for c in stolen), stolen
+    for i, ((a, o, w), (a2, o2, w2)) in enumerate(zip(got, ref)):
+        assert torch.equal(w, w2), (i, stolen, float((w - w2).abs().max()))
+        assert torch.equal(a, a2) and torch.equal(o, o2), i
+    pipe.close()
+
+
+def test_work_stealing_full_size_audioldm2_values_do_not_depend_on_who_inverted():
+    """Full-size AudioLDM2 at a short schedule, 6 clips: with steal on (lanes on 64 CUs invert some clips with engines built
+    under the 128-CU front stage's tile regime) every clip is bit-identical to the same clip through the same pipeline alone
+    (front-inverted by construction)."""
+    T, tstart, G = 8, 4, 4
+    m = models.load_model("cvssp/audioldm2", DEV, T, allow_synthetic=True)
+    mels = [load_audio((synthetic_clip(seconds=10.0, seed=3 + i), 16000), m.get_fn_STFT(), device=DEV, stft=True)[0]
+            for i in range(6)]
+    seeds = [7 + i for i in range(6)]
+    pipe = ClipPipeline(m, plan="partition", edit_cus=128, edit_lanes=2, timestep_group=G, steal=True, steal_min_remaining=2)
+    pipe.warm_up(mels[0], *ARGS, T, tstart)
+    got = pipe.edit_clips(mels, *ARGS, T, tstart, seeds=seeds)
+    stolen = pipe.report()["clips_inverted_by_edit_lanes"]
+    alone = [pipe.edit_clips([x0], *ARGS, T, tstart, seeds=[s])[0] for x0, s in zip(mels, seeds)]
+    assert pipe.report()["clips_inverted_by_edit_lanes"] == []
+    print("full-size steal: clips inverted by the edit lanes:", stolen)
+    assert len(stolen) >= 1           # at T = 8 the lanes' edit loops are short: they are idle and take clips
+    for i, ((a, o, w), (a1, o1, w1)) in enumerate(zip(got, alone)):
+        assert torch.isfinite(w).all() and torch.equal(w, w1) and torch.equal(a, a1) and torch.equal(o, o1), (i, stolen)
+    pipe.close()
+
+
 def test_cu_masked_streams_census_and_results():
     """aed_stream_create_cu_mask: a contiguous range of 8k mask bits is k CUs on each of the 8 XCDs (aed_cu_census reads
     the hardware's XCC / SE / CU ids); a hipGraph replayed on a masked stream gives the same values as on a plain one."""

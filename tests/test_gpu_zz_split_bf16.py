@@ -115,6 +115,25 @@ def test_c_abi_harness_feature_matrix():
     assert max(row["rel_l2_vs_fp32_kernel"] for row in rows) < 5e-6
 
 
+def test_c_abi_harness_wide_chunk_cases():
+    """tools/x6_bench.cpp `wide`: the loader / epilogue modes again with op flag bit 8 (32-wide K chunks on the 512-thread
+    tiles 8 / 9, round 5) against the fp32 kernel: stride 2, upsampled grid, two-source A, SiLU / LeakyReLU of A, row vector,
+    residual, split-K, ragged edges, K = 96 (three chunks), Cin = 16 (stays on 16-wide chunks); then nine cases with flag bit 9
+    as well (deep prefetch: four 32-wide chunks in flight on the 256-thread tiles 2 / 3 / 4)."""
+    import json
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "audioeditingcode_amd", "x6_bench")
+    if not os.path.exists(exe):
+        pytest.skip("audioeditingcode_amd/x6_bench is built by __graft_entry__.build()")
+    r = subprocess.run([exe, "1", "wide"], capture_output=True, text=True, timeout=300)
+    rows = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith('{"case"')]
+    assert len(rows) == 14 + 9, (r.returncode, r.stderr[-400:])        # + the deep-prefetch cases (flag bit 9, tiles 2 / 3 / 4)
+    assert r.returncode == 0 and all(row["pass"] for row in rows), ([row for row in rows if not row["pass"]][:3], r.stderr[-400:])
+    assert [row["flags"] for row in rows] == [268] * 14 + [780] * 9
+    assert max(row["rel_l2_vs_fp32_kernel"] for row in rows) < 5e-6
+
+
 def _attention_pair(B, H, Nq, Nk, D, masked, qkv_packed, seed):
     """One attention record through the fp32 transposed-score kernel and the split-bf16 kernel (variant 3) over the same
     device operands; fp64 reference on the CPU.  qkv_packed: q / k / v are column slices of one [B*N, 3C] buffer (the

@@ -389,7 +389,8 @@ def test_arith_mode_marks_only_the_lds_staged_gemms():
         assert a.code == b.code == c.code == L.OP_CONV_GEMM and a.flags == c.flags == 0 and list(a.i) == list(c.i)
         assert list(a.i[:29]) == list(b.i[:29]) and list(a.i[30:]) == list(b.i[30:])
         by_name[mt["name"]] = (a.i[29], b.i[29], b.flags)
-    assert by_name["big3x3"] == (1, 1, 12) and by_name["huge3x3"] == (1, 8, 12)
+    # (round 5: a split-bf16 3x3 convolution on a 512-thread tile also carries flag bit 8 = 32-wide K chunks)
+    assert by_name["big3x3"] == (1, 1, 12) and by_name["huge3x3"] == (1, 8, 12 | 256)
     assert by_name["small"][0] >= 10 and by_name["small"][1:] == (by_name["small"][0], 0)
     assert by_name["cin8"][2] == 0 and by_name["cin8"][0] == by_name["cin8"][1]
     assert tape_mod.x6_tile(204800, 256, 1, 1) == 8 and tape_mod.x6_tile(2048, 256, 1, 1) == 1

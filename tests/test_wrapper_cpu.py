@@ -520,6 +520,44 @@ def test_clip_pipeline_group_plan_on_cpu(cpu_stack, monkeypatch):
         torch.set_num_threads(threads)
 
 
+def test_clip_pipeline_work_stealing_on_cpu(cpu_stack, monkeypatch):
+    """steal=True (round 5): an edit lane with an empty queue inverts the next unstarted clip itself; a clip's values do not
+    depend on who inverted it, the tail of the run stays with the front stage, every clip is edited exactly once."""
+    log = []
+    ClipPipeline = _fake_hip_for_pipeline(monkeypatch, log)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(2)
+    try:
+        T, tstart = 3, 2
+        m = _model(T)
+        mels = [load_audio((synthetic_clip(seconds=0.32, seed=7 + i), 16000), m.get_fn_STFT(), device="cpu", stft=True)[0]
+                for i in range(7)]
+        args = (["a dog barking"], ["a cat meowing"], [""], [3.0], [12.0], T, tstart)
+        serial = []
+        for i, x0 in enumerate(mels):
+            torch.manual_seed(40 + i)
+            serial.append(edit_clip(m, x0, *args, schedule="batched", timestep_group=3))
+        pipe = ClipPipeline(m, plan="partition", edit_cus=128, edit_lanes=2, timestep_group=3, steal=True, steal_min_remaining=3)
+        assert pipe.steal and not ClipPipeline(m, plan="partition", edit_cus=96, edit_group=2, timestep_group=3, steal=True).steal
+        pipe.warm_up(mels[0], *args)
+        back = [w for w in pipe.workers if w.stage == "back"]
+        for w in back:                          # a lane that may steal owns an inversion engine (U-Net batch 2 G) besides its edit engine
+            ed = w.view.editor(mels[0].shape[-2] // 4, mels[0].shape[-1] // 4)
+            assert sorted({k[0] for k in ed._plans}) == ["edit", "invert"]
+        got = pipe.edit_clips(mels, *args, seeds=[40 + i for i in range(7)])
+        rep = pipe.report()
+        stolen = rep["clips_inverted_by_edit_lanes"]
+        assert rep["steal"] and all(c <= 7 - 3 for c in stolen), stolen          # the last clips belong to the front stage
+        assert len(stolen) >= 1                  # (the CPU front stage is slow: the idle lanes do take clips)
+        for i, ((a, o, w), (a2, o2, w2)) in enumerate(zip(got, serial)):
+            assert torch.equal(w, w2) and torch.equal(a, a2) and torch.equal(o, o2), (i, stolen)
+        # one clip alone: nothing to steal
+        one = pipe.edit_clips(mels[:1], *args, seeds=[40])
+        assert pipe.report()["clips_inverted_by_edit_lanes"] == [] and torch.equal(one[0][2], serial[0][2])
+    finally:
+        torch.set_num_threads(threads)
+
+
 def test_export_model_images_on_cpu(monkeypatch, tmp_path):
     """image.export_model_images: the five engines of a wrapper (STFT, VAE encode, U-Net, VAE decode, vocoder) become five
     tape images whose named buffers have the engines' shapes; loaded into host memory, the STFT image's window / basis and

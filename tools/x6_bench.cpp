@@ -254,7 +254,22 @@ static int run_wide_cases(hipStream_t st) {
     int bad = 0;
     for (const Case& c : cases) bad += run_case(c, st, 12 | 256);
     fprintf(stderr, "wide-chunk cases: %d of %d failed\n", bad, (int)(sizeof(cases) / sizeof(cases[0])));
-    return bad;
+    // deep prefetch (flag bit 9) on the 256-thread tiles 2 / 3 / 4
+    const Case deep[] = {
+        {"deep: 3x3 same, tile 4",                   4, 32, 16,  64,  64, 3, 3, 1, 1, 1, 1, 1, 0, 32, 16,  0, 0, 0, 0, 0, 0, 1, 1, 0, 4},
+        {"deep: 3x3 two-source A, tile 3",           4, 32, 16, 192, 128, 3, 3, 1, 1, 1, 1, 1, 0, 32, 16, 64, 0, 0, 0, 0, 0, 1, 1, 0, 3},
+        {"deep: 1x1 two-source + residual, tile 2",  4, 32, 16, 128, 128, 1, 1, 1, 0, 0, 1, 1, 0, 32, 16, 64, 0, 0, 1, 0, 0, 1, 1, 0, 2},
+        {"deep: 3x3 SiLU(A) + row vector + res, t4", 4, 32, 16,  64,  64, 3, 3, 1, 1, 1, 1, 1, 0, 32, 16,  0, 1, 0, 1, 1, 0, 1, 1, 0, 4},
+        {"deep: linear K = 96 (3 chunks), tile 3",   1, 1024, 1,  96, 192, 1, 1, 1, 0, 0, 1, 1, 0, 1024, 1, 0, 0, 0, 0, 0, 0, 1, 1, 0, 3},
+        {"deep: linear K = 640, tile 2",             1,  128, 1, 640, 640, 1, 1, 1, 0, 0, 1, 1, 0,  128, 1, 0, 0, 0, 1, 0, 0, 1, 1, 0, 2},
+        {"deep: 3x3 split-K 8, 128 rows, tile 3",    2, 32,  2, 640, 640, 3, 3, 1, 1, 1, 1, 1, 0, 32,  2,  0, 0, 0, 1, 0, 0, 8, 1, 0, 3},
+        {"deep: 3x3 stride 2, tile 4",               4, 32, 16,  64, 128, 3, 3, 2, 1, 1, 1, 1, 0, 16,  8,  0, 0, 0, 0, 0, 0, 1, 1, 0, 4},
+        {"deep: ragged M = 1000, N = 136, tile 3",   5, 20, 10,  32, 136, 3, 3, 1, 1, 1, 1, 1, 0, 20, 10,  0, 0, 0, 0, 0, 0, 1, 1, 0, 3},
+    };
+    int bad2 = 0;
+    for (const Case& c : deep) bad2 += run_case(c, st, 12 | 256 | 512);
+    fprintf(stderr, "deep-prefetch cases: %d of %d failed\n", bad2, (int)(sizeof(deep) / sizeof(deep[0])));
+    return bad + bad2;
 }
 
 // ---- replay: the AED_OP_CONV_GEMM records of a whole U-Net forward (tools/dump_gemm_ops.py), each in both arithmetics ------
@@ -456,19 +471,31 @@ static int run_sweep(const char* path, int R, hipStream_t st, bool with_x6) {
         bool has_auto = false;
         for (int t : cand) has_auto |= t == r.tile_f32;
         if (!has_auto) cand.push_back(r.tile_f32);
+        // Round 5: split-K candidates (encoded as tile + 1000 * ksplit) for the small-M, long-K contractions -- U-Net level 2 / 3
+        // at the edit loop's batch: a 128-row 3x3 convolution streams up to 29 MB of weights through a handful of workgroups
+        // (~0.2 TB/s on a 64-CU lane).  K split across blockIdx.z gives every CU a slice of the weight stream; the partial slabs
+        // are summed in a fixed order by AED_OP_SPLITK_REDUCE (second launch).  Not for LayerNorm-fold / GEGLU records (unsplit).
+        // tile codes 200 + t: the split-bf16 kernel with op flag bits 8 | 9 (32-wide chunks, four of them in flight: "deep")
+        if (!generic && with_x6 && M <= 8192) for (int t : (geglu ? std::vector<int>{3} : std::vector<int>{2, 3, 4})) cand.push_back(200 + t);
+        if (!generic && !geglu && !i[31] && M <= 2048 && K >= 1024 && !i[27])
+            for (int t : (with_x6 ? std::vector<int>{4, 2, 104, 102, 103, 204, 202, 203} : std::vector<int>{4, 2}))
+                for (int ks : {2, 4, 8, 16, 32})
+                    if (K / 32 / ks >= 4 && (long)((M + 63) / 64) * ((N + 63) / 64) * ks <= 4096) cand.push_back(t + 1000 * ks);
         const size_t wbytes = (size_t)N * K * 4, step = (wbytes + 4095) / 4096 * 4096, span = POOL - wbytes - 4096;
         std::string all;
         double best_us = 1e30, auto_us = -1;
         int best_t = -1;
-        for (int t : cand) {
+        int best_ks = 1;
+        for (int tc : cand) {
+            const int t = tc % 1000, ks = tc >= 1000 ? tc / 1000 : 1;
             aed_op op;
             memset(&op, 0, sizeof(op));
             op.code = AED_OP_CONV_GEMM;
             memcpy(op.i, r.i, sizeof(op.i));
             memcpy(op.f, r.f, sizeof(r.f));
-            op.flags = t >= 100 ? 12 : 0;
+            op.flags = t >= 200 ? (12 | 256 | 512) : (t >= 100 ? 12 : 0);
             op.i[29] = t % 100;
-            op.i[28] = 1;
+            op.i[28] = ks;
             op.p[0] = A; op.p[2] = r.have[0] ? bias : nullptr; op.p[3] = C; op.p[4] = r.have[1] ? res : nullptr;
             op.p[5] = r.have[2] ? rv : nullptr; op.p[6] = ws; op.p[8] = r.have[3] ? A2 : nullptr;
             op.p[1] = pool;
@@ -494,19 +521,19 @@ static int run_sweep(const char* path, int R, hipStream_t st, bool with_x6) {
             }
             aed_graph_destroy(g);
             char buf[64];
-            snprintf(buf, sizeof(buf), "%s\"%d:1\": %.2f", all.empty() ? "" : ", ", t, us);
+            snprintf(buf, sizeof(buf), "%s\"%d:%d\": %.2f", all.empty() ? "" : ", ", t, ks, us);
             all += buf;
-            if (us < best_us) { best_us = us; best_t = t; }
-            if (t == r.tile_f32) auto_us = us;
+            if (us < best_us) { best_us = us; best_t = t; best_ks = ks; }
+            if (t == r.tile_f32 && ks == 1) auto_us = us;
         }
         if (best_t < 0) continue;
         tot_auto += count[q] * (auto_us > 0 ? auto_us : best_us);
         tot_best += count[q] * best_us;
         printf("%s {\"M\": %d, \"N\": %d, \"K\": %d, \"taps\": %d, \"geglu\": %d, \"ln\": %d, \"two_source\": %d, \"stride\": %d, "
-               "\"up\": %d, \"count\": %d, \"name\": \"%s\", \"flops\": %.0f, \"auto\": \"%d:1\", \"auto_us\": %.2f, \"best\": \"%d:1\", "
+               "\"up\": %d, \"count\": %d, \"name\": \"%s\", \"flops\": %.0f, \"auto\": \"%d:1\", \"auto_us\": %.2f, \"best\": \"%d:%d\", "
                "\"best_us\": %.2f, \"all\": {%s}}",
                q ? ",\n" : "", M, N, K, i[12] * i[13], geglu, i[31], i[32] > 0, i[14], i[19], count[q], r.name.c_str(),
-               2.0 * M * (double)N * K, r.tile_f32, auto_us, best_t, best_us, all.c_str());
+               2.0 * M * (double)N * K, r.tile_f32, auto_us, best_t, best_ks, best_us, all.c_str());
         fflush(stdout);
         fprintf(stderr, "%7d %5d %6d t%d g%d l%d x%3d  auto %3d %8.1f us | best %3d %8.1f us\n", M, N, K, i[12] * i[13], geglu, i[31],
                 count[q], r.tile_f32, auto_us, best_t, best_us);

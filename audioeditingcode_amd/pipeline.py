@@ -195,9 +195,19 @@ class ClipPipeline:
             if self.edit_group > 1 and not self.codec_stage:
                 raise ValueError("the group plan (edit_group > 1) hands every edited latent to the codec stage")
             self.stages = [("front", ("front",), front), ("back", ("back",), back)]
-            if codec_queue not in ("front", "chip"):
-                raise ValueError("codec_queue must be 'front' (the inversion partition's queue) or 'chip' (an unmasked queue)")
+            if codec_queue not in ("front", "chip", "lane"):
+                raise ValueError("codec_queue must be 'front' (the inversion partition's queue), 'chip' (an unmasked queue) or "
+                                 "'lane' (the edit lane that edited the clip)")
             self.codec_queue = codec_queue
+            if codec_queue == "lane":
+                # Round 5: with the split-K tables an edit lane needs 1.3 s per clip and gets one every 1.66 s (two lanes, front
+                # stage 0.83 s per clip): the lanes have the slack, the inversion queue has none.  The edited latent's VAE decode +
+                # two vocoder passes (44 ms on the whole chip, ~110 ms on 64 CUs) run on the lane that edited the clip, in stream
+                # order after its loop; no codec stage, and the next clip's set-up goes back to a side stream (round 3's
+                # overlap_prep) so that the inversion queue carries the two U-Net calls and little else.
+                if self.edit_group > 1:
+                    raise ValueError("the group plan hands its clips to a codec stage (codec_queue 'front' or 'chip')")
+                self.codec_stage = False
             if self.codec_stage:
                 front[0].prep = None
                 # "chip" (round 5 A/B): the codec jobs on an UNMASKED queue of their own -- 44 ms of throughput kernels per clip
@@ -426,7 +436,7 @@ class ClipPipeline:
         # beside a busy inversion partition: profiles/r03_codec_partition.md): they run unmasked, and the edit partition is
         # free for the next clip's set-up meanwhile
         cs = st
-        if w.full is not None and w.full.stream is not st:
+        if getattr(self, "codec_queue", "front") != "lane" and w.full is not None and w.full.stream is not st:
             cs = w.full.stream
             edited = self.event_type()
             edited.record(st)
@@ -608,11 +618,28 @@ class ClipPipeline:
                                 take = len(job["items"]) - i >= self.steal_min_remaining and job["error"] is None
                                 if take:
                                     job["next"] += 1
+                                    job["stealers"] += 1
                             if take:
                                 got, run = (i, None), ("front",) + tuple(halves)
                                 self.stolen.append(i)
                     if got is _STOP or job["error"] is not None:
                         return
+                    ev = got[1].get("done") if (stealing and run == halves and isinstance(got[1], dict)) else None
+                    if ev is not None and not ev.query():
+                        # the queued clip's inversion is still running on the front partition (the front worker's HOST thread
+                        # runs ahead of its queue): editing it now means waiting.  If no other lane is inverting a clip of its
+                        # own, hand the payload back and take an unstarted clip instead.
+                        with job["lock"]:
+                            i2 = job["next"]
+                            take = (len(job["items"]) - i2 >= self.steal_min_remaining and job["error"] is None
+                                    and job["stealers"] == 0)
+                            if take:
+                                job["next"] += 1
+                                job["stealers"] += 1
+                        if take:
+                            job["queues"][stage_idx].put(got)
+                            got, run = (i2, None), ("front",) + tuple(halves)
+                            self.stolen.append(i2)
                     i, payload = got
                 v._clip_index, v._clip_seed, v._clip_drew = i, job["seeds"][i], False
                 with job["lock"]:
@@ -631,6 +658,8 @@ class ClipPipeline:
                 finally:
                     with job["lock"]:
                         job["busy"][stage_idx] -= 1
+                        if stage_idx and "front" in run:
+                            job["stealers"] -= 1
                 job["times"].append(dict(clip=i, stage=w.stage, worker=w.k, start=t0 - job["t0"],
                                          end=time.perf_counter() - job["t0"]))
                 if last_stage:
@@ -671,7 +700,7 @@ class ClipPipeline:
         return dict(items=list(items), seeds=seeds, prepare=prepare, a=a, out=[None] * K, next=0, uniform=uniform,
                     prefetch={}, lock=threading.Lock(), error=None, gate=_DrawGate(), t0=time.perf_counter(), times=[],
                     queues=[queue.Queue() for _ in self.stages], busy=[0] * len(self.stages),
-                    stage_done=[False] * len(self.stages), front_event=None)
+                    stage_done=[False] * len(self.stages), front_event=None, stealers=0)
 
     def _args(self, source_prompt, target_prompt, target_neg_prompt, cfg_src, cfg_tar, T, tstart, eta):
         if len(source_prompt) != 1 or len(target_prompt) != 1:

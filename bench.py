@@ -224,9 +224,10 @@ def main():
                     help="partition plan: an edit lane with an empty queue inverts the next unstarted clip itself "
                          "(pipeline.ClipPipeline `steal`)")
     ap.add_argument("--no-steal", action="store_true", help="switch --steal off where it is the default")
-    ap.add_argument("--codec-queue", default="front", choices=["front", "chip"],
-                    help="partition plan with a codec stage: VAE decode + vocoder on the inversion partition's queue (default) or on "
-                         "an unmasked queue of their own")
+    ap.add_argument("--codec-queue", default="lane", choices=["front", "chip", "lane"],
+                    help="partition plan: where the edited latent's VAE decode + vocoder run -- 'lane' (default since round 5): on the "
+                         "edit lane that edited the clip (the lanes have the slack: 1.3 s of work per 1.66 s); 'front': a codec stage "
+                         "on the inversion partition's queue (round 4); 'chip': a codec stage on an unmasked queue of its own")
     ap.add_argument("--group-wait-ms", type=float, default=0.0,
                     help="group plan: how long a free edit lane waits for a full group before it takes the clips that are ready")
     ap.add_argument("--arith", default="bf16x6", choices=["f32", "bf16x6"],
@@ -426,7 +427,9 @@ def main():
                            f"up to {pipe.clips_in_flight} clips in flight, each alone in its U-Net batches: ")
                         + f"forward inversion ({args.group} timesteps per U-Net call) on {pipe.total - pipe.edit_cus} CUs beside {lanes_txt}"
                         + ("; VAE decode + vocoder as a third stage on the inversion partition's queue, between its inversions"
-                           if getattr(pipe, "codec_stage", False) else ""))
+                           if getattr(pipe, "codec_stage", False) else
+                           ("; VAE decode + vocoder on the edit lane that edited the clip, the next clip's set-up on a side stream"
+                            if getattr(pipe, "codec_queue", "") == "lane" else "")))
         elif args.lane_cus:
             headline = (f"{pipe.clips_in_flight} whole clips in flight per GPU, each on its own {args.lane_cus}-CU slice of the chip "
                         f"(timestep-batched inversion, {args.group} timesteps per U-Net call, then the edit loop)")

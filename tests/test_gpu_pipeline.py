@@ -203,6 +203,29 @@ def test_group_plan_full_size_audioldm2_groups_of_four_vs_alone():
     pipe.close()
 
 
+def test_codec_on_the_edit_lanes_is_bit_identical_to_one_clip_at_a_time_tiny():
+    """codec_queue="lane" (round 5, the bench's default): no codec stage -- the lane that edited a clip runs its VAE decode +
+    vocoder on its own 64-CU stream, the next clip's set-up runs on the front stage's side stream: latents and waveforms
+    equal the same clips one at a time, bit for bit."""
+    T, tstart, G = 10, 6, 5
+    m = models.load_model("tiny/audioldm2", DEV, T, seed=0)
+    wavs = [synthetic_clip(seconds=1.25, seed=7 + i) for i in range(5)]
+    to_mel = lambda view, wav: load_audio((wav, 16000), view.get_fn_STFT(), device=DEV, stft=True)[0]     # noqa: E731
+    mels = [to_mel(m, w) for w in wavs]
+    seeds = [40 + i for i in range(5)]
+    ref = _serial_b(m, mels, T, tstart, seeds, G)
+    pipe = ClipPipeline(m, plan="partition", edit_cus=128, edit_lanes=2, timestep_group=G, codec_queue="lane")
+    assert [w.stage for w in pipe.workers] == ["front", "back", "back"] and pipe.workers[0].prep is not None
+    pipe.warm_up(wavs[0], *ARGS, T, tstart, prepare=to_mel)
+    got = pipe.edit_clips(wavs, *ARGS, T, tstart, seeds=seeds, prepare=to_mel)
+    for i, ((a, o, w), (a2, o2, w2)) in enumerate(zip(got, ref)):
+        assert torch.equal(w, w2), (i, float((w - w2).abs().max()))
+        assert torch.equal(a, a2) and torch.equal(o, o2), i
+    rep = pipe.report()
+    assert rep["clips_in_flight"] == 3 and "codec_lane" not in rep["device_ms"]
+    pipe.close()
+
+
 def test_work_stealing_is_bit_identical_to_one_clip_at_a_time_tiny(monkeypatch):
     """steal=True (round 5): an edit lane with an empty queue inverts the next unstarted clip on its own CUs, with inversion
     engines built under the FRONT stage's tile regime -- so a clip's values do not depend on who inverted it: 8 clips through

@@ -315,6 +315,6 @@ def test_oracle_unet_matches_the_references_inline_forward_graphs():
             with torch.no_grad():
                 got = ounet.unet_forward(f["unet"], sd, x, torch.tensor(t), **ugc.oracle_kwargs(fam, cond),
                                          **ugc.hook_kwargs(g, fam, hook))
-            ugc.check(fam, size, hook, got, ugc.expected(g, fam, size, hook), 2e-6, rel)
+            ugc.check(fam, size, hook, got, ugc.expected(g, fam, size, hook), 2e-5, rel)   # fp32 rounding: the CPU thread count changes summation orders
             n += 1
     assert n == 24

@@ -520,6 +520,41 @@ def test_clip_pipeline_group_plan_on_cpu(cpu_stack, monkeypatch):
         torch.set_num_threads(threads)
 
 
+def test_clip_pipeline_codec_on_the_edit_lanes_on_cpu(cpu_stack, monkeypatch):
+    """codec_queue="lane" (round 5): no codec stage -- the lane that edited a clip decodes it (VAE decode + vocoder on the lane's
+    own stream), the next clip's set-up runs on the front stage's side stream; every clip equals the serial edit bit for bit."""
+    log = []
+    ClipPipeline = _fake_hip_for_pipeline(monkeypatch, log)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(2)
+    try:
+        T, tstart = 3, 2
+        m = _model(T)
+        mels = [load_audio((synthetic_clip(seconds=0.32, seed=7 + i), 16000), m.get_fn_STFT(), device="cpu", stft=True)[0]
+                for i in range(4)]
+        args = (["a dog barking"], ["a cat meowing"], [""], [3.0], [12.0], T, tstart)
+        serial = []
+        for i, x0 in enumerate(mels):
+            torch.manual_seed(40 + i)
+            serial.append(edit_clip(m, x0, *args, schedule="batched", timestep_group=3))
+        pipe = ClipPipeline(m, plan="partition", edit_cus=128, edit_lanes=2, timestep_group=3, codec_queue="lane")
+        assert [w.stage for w in pipe.workers] == ["front", "back", "back"] and not pipe.codec_stage
+        assert pipe.workers[0].prep is not None                      # the set-up of the next clip overlaps the running inversion
+        with pytest.raises(ValueError):
+            ClipPipeline(m, plan="partition", edit_cus=96, edit_group=2, timestep_group=3, codec_queue="lane")
+        with pytest.raises(ValueError):
+            ClipPipeline(m, plan="partition", edit_cus=96, timestep_group=3, codec_queue="somewhere")
+        pipe.warm_up(mels[0], *args)
+        log.clear()
+        got = pipe.edit_clips(mels, *args, seeds=[40 + i for i in range(4)])
+        for (a, o, w), (a2, o2, w2) in zip(got, serial):
+            assert torch.equal(a, a2) and torch.equal(o, o2) and torch.equal(w, w2)
+        lanes = {w.lane.stream.name for w in pipe.workers if w.stage == "back"}
+        assert lanes == {"cus0-63", "cus64-127"}
+    finally:
+        torch.set_num_threads(threads)
+
+
 def test_clip_pipeline_work_stealing_on_cpu(cpu_stack, monkeypatch):
     """steal=True (round 5): an edit lane with an empty queue inverts the next unstarted clip itself; a clip's values do not
     depend on who inverted it, the tail of the run stays with the front stage, every clip is edited exactly once."""

@@ -223,14 +223,23 @@ class EditEngine(LoopPlumbing):
     def _arith_for(self, B):
         return self.arith if B >= self.ARITH_MIN_BATCH else "f32"
 
-    def unet(self, B, L0=0, L1=0):
+    # CFG row sharing (unet.UNetEngine `share`): the loops below lay the batch out as [uncond | prompt_0 | ...] blocks that all
+    # carry the same x_t and timestep; with ONE clip per engine (n = 1) the blocks of a timestep are adjacent rows and the
+    # context-free head of the U-Net is computed once per timestep instead of once per row.  False = every row through the whole
+    # graph (rounds 1-4; A/B switch).
+    SHARE_CFG_ROWS = True
+
+    def unet(self, B, L0=0, L1=0, share=1):
         arith = self._arith_for(B)
+        share = int(share) if (self.SHARE_CFG_ROWS and share > 1 and self.kind != "audioldm") else 1
         key = (B, L0, L1) if arith == "f32" else (B, L0, L1, arith)
+        if share > 1:
+            key = key + (f"share{share}",)
         if key not in self._unets:
             with tape_mod.arith_mode(arith):
                 self._unets[key] = UNetEngine(self.cfg, self.weights, self.device, B, self.H, self.W, ctx_len0=L0,
                                               ctx_len1=L1, use_ehs=self.kind != "audioldm",
-                                              timesteps_dev=self.ts_dev, state_dev=self.state)
+                                              timesteps_dev=self.ts_dev, state_dev=self.state, share=share)
         return self._unets[key]
 
     def _set_cond(self, eng, groups, repeat=1):
@@ -377,7 +386,7 @@ class EditEngine(LoopPlumbing):
                 coef=torch.zeros((T, L.COEF_STRIDE), device=self.device, dtype=torch.float32),
                 cfgt=(torch.empty((max(P, 1), n, self.H, self.W, self.C), device=self.device, dtype=torch.float32)
                       if cfg_tensor is not None else None))
-            eng = plan["eng"] = self.unet(G * rows_per_t, L0, L1)
+            eng = plan["eng"] = self.unet(G * rows_per_t, L0, L1, share=(1 + P) if n == 1 else 1)
             pre, post = Tape(self.device), Tape(self.device)
             for g in range(G):
                 for blk in range(1 + P):
@@ -463,7 +472,7 @@ class EditEngine(LoopPlumbing):
                 coef=torch.zeros((Z, L.COEF_STRIDE), device=self.device, dtype=torch.float32),
                 cfgt=(torch.empty((P, n, self.H, self.W, self.C), device=self.device, dtype=torch.float32)
                       if cfg_tensor is not None else None))
-            eng = plan["eng"] = self.unet(n * (1 + P), L0, L1)
+            eng = plan["eng"] = self.unet(n * (1 + P), L0, L1, share=(1 + P) if n == 1 else 1)
             pre, post = Tape(self.device), Tape(self.device)
             for blk in range(1 + P):
                 pre.copy2d(plan["cur"], eng.x_in[blk * n:(blk + 1) * n], rows=1, cols=numel, ld_src=numel,

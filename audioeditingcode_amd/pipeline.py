@@ -343,38 +343,48 @@ class ClipPipeline:
             noise = torch.stack([torch.randn(shape, dtype=torch.float32) for _ in range(T)])
         return noise.pin_memory() if torch.cuda.is_available() else noise
 
+    def _claim_noise(self, job, index, shape, T, helper=False):
+        """Clip `index`'s T noise maps, drawn ONCE per job: whoever claims the index first -- the consumer itself or a helper
+        thread running ahead -- draws them at the clip's turn; everybody else waits for that draw.  (With one front lane there
+        is one claimant per clip anyway; with work stealing several lanes reach their draws concurrently, and two draws of one
+        clip would both pass the gate at its turn and interleave on the global generator.)"""
+        with job["lock"]:
+            box = job["prefetch"].get(index)
+            mine = box is None
+            if mine:
+                box = job["prefetch"][index] = dict(shape=tuple(shape), T=T, ready=threading.Event())
+        if mine:
+            def work():
+                try:
+                    box["noise"] = self._draw(job["gate"], index, job["seeds"][index], box["shape"], T)
+                except BaseException as e:                      # noqa: BLE001 -- re-raised by the consumer
+                    box["error"] = e
+                finally:
+                    box["ready"].set()
+            if helper:
+                threading.Thread(target=work, name=f"aed-noise-{index}", daemon=True).start()
+            else:
+                work()
+        return box
+
     def _gated_sample(self, view, job):
         """view.sample_xts_from_x0 with the clip's T draws taken from the global generator in clip order.  When every clip
         has the same shape, clip i+1's maps (40 ms of single-threaded CPU RNG for a 10 s clip) are drawn on a helper thread
         right after clip i's -- same generator, same order -- so they are ready when clip i+1 reaches this point."""
-        gate = job["gate"]
 
         def sample_xts_from_x0(x0, num_inference_steps=50):
             ed = view.editor(x0.shape[-2], x0.shape[-1])
             x = x0.reshape(1, *x0.shape[-3:])
             i, T = view._clip_index, int(num_inference_steps)
-            pre = job["prefetch"].pop(i, None)
-            if pre is not None:
-                pre["thread"].join()
-                if "error" in pre:
-                    raise pre["error"]
-                assert pre["shape"] == tuple(x.shape) and pre["T"] == T, "uniform clips were promised (prefetched noise)"
-                noise = pre["noise"]
-            else:
-                noise = self._draw(gate, i, view._clip_seed, tuple(x.shape), T)
+            box = self._claim_noise(job, i, x.shape, T)
+            box["ready"].wait()
+            if "error" in box:
+                raise box["error"]
+            assert box["shape"] == tuple(x.shape) and box["T"] == T, "uniform clips were promised (prefetched noise)"
+            noise, box["noise"] = box["noise"], None            # the maps are consumed once; the claim stays
             view._clip_drew = True
-            nxt = i + 1
-            if job["uniform"] and nxt < len(job["items"]) and nxt not in job["prefetch"]:
-                box = dict(shape=tuple(x.shape), T=T)
-
-                def work():
-                    try:
-                        box["noise"] = self._draw(gate, nxt, job["seeds"][nxt], box["shape"], T)
-                    except BaseException as e:                      # noqa: BLE001 -- re-raised by the consumer
-                        box["error"] = e
-                box["thread"] = threading.Thread(target=work, name=f"aed-noise-{nxt}", daemon=True)
-                job["prefetch"][nxt] = box
-                box["thread"].start()
+            if job["uniform"] and i + 1 < len(job["items"]):
+                self._claim_noise(job, i + 1, x.shape, T, helper=True)
             return ed.sample_xts(x, noise=noise)[:, 0]
         return sample_xts_from_x0
 

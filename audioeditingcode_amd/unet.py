@@ -147,8 +147,19 @@ class PackedUNetWeights:
 
 class UNetEngine:
     def __init__(self, cfg, weights, device, batch, H, W, ctx_len0=0, ctx_len1=0, use_ehs=True,
-                 timesteps_dev=None, state_dev=None, two_source=None):
+                 timesteps_dev=None, state_dev=None, two_source=None, share=1):
         self.cfg = cfg
+        # share = S > 1 (round 5, "CFG row sharing"): the caller promises that batch rows S*p .. S*p + S - 1 carry the SAME sample and
+        # timestep and differ only in their text context -- the [uncond | prompt ...] rows of one clip (inversion_utils.py:82-93 runs
+        # the U-Net once per row on `xt` / `xt.expand(...)`).  Everything upstream of the first module that reads the context --
+        # conv_in, the context-free down block(s), the first resnet and the double-self-attention transformer of the first attention
+        # site (AudioLDM2: cross_attention_dim [None, 768, 1024]) -- is then computed ONCE per group of S rows at batch B / S and
+        # its outputs (the stream and the skip tensors) are expanded to the full batch by strided copies: 12.3 of a sample
+        # forward's 172.4 GF, 3.6 % of a CFG pair.  Not for class-conditioned models (AudioLDM-1: the FiLM embedding enters every
+        # resnet).  `Tape.flops` keeps the algorithmic count of the full batch.
+        self.S = int(share) if (share and share > 1 and batch % int(share) == 0 and
+                                cfg.get("class_embed_type") is None) else 1
+        self.cB = batch             # batch of the module being laid out (batch / S inside the shared prefix)
         # Every LayerNorm is folded into the GEMM that consumes it and the GEGLU gate rides in the FF1 epilogue (the
         # standalone kernels were retired in ABI v4); up-block concats are read in place (no copy launches).
         self.two_source = TWO_SOURCE if two_source is None else two_source
@@ -167,11 +178,25 @@ class UNetEngine:
         self.tape = Tape(device)
         self.ctx_tape = Tape(device)
         self._tmp = {}
+        # ops laid out inside the shared prefix execute 1 / S of the reference formulation's work: `flops` (ALGORITHMIC, the
+        # reference's count for the full batch) is scaled back after the build, `exec_flops` stays what the kernels execute
+        self._prefix_idx = []
+        _add = self.tape._add
+
+        def counted_add(*a, **k):
+            idx = _add(*a, **k)
+            if self.cB != self.B:
+                self._prefix_idx.append(idx)
+            return idx
+        self.tape._add = counted_add
         if not isinstance(weights, PackedUNetWeights):
             weights = PackedUNetWeights(weights, device)
         self.weights = weights
         self.wd, self.temb_off, self.temb_total = weights.wd, weights.temb_off, weights.temb_total
         self._build()
+        del self.tape._add                          # back to the class method
+        for idx in self._prefix_idx:
+            self.tape.meta[idx]["flops"] *= self.S
 
     def tmp(self, tag, *shape):
         key = (tag, tuple(shape))
@@ -183,14 +208,15 @@ class UNetEngine:
     def _resnet(self, p, x, Cin, Cout, H, W, dest, groups, eps, x2=None, C1=0):
         """ResnetBlock2D.  x2/C1: the block input is the channel concat (x[..., :C1] | x2) of an up block
         (models.py:349-357), read in place by GroupNorm and the shortcut conv -- never materialised."""
-        tp, wd, B = self.tape, self.wd, self.B
+        tp, wd, B = self.tape, self.wd, self.cB
         h = self.tmp("res_h", B, H, W, Cout)
         off = self.temb_off[p + ".time_emb_proj"]
         a = self.tmp("gn_a", B, H, W, Cin)
         tp.groupnorm(x, wd[p + ".norm1.weight"], wd[p + ".norm1.bias"], a, B=B, HW=H * W, C=Cin, G=groups,
                      eps=eps, act=L.ACT_SILU, x2=x2, C1=C1, name=p + ".norm1")
         tp.conv(a, wd[p + ".conv1.weight"], wd[p + ".conv1.bias"], h, B=B, IH=H, IW=W, Cin=Cin, OH=H, OW=W, N=Cout,
-                KH=3, KW=3, pad_h=1, pad_w=1, rowvec=self.temb_all[:, off:off + Cout], ld_rv=self.temb_total,
+                KH=3, KW=3, pad_h=1, pad_w=1, rowvec=self.temb_all[:, off:off + Cout],
+                ld_rv=self.temb_total * (self.B // B),      # inside the shared prefix row p stands for full rows S*p ..: their temb
                 name=p + ".conv1")
         a2 = self.tmp("gn_a2", B, H, W, Cout)
         tp.groupnorm(h, wd[p + ".norm2.weight"], wd[p + ".norm2.bias"], a2, B=B, HW=H * W, C=Cout, G=groups,
@@ -215,7 +241,7 @@ class UNetEngine:
 
     def _attn(self, p, x, C, N, heads, out, kv=None, Lk=0, bias=None):
         """attention sub-layer: LayerNorm-folded input projections + fused attention.  x: [B*N, C] (raw, un-normalised)."""
-        tp, B = self.tape, self.B
+        tp, B = self.tape, self.cB
         M = B * N
         D = C // heads
         if kv is None:
@@ -233,7 +259,7 @@ class UNetEngine:
         return out
 
     def _transformer(self, p, x, C, H, W, heads, kind, dest, groups):
-        tp, wd, B = self.tape, self.wd, self.B
+        tp, wd, B = self.tape, self.wd, self.cB
         N = H * W
         M = B * N
         t0 = self.tmp("t_0", M, C)
@@ -270,7 +296,7 @@ class UNetEngine:
         """Folded cross-attention: latency regime only (lin_gemm kernels), key count a power of two <= 32 (one softmax
         group per head inside a 32-column tile), 64-row aligned batch items."""
         return (self.fold_xattn and Lk in (8, 16, 32) and N % 64 == 0 and (heads * Lk) % 32 == 0 and
-                self.B * N <= 4096 and C % 32 == 0)
+                self.cB * N <= 4096 and C % 32 == 0)
 
     def _folded_cross_attention(self, p, b, t1, kv, Lk, kbias, C, N, heads, x, dest):
         """Cross-attention over a SHORT, per-prompt-constant key set as two skinny GEMMs (exact algebra, no attention
@@ -279,7 +305,7 @@ class UNetEngine:
             t2[m]           = sum_(h,j) softmax_j(scores)[m,(h,j)] . (v_h[j] Wo_h^T) + bo + t1[m]
         G' = gamma o (k_h Wq_h) and VO = v_h Wo_h^T depend only on the prompt: they are built once per set_conditioning
         on the context tape (one small launch per block, AED_OP_XATTN_FOLD) and indexed per batch item by the lin_gemm kernels."""
-        tp, ct, wd, B = self.tape, self.ctx_tape, self.wd, self.B
+        tp, ct, wd, B = self.tape, self.ctx_tape, self.wd, self.cB
         base = b + ".attn2"
         self.weights.ensure_folded_cross_attention(base, heads)
         HL, D, M = heads * Lk, C // heads, B * N
@@ -325,9 +351,23 @@ class UNetEngine:
                 kind = "cross1"
             else:
                 kind = "cross0"
-            dest = self.tape.alloc(self.B, H, W, C)
+            if kind != "self2" and self.cB != self.B:
+                x = self._expand(x, H, W, C)                 # the first module that reads the text context: leave the shared prefix
+            dest = self.tape.alloc(self.cB, H, W, C)
             x = self._transformer(f"{prefix}.attentions.{k0 + j}", x, C, H, W, heads, kind, dest, groups)
         return x
+
+    def _expand(self, x, H, W, C, leave=True):
+        """[B/S, H, W, C] -> [B, H, W, C] with full row S*p + k = shared row p (S strided copies); `leave`: the builder continues at
+        the full batch."""
+        S, Bp = self.S, self.B // self.S
+        full = self.tape.alloc(self.B, H, W, C)
+        n = H * W * C
+        for k in range(S):
+            self.tape.copy2d(x, full[k:], rows=Bp, cols=n, ld_src=n, ld_dst=S * n, name="cfg_share.expand")
+        if leave:
+            self.cB = self.B
+        return full
 
     # ------------------------------------------------------------------ graph
     def _build(self):
@@ -388,30 +428,39 @@ class UNetEngine:
         tp.linear(self.emb, wd["temb_all.weight"], wd["temb_all.bias"], self.temb_all, M=B, K=emb_dim,
                   N=self.temb_total, in_act=L.ACT_SILU, name="time_emb_proj(all resnets)")
 
-        # ---- conv_in + down
-        h = tp.alloc(B, H, W, boc[0])
-        tp.conv(self.x_in, wd["conv_in.weight"], wd["conv_in.bias"], h, B=B, IH=H, IW=W, Cin=cin, OH=H, OW=W,
-                N=boc[0], KH=3, KW=3, pad_h=1, pad_w=1, name="conv_in")
-        skips = [(h, boc[0], H, W)]
+        # ---- conv_in + down.  With CFG row sharing the builder starts at batch B / S (row p reads x_in row S*p: the S rows of a
+        # group hold the same sample) and returns to the full batch at the first module that reads the text context (_site).
+        if self.S > 1 and not self.use_ehs:
+            self.S = 1                              # no context at all: nothing distinguishes the rows, the caller's batch stands
+        self.cB = Bc = B // self.S
+        h = tp.alloc(Bc, H, W, boc[0])
+        tp.conv(self.x_in, wd["conv_in.weight"], wd["conv_in.bias"], h, B=Bc, IH=H, IW=W, Cin=cin, OH=H, OW=W,
+                N=boc[0], KH=3, KW=3, pad_h=1, pad_w=1, a_bs=self.S * H * W * cin, name="conv_in")
+
+        def skip_of(t, c_, h_, w_):                 # a skip tensor is consumed at the full batch by the up blocks
+            return (t if self.cB == B else self._expand(t, h_, w_, c_, leave=False), c_, h_, w_)
+        skips = [skip_of(h, boc[0], H, W)]
         ch, hh, ww = boc[0], H, W
         for i, bt in enumerate(cfg["down_block_types"]):
             co = boc[i]
             for j in range(lpb):
-                d = tp.alloc(B, hh, ww, co)
+                d = tp.alloc(self.cB, hh, ww, co)
                 h = self._resnet(f"down_blocks.{i}.resnets.{j}", h, ch, co, hh, ww, d, groups, eps)
                 ch = co
                 if "CrossAttn" in bt:
                     h = self._site(f"down_blocks.{i}", j * len(ctx_pb[i]), h, co, hh, ww, heads_pb[i], ctx_pb[i],
                                    groups)
-                skips.append((h, ch, hh, ww))
+                skips.append(skip_of(h, ch, hh, ww))
             if i < nb - 1:
                 oh, ow = (hh + 2 - 3) // 2 + 1, (ww + 2 - 3) // 2 + 1
-                d = tp.alloc(B, oh, ow, co)
+                d = tp.alloc(self.cB, oh, ow, co)
                 p = f"down_blocks.{i}.downsamplers.0.conv"
-                tp.conv(h, wd[p + ".weight"], wd[p + ".bias"], d, B=B, IH=hh, IW=ww, Cin=co, OH=oh, OW=ow, N=co,
+                tp.conv(h, wd[p + ".weight"], wd[p + ".bias"], d, B=self.cB, IH=hh, IW=ww, Cin=co, OH=oh, OW=ow, N=co,
                         KH=3, KW=3, stride=2, pad_h=1, pad_w=1, name=p)
                 h, hh, ww = d, oh, ow
-                skips.append((h, ch, hh, ww))
+                skips.append(skip_of(h, ch, hh, ww))
+        if self.cB != B:                            # no module read the context on the way down (never the case for the three families)
+            h = self._expand(h, hh, ww, ch)
 
         # ---- mid
         d = tp.alloc(B, hh, ww, ch)

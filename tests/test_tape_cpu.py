@@ -451,3 +451,47 @@ def test_attention_records_under_bf16x6_flag_and_lane_rule():
     assert rec(200, 1024, 32, "cus128", "bf16x6") == (4, 3)       # the inversion's batch
     assert rec(2, 1024, 32, "cus64", "f32") == (0, 0)
     assert rec(8, 64, 80, "cus64", "bf16x6") == (4, 0)            # <= 64 keys: single-pass kernel; d_head 80 not in the split kernel
+
+
+def test_cfg_row_sharing_computes_the_context_free_head_once(monkeypatch):
+    """unet.UNetEngine(share=S) (round 5): rows S*p .. S*p+S-1 carry the same sample and timestep ([uncond | prompt] rows of one
+    clip); conv_in, the context-free down block, the first resnet and the double-self-attention transformer of the first site are
+    laid out at batch B / S and expanded -- same values as the full-batch engine on the interpreter, fewer executed flops, the
+    ALGORITHMIC flop count unchanged; class-conditioned models (AudioLDM-1) and hook engines never share."""
+    from audioeditingcode_amd import configs, weights
+    from audioeditingcode_amd.tape import Tape
+    from audioeditingcode_amd.unet import UNetEngine
+    from oracle import tape_interp, unet as ounet
+    monkeypatch.setattr(Tape, "run", tape_interp.run_tape)
+    g = torch.Generator().manual_seed(1)
+    for kind, L0, L1 in (("audioldm2", 8, 5), ("tango", 6, 0)):
+        fam = configs.tiny_family(kind)
+        cfg = fam["unet"]
+        sd = weights.random_state_dict(weights.unet_param_shapes(cfg), seed=0)
+        B, H, W, S = 6, 32, 16, 2
+        x = torch.randn(B // S, H, W, 8, generator=g).repeat_interleave(S, 0)        # rows 2p, 2p+1 hold the same sample
+        if kind == "audioldm2":
+            cond = dict(ehs0=torch.randn(B, L0, fam["ctx"]["gpt2_dim"], generator=g),
+                        ehs1=torch.randn(B, L1, fam["ctx"]["t5_dim"], generator=g), bias1=torch.zeros(B, L1))
+        else:
+            cond = dict(ehs0=torch.randn(B, L0, fam["ctx"]["t5_dim"], generator=g), bias0=torch.zeros(B, L0))
+        outs, engs = [], []
+        for share in (1, S):
+            eng = UNetEngine(cfg, sd, "cpu", B, H, W, ctx_len0=L0, ctx_len1=L1, share=share)
+            eng.set_conditioning(**cond)
+            eng.x_in.copy_(x)
+            eng.set_timestep(501)
+            eng.forward()
+            outs.append(eng.eps.clone())
+            engs.append(eng)
+        full, shared = engs
+        assert shared.S == S and full.S == 1
+        assert torch.allclose(outs[0], outs[1], rtol=0, atol=2e-6 * float(outs[0].abs().max()))
+        assert shared.tape.flops == full.tape.flops                       # algorithmic work: the reference's count
+        saved = 1 - shared.tape.exec_flops / full.tape.exec_flops
+        assert (0.02 < saved < 0.08) if kind == "audioldm2" else (0.0 < saved < 0.05), (kind, saved)
+        assert sum(1 for m in shared.tape.meta if m["name"] == "cfg_share.expand") >= 2 * S
+        assert all(tuple(a.shape) == tuple(b.shape) for a, b in zip(full.skips, shared.skips))     # hooks see full-batch skips
+    fam = configs.tiny_family("audioldm")
+    sd = weights.random_state_dict(weights.unet_param_shapes(fam["unet"]), seed=0)
+    assert UNetEngine(fam["unet"], sd, "cpu", 4, 32, 16, use_ehs=False, share=2).S == 1        # FiLM embedding differs per row

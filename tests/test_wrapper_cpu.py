@@ -593,6 +593,42 @@ def test_clip_pipeline_work_stealing_on_cpu(cpu_stack, monkeypatch):
         torch.set_num_threads(threads)
 
 
+def test_noise_maps_of_a_clip_are_drawn_once_whoever_asks():
+    """ClipPipeline._claim_noise: several lanes (and the helper thread running one clip ahead) may ask for the same clip's noise
+    maps at the same moment; exactly one of them draws, at the clip's turn in the global draw order, and every asker sees that
+    draw.  (Two draws of one clip would both pass the order gate and interleave on the global generator -- what the full-size
+    work-stealing test caught on the MI355X in round 5.)"""
+    import threading
+    from audioeditingcode_amd.pipeline import ClipPipeline, _DrawGate
+    K, T, shape = 6, 5, (1, 2, 8, 4)
+    seeds = [90 + i for i in range(K)]
+    want = []
+    for s in seeds:
+        torch.manual_seed(s)
+        want.append(torch.stack([torch.randn(shape) for _ in range(T)]))
+    job = dict(prefetch={}, lock=threading.Lock(), gate=_DrawGate(), seeds=seeds)
+    pipe = ClipPipeline.__new__(ClipPipeline)
+    got, errs = {}, []
+
+    def asker(i, helper):
+        try:
+            box = pipe._claim_noise(job, i, shape, T, helper=helper)
+            box["ready"].wait(timeout=30)
+            got.setdefault(i, []).append(box)
+        except BaseException as e:               # noqa: BLE001
+            errs.append(e)
+    threads = [threading.Thread(target=asker, args=(i, h)) for i in reversed(range(K)) for h in (False, True, False)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=60)
+    assert not errs and all(not t.is_alive() for t in threads)
+    for i in range(K):
+        assert len(got[i]) == 3 and all(b is got[i][0] for b in got[i])              # one claim per clip
+        assert "error" not in got[i][0] and torch.equal(got[i][0]["noise"], want[i]), i
+    assert job["gate"].next == K
+
+
 def test_export_model_images_on_cpu(monkeypatch, tmp_path):
     """image.export_model_images: the five engines of a wrapper (STFT, VAE encode, U-Net, VAE decode, vocoder) become five
     tape images whose named buffers have the engines' shapes; loaded into host memory, the STFT image's window / basis and

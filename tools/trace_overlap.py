@@ -69,23 +69,52 @@ for q, v in sorted(rows.items(), key=lambda kv: -len(kv[1])):
     top = ", ".join(f"`{n}` {t / 1e6:.1f}" for n, t in by.most_common(3))
     info[q] = dict(u=u, busy=busy, names=by, n=len(v))
     print(f"| {q} | {len(v)} | {busy / 1e6:.1f} | {(v[0][0] - t_min) / 1e6:.0f}..{(max(e for _, e, _ in v) - t_min) / 1e6:.0f} | {top} |")
+# ---- the pipeline's queues by role (round 5: one inversion queue, SEVERAL edit lanes)
 front = max((q for q in info if info[q]["names"].get("invert_step_kernel")), key=lambda q: info[q]["names"]["invert_step_kernel"], default=None)
-back = max((q for q in info if info[q]["names"].get("reverse_step_kernel") and q != front),
-           key=lambda q: info[q]["names"]["reverse_step_kernel"], default=None)
-if front is None or back is None:
-    print("\nno queue pair with invert_step_kernel / reverse_step_kernel found (not a partition-pipeline trace?)")
+lanes = sorted((q for q in info if info[q]["names"].get("reverse_step_kernel") and q != front),
+               key=lambda q: -info[q]["names"]["reverse_step_kernel"])
+lanes = [q for q in lanes if info[q]["names"]["reverse_step_kernel"] >= 0.05 * info[lanes[0]]["names"]["reverse_step_kernel"]] if lanes else []
+if front is None or not lanes:
+    print("\nno queue set with invert_step_kernel / reverse_step_kernel found (not a partition-pipeline trace?)")
     sys.exit(0)
-both = intersect(info[front]["u"], info[back]["u"])
-fb, bb = info[front]["busy"], info[back]["busy"]
-print(f"\n## both kernel classes resident at once\n")
-print(f"* queue {front} = front stage (inversion at U-Net batch 2G: `conv_gemm_kernel<128, 128, ...>`, `attention_t_kernel<D, 1>`, "
-      f"`invert_step_kernel`), busy {fb / 1e6:.1f} ms;")
-print(f"* queue {back} = back stage (edit loop at U-Net batch 2: `lin_gemm_kernel<...>`, `gn_small`, `attention_t_kernel<D, 4>`, "
-      f"`reverse_step_kernel`), busy {bb / 1e6:.1f} ms;")
-print(f"* **{both / 1e6:.1f} ms with a kernel of BOTH queues in flight** = {100 * both / bb:.1f} % of the back stage's busy time, "
-      f"{100 * both / fb:.1f} % of the front stage's, {100 * both / (t_max - t_min):.1f} % of the traced wall time.")
+
+
+def steps(q, name):
+    return sum(1 for _, _, n in rows[q] if n.startswith(name))
+
+
+print("\n## the pipeline's queues\n")
+fb = info[front]["busy"]
+print(f"* queue {front} = front stage (inversion at U-Net batch 2G: `conv_gemm_x6_kernel<256|128, ...>`, `attention_x6_kernel`, "
+      f"`invert_step_kernel`): busy {fb / 1e6:.1f} ms, {steps(front, 'invert_step_kernel')} inversion step kernels;")
+for q in lanes:
+    bb = info[q]["busy"]
+    both = intersect(info[front]["u"], info[q]["u"])
+    print(f"* queue {q} = edit lane (batch-2 loop: `lin_gemm_kernel`, small `conv_gemm_x6_kernel` tiles, `reverse_step_kernel`): busy "
+          f"{bb / 1e6:.1f} ms, {steps(q, 'reverse_step_kernel')} edit steps; **{both / 1e6:.1f} ms with a kernel of this lane AND the "
+          f"front stage in flight** = {100 * both / bb:.1f} % of the lane's busy time;")
+if len(lanes) >= 2:
+    l01 = intersect(info[lanes[0]]["u"], info[lanes[1]]["u"])
+    # all three: intersect the pairwise-intersection intervals with the front's
+    ab, i, j = [], 0, 0
+    a, b = info[lanes[0]]["u"], info[lanes[1]]["u"]
+    while i < len(a) and j < len(b):
+        s_, e_ = max(a[i][0], b[j][0]), min(a[i][1], b[j][1])
+        if e_ > s_:
+            ab.append((s_, e_))
+        if a[i][1] < b[j][1]:
+            i += 1
+        else:
+            j += 1
+    all3 = intersect(ab, info[front]["u"])
+    print(f"* the two edit lanes together: {l01 / 1e6:.1f} ms with a kernel of BOTH in flight; front stage + both lanes: "
+          f"**{all3 / 1e6:.1f} ms = {100 * all3 / (t_max - t_min):.1f} % of the traced wall time** with three kernels resident at once.")
+wall = (t_max - t_min) / 1e6
+print(f"* busy fractions of the traced wall time ({wall:.0f} ms, fill / warm-up / drain included): front {100 * fb / 1e6 / wall:.1f} %, "
+      + ", ".join(f"lane {q} {100 * info[q]['busy'] / 1e6 / wall:.1f} %" for q in lanes) + ".")
 # a concrete pair: the longest inversion kernel and the edit kernels that ran entirely inside it
 fv = sorted(rows[front], key=lambda x: x[0] - x[1])[0]
-inside = [(s, e, n) for s, e, n in rows[back] if s >= fv[0] and e <= fv[1]]
-print(f"* example: `{fv[2]}` on queue {front} ran for {(fv[1] - fv[0]) / 1e3:.0f} us; {len(inside)} kernels of queue {back} started "
+inside = [(s_, e_, n) for s_, e_, n in rows[lanes[0]] if s_ >= fv[0] and e_ <= fv[1]]
+print(f"* example: `{fv[2]}` on queue {front} ran for {(fv[1] - fv[0]) / 1e3:.0f} us; {len(inside)} kernels of queue {lanes[0]} started "
       f"and finished inside that interval" + (f" (e.g. `{inside[0][2]}`, {(inside[0][1] - inside[0][0]) / 1e3:.1f} us)." if inside else "."))
+# per-clip device time of each stage from the step kernels: an inversion = 2 runs of invert_step kernels, an edit loop = 100 steps

@@ -35,15 +35,24 @@ def family(n):
     return "other"
 
 
+PEAK_BF16 = 2500.0
+
+
 def tape_flops(B):
+    """(algorithmic GEMM flops, algorithmic forward flops, #ops, executed fp32-equivalent flops of the records the split-bf16
+    kernel takes, ... of the records on fp32-input MFMAs) of the U-Net tape at batch B, laid out on the CPU in the product's
+    arithmetic (tape.arith_mode("bf16x6"), whole-chip tile tables)."""
     import torch
-    from audioeditingcode_amd import configs, weights
+    from audioeditingcode_amd import configs, tape as tape_mod, weights
     from audioeditingcode_amd.unet import UNetEngine
     fam = configs.FAMILIES["audioldm2"]
     sd = {k: torch.zeros(s) for k, s in weights.unet_param_shapes(fam["unet"]).items()}
-    eng = UNetEngine(fam["unet"], sd, "cpu", B, 256, 16, ctx_len0=8, ctx_len1=16)
+    with tape_mod.arith_mode("bf16x6"):
+        eng = UNetEngine(fam["unet"], sd, "cpu", B, 256, 16, ctx_len0=8, ctx_len1=16)
     conv = sum(m["flops"] for m in eng.tape.meta if m["code"] == 1)
-    return conv, eng.tape.flops, len(eng.tape.ops)
+    x6 = sum(m["exec_flops"] for op, m in zip(eng.tape.ops, eng.tape.meta) if m["code"] == 1 and (op.flags & 4) and op.i[29] < 10)
+    f32 = sum(m["exec_flops"] for op, m in zip(eng.tape.ops, eng.tape.meta) if m["code"] == 1 and not ((op.flags & 4) and op.i[29] < 10))
+    return conv, eng.tape.flops, len(eng.tape.ops), x6, f32
 
 
 rows = []
@@ -81,7 +90,7 @@ print(f"{len(rows)} dispatches, {sum(e - s for s, e, _ in rows) / 1e6:.1f} ms of
       f"{len(segs)} step segments, classes with a full U-Net forward:\n")
 for (kind, nstep), lst in classes.items():
     B = 2 * nstep
-    conv_fl, all_fl, n_ops = tape_flops(B)
+    conv_fl, all_fl, n_ops, x6_fl, f32_fl = tape_flops(B)
     n = len(lst)
     launches = sum(len(k) for k in lst) / n
     busy = sum(sum(e - s for s, e, _ in k) for k in lst) / n / 1e6
@@ -106,6 +115,18 @@ for (kind, nstep), lst in classes.items():
         if fm.startswith("gemm"):
             extra = f" ({conv_fl / (t / n) / 1e9:.1f} TFLOP/s algorithmic = {conv_fl / (t / n) / 1e9 / PEAK:.3f} of peak)"
         print(f"| {fm}{extra} | {c / n:.0f} | {t / n:.3f} | {100 * t / n / busy:.1f} % | {1e3 * t / c:.2f} |")
+    # PHYSICAL fractions (round 5): executed MFMA flops of a kernel class over the peak of the instruction it issues
+    t_x6 = sum(t for nm, (c, t) in ker_t.items() if nm.startswith("conv_gemm_x6")) / n
+    t_f32 = sum(t for nm, (c, t) in ker_t.items() if nm.startswith("conv_gemm_kernel") or nm.startswith("lin_gemm") or
+                nm.startswith("splitk_reduce")) / n
+    if t_x6 > 0:
+        print(f"\n* `conv_gemm_x6_kernel<*>` (v_mfma_f32_32x32x16_bf16, six piece products per fp32 product): {x6_fl / 1e9:.1f} GF "
+              f"fp32-equivalent per segment = {6 * x6_fl / 1e12:.2f} TF of executed bf16 MFMA flops in {t_x6:.3f} ms -> "
+              f"**{6 * x6_fl / t_x6 / 1e9:.1f} TFLOP/s = {6 * x6_fl / t_x6 / 1e9 / PEAK_BF16:.3f} of the {PEAK_BF16:.0f} TF bf16 MFMA peak** "
+              f"({x6_fl / t_x6 / 1e9:.1f} TFLOP/s fp32-equivalent)")
+    if t_f32 > 0:
+        print(f"* fp32-input MFMA GEMM kernels (`conv_gemm_kernel`, `lin_gemm_kernel`, + `splitk_reduce`): {f32_fl / 1e9:.1f} GF in "
+              f"{t_f32:.3f} ms -> {f32_fl / t_f32 / 1e9:.1f} TFLOP/s = {f32_fl / t_f32 / 1e9 / PEAK:.3f} of the {PEAK} TF fp32 MFMA peak")
     print("\n| kernel | launches / segment | ms / segment | avg us |")
     print("|---|---|---|---|")
     for nm, (c, t) in sorted(ker_t.items(), key=lambda kv: -kv[1][1])[:16]:

@@ -29,6 +29,7 @@ static inline int aed_cdiv(int a, int b) { return (a + b - 1) / b; }
 // launchers (one per opcode family), defined in the .hip files
 int launch_conv_gemm(const aed_op* op, hipStream_t s);
 int launch_splitk_reduce(const aed_op* op, hipStream_t s);
+int launch_splitk_reduce_slices(const aed_op* op, int slices, hipStream_t s);   // slices > 0: the producer's slice count
 int launch_gn_stats(const aed_op* op, hipStream_t s);
 int launch_gn_apply(const aed_op* op, hipStream_t s);
 int launch_gn_scale_shift(const aed_op* op, hipStream_t s);

@@ -643,10 +643,11 @@ int launch_conv_gemm(const aed_op* op, hipStream_t s) {
     return 0;
 }
 
-int launch_splitk_reduce(const aed_op* op, hipStream_t s) {
+int launch_splitk_reduce_slices(const aed_op* op, int slices, hipStream_t s) {
     CGParams p;
     int rc = cg_fill_params(op, p, 32);
     if (rc) return rc;
+    if (slices > 0) p.ksplit = slices;      // the producer's own clamp (a kernel with wider k chunks has fewer of them)
     size_t total = (size_t)p.M * p.N;
     int grid = (int)((((p.N & 3) == 0 ? total >> 2 : total) + 255) / 256);
     if (grid > 2048) grid = 2048;
@@ -654,3 +655,5 @@ int launch_splitk_reduce(const aed_op* op, hipStream_t s) {
     AED_CHECK_HIP(hipGetLastError());
     return 0;
 }
+
+int launch_splitk_reduce(const aed_op* op, hipStream_t s) { return launch_splitk_reduce_slices(op, 0, s); }

@@ -509,7 +509,8 @@ int launch_conv_gemm_f8(const aed_op* op, hipStream_t s) {
         AED_REQUIRE(p.Wq && p.Wsc && (uintptr_t)p.Wq % 16 == 0 && (long long)p.N * p.K < (1LL << 31),
                     "conv_gemm_f8: flag bit 7 needs 16-byte aligned pre-quantised weights in p[7] / p[9]");
     }
-    if (p.ksplit > (p.K + 31) / 32) p.ksplit = (p.K + 31) / 32;     // launch_splitk_reduce clamps with 32-wide chunks
+    if (p.ksplit > p.nchunks) p.ksplit = p.nchunks;                 // this kernel walks F8_BK-wide chunks
+    if (p.ksplit < 1) p.ksplit = 1;
     if (cfg == 0) {
         const int cus = aed_num_cus();
         auto blocks = [&](int bm, int bn) { return (long)aed_cdiv(p.M, bm) * aed_cdiv(p.N, bn) * p.ksplit; };
@@ -528,6 +529,6 @@ int launch_conv_gemm_f8(const aed_op* op, hipStream_t s) {
     }
     if (rc) return rc;
     AED_CHECK_HIP(hipGetLastError());
-    if (p.ksplit > 1) return launch_splitk_reduce(op, s);
+    if (p.ksplit > 1) return launch_splitk_reduce_slices(op, p.ksplit, s);
     return 0;
 }

@@ -227,7 +227,13 @@ class EditEngine(LoopPlumbing):
     # carry the same x_t and timestep; with ONE clip per engine (n = 1) the blocks of a timestep are adjacent rows and the
     # context-free head of the U-Net is computed once per timestep instead of once per row.  False = every row through the whole
     # graph (rounds 1-4; A/B switch).
+    # Used by the timestep-batched INVERSION only (shared head at batch G >= 2).  In the edit loop the shared head would run at
+    # batch 1; that engine is correct alone and under a forward-level stress test, but inside the clip pipeline the FIRST clip of
+    # a multi-clip run came out different from run to run in 6 of 14 runs on the MI355X (tools/diag/share_pipeline*.py,
+    # profiles/r05_cfg_row_sharing.md; never with the inversion's engines, never without sharing) and the cause was not found
+    # this round, so SHARE_IN_EDIT_LOOP stays off: the edit lanes have slack anyway, the inversion is what is power-bound.
     SHARE_CFG_ROWS = True
+    SHARE_IN_EDIT_LOOP = False
 
     def unet(self, B, L0=0, L1=0, share=1):
         arith = self._arith_for(B)
@@ -386,7 +392,7 @@ class EditEngine(LoopPlumbing):
                 coef=torch.zeros((T, L.COEF_STRIDE), device=self.device, dtype=torch.float32),
                 cfgt=(torch.empty((max(P, 1), n, self.H, self.W, self.C), device=self.device, dtype=torch.float32)
                       if cfg_tensor is not None else None))
-            eng = plan["eng"] = self.unet(G * rows_per_t, L0, L1, share=(1 + P) if n == 1 else 1)
+            eng = plan["eng"] = self.unet(G * rows_per_t, L0, L1, share=(1 + P) if (n == 1 and G >= 2) else 1)
             pre, post = Tape(self.device), Tape(self.device)
             for g in range(G):
                 for blk in range(1 + P):
@@ -472,7 +478,7 @@ class EditEngine(LoopPlumbing):
                 coef=torch.zeros((Z, L.COEF_STRIDE), device=self.device, dtype=torch.float32),
                 cfgt=(torch.empty((P, n, self.H, self.W, self.C), device=self.device, dtype=torch.float32)
                       if cfg_tensor is not None else None))
-            eng = plan["eng"] = self.unet(n * (1 + P), L0, L1, share=(1 + P) if n == 1 else 1)
+            eng = plan["eng"] = self.unet(n * (1 + P), L0, L1, share=(1 + P) if (n == 1 and self.SHARE_IN_EDIT_LOOP) else 1)
             pre, post = Tape(self.device), Tape(self.device)
             for blk in range(1 + P):
                 pre.copy2d(plan["cur"], eng.x_in[blk * n:(blk + 1) * n], rows=1, cols=numel, ld_src=numel,

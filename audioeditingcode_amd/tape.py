@@ -339,7 +339,10 @@ class Tape:
                         [x, w, bias, out, res, rowvec, None, None, x2, kbias], name=name,
                         flops=2 * M * N * K if alg_flops is None else alg_flops, exec_flops=2 * M * N * K,
                         nbytes=4 * (B * IH * IW * Cin + N * K + M * n_out), flags=flags)
-        if flags & 64 and FP8_PREQUANT and Cin % 64 == 0 and kbias is None and torch.is_tensor(w) and w.is_cuda:
+        f8_fits = x6_ok and Cin % 64 == 0 and lda % 4 == 0 and (x2 is None or C1 % 64 == 0) and i[29] in (0, 1, 2, 3, 4, 8, 9) \
+            and not (i[36] or i[37] or i[39]) and i[38] <= 1      # launch_conv_gemm_f8's `fits`: anything else falls back to
+        #                                                           the x6 / fp32 kernels, which read p[9] as the key bias
+        if flags & 64 and FP8_PREQUANT and f8_fits and kbias is None and torch.is_tensor(w) and w.is_cuda:
             # fp8 experiment: the (frozen) weights are quantised to MX-FP8 ONCE, here, and the record points at the bytes
             q, sc = mx_quantized_weights(w, N, K)
             self.keep += [q, sc]

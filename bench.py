@@ -254,11 +254,15 @@ def main():
                     help="DDIM steps of the config-1 CPU anchor clip measured end to end through the oracle (0 = skip; BASELINE "
                          "configs[0] is 50 steps: the un-extrapolated anchor SURVEY 8(d) asks for, ~50-110 s of CPU on the box's "
                          "host; round 4 cut it to 12 steps and extrapolated)")
+    ap.add_argument("--no-share-cfg-rows", action="store_true",
+                    help="A/B: every classifier-free-guidance row through the whole U-Net graph (rounds 1-4) instead of computing "
+                         "the context-free head once per latent (EditEngine.SHARE_CFG_ROWS)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
 
-    from audioeditingcode_amd import configs, dist as adist, models, weights
+    from audioeditingcode_amd import configs, dist as adist, editing, models, weights
+    editing.EditEngine.SHARE_CFG_ROWS = not args.no_share_cfg_rows
     from audioeditingcode_amd.main_run import edit_clip
     from audioeditingcode_amd.utils import prepare_waveform, synthetic_clip
 
@@ -579,7 +583,7 @@ def main():
                           "clips_per_gpu_per_step": NC,
                           "clips_in_flight_per_gpu": NC if pipe_info is None else pipe_info["clips_in_flight"],
                           "parallelism": f"clip-dp{world}" + ("" if pipe_info is None else f" x {PLAN} pipeline"),
-                          "arith": ARITH_TEXT[args.arith], "codec_arith": getattr(m, "codec_arith", "f32"),
+                          "arith": ARITH_TEXT[args.arith], "cfg_row_sharing": not args.no_share_cfg_rows, "codec_arith": getattr(m, "codec_arith", "f32"),
                           "weights_broadcast_s": t_bcast if grouped else 0.0,
                           "per_rank_clips_per_s": per_rank, "rank_resources": rank_resources,
                           "process_group": (torch.distributed.get_backend() if grouped else None),
@@ -659,7 +663,14 @@ def family_table(eng, ms, cu_frac=1.0):
                      achieved_tflops_fp32_equiv=f["flops_fp32_equiv"] / (f["ms"] * 1e-3) / 1e12)
         elif f["ms"] > 0 and f["bytes"] > 0:
             gbs = f["bytes"] / (f["ms"] * 1e-3) / 1e9
-            d.update(algorithmic_gb_per_s=gbs, hbm_peak_gb_per_s=PEAK_HBM_GBS * cu_frac, frac=gbs / (PEAK_HBM_GBS * cu_frac))
+            # HBM is not partitioned by a CU mask: a partition alone may pull the whole chip's bandwidth.  A producer ->
+            # consumer pair whose tensor fits the 256 MB Infinity Cache can move its algorithmic bytes faster than HBM could:
+            # then there is no HBM fraction to state
+            d.update(algorithmic_gb_per_s=gbs, hbm_peak_gb_per_s=PEAK_HBM_GBS)
+            if gbs <= PEAK_HBM_GBS:
+                d["frac"] = gbs / PEAK_HBM_GBS
+            else:
+                d["served_from_cache"] = True
         out[name] = d
     return out
 

@@ -149,6 +149,44 @@ def test_partition_pipeline_full_size_audioldm2_bit_identical_and_finite():
     pipe.close()
 
 
+@pytest.mark.parametrize("lanes,codec_queue", [(1, "front"), (2, "lane")])
+def test_partition_pipeline_full_size_repeated_runs_are_bit_identical(lanes, codec_queue):
+    """The same 4 clips through the full-size partition pipeline five times: every repeat returns the first run's bits, and the
+    inversion's noise maps handed from the front stage to the edit lanes are the same every time.  (Round 5: with CFG row
+    sharing also in the batch-2 EDIT engine the first clip of a run differed from run to run in 6 of 14 runs -- the reason
+    EditEngine.SHARE_IN_EDIT_LOOP is off; this test keeps watching the shipped configuration: the one-lane layout of the test
+    above and the bench's two lanes with the codec on the lanes.)"""
+    T, tstart, G, R = 8, 4, 4, 5
+    m = models.load_model("cvssp/audioldm2", DEV, T, allow_synthetic=True)
+    mels = [load_audio((synthetic_clip(seconds=10.0, seed=3 + i), 16000), m.get_fn_STFT(), device=DEV, stft=True)[0]
+            for i in range(4)]
+    seeds = [7, 8, 9, 10]
+    pipe = ClipPipeline(m, plan="partition", edit_cus=128, edit_lanes=lanes, codec_queue=codec_queue, timestep_group=G)
+    ed_front = None
+    pipe.warm_up(mels[0], *ARGS, T, tstart)
+    ed_front = pipe.workers[0].view.editor(256, 16)
+    assert any(e.S == 2 for e in ed_front._unets.values())                # the inversion's engine shares the context-free head
+    for w in pipe.workers:
+        if w.stage == "back":
+            assert all(e.S == 1 for e in w.view.editor(256, 16)._unets.values() if e.B == 2)
+    stash = {}
+    orig = pipe._front
+
+    def front(w, st, job, i):
+        f = orig(w, st, job, i)
+        stash.setdefault(i, []).append((f["zs"].clone(), f["wts"].clone()))
+        return f
+    pipe._front = front
+    runs = [pipe.edit_clips(mels, *ARGS, T, tstart, seeds=seeds) for _ in range(R)]
+    torch.cuda.synchronize()
+    for r in range(1, R):
+        for i in range(4):
+            assert torch.equal(stash[i][r][0], stash[i][0][0]) and torch.equal(stash[i][r][1], stash[i][0][1]), (r, i)
+            for a, b in zip(runs[r][i], runs[0][i]):
+                assert torch.equal(a, b), (r, i, float((a - b).abs().max()))
+    pipe.close()
+
+
 def test_group_plan_steps_several_clips_in_lockstep_tiny():
     """Group plan (round 5): the back stage steps the edit loops of up to `edit_group` clips in lockstep (U-Net batch 2g), on
     ONE 96-CU lane, greedy and with a forced full group; every clip agrees with the clip edited alone to fp32 rounding; the

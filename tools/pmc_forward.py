@@ -21,7 +21,8 @@ pw = PackedUNetWeights(sd, "cuda:0")
 g = torch.Generator().manual_seed(1)
 for B in [int(a) for a in sys.argv[1:]] or [40, 2]:
     with tape_mod.arith_mode(ARITH):
-        eng = UNetEngine(fam["unet"], pw, "cuda:0", B, 256, 16, ctx_len0=8, ctx_len1=16)
+        # the inversion's engine computes the context-free head once per [uncond | prompt] row pair (round 5); the edit loop's does not
+        eng = UNetEngine(fam["unet"], pw, "cuda:0", B, 256, 16, ctx_len0=8, ctx_len1=16, share=2 if B > 2 else 1)
     if TAPMAJOR:
         for op in eng.tape.ops:
             if op.code == 1:

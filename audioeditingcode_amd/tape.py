@@ -333,7 +333,7 @@ class Tape:
             i[29] = x6_tile(M, N, tile, ksplit)
         if flags & 4 and i[29] in (8, 9) and KH * KW > 1 and Cin % 32 == 0 and (x2 is None or C1 % 32 == 0) and WIDE_CHUNKS:
             # wide chunks (two bf16 k-blocks per LDS stage and barrier; csrc/conv_gemm_x6.hip, flag bit 8): +3-4 % on the long-K
-            # 3x3 convolutions at the inversion's batch, nothing on the short-K Linears (profiles/r05_x6_wide_chunks.md)
+            # 3x3 convolutions at the inversion's batch, nothing on the short-K Linears (profiles/r05_small_m.md section 4)
             flags |= 256
         idx = self._add(L.OP_CONV_GEMM, i, [in_slope, out_p, out_div, ln_eps, sm_scale],
                         [x, w, bias, out, res, rowvec, None, None, x2, kbias], name=name,

@@ -1,10 +1,13 @@
 """Several clips in flight on one MI355X (BASELINE config 2 served as a stream of independent clips).
 
 Why.  One clip of the reference path is a sequential chain of two regimes: the forward inversion
-(inversion_utils.py:75-133; timestep-batched here: two U-Net calls at batch 200, throughput-bound, ~0.63 of the fp32 MFMA
-peak on the CUs it gets) and the 100-step edit loop (:221-315; ~600 dependent launches per step at U-Net batch 2, bound by
-launch / first-operand latency: 8.6 ms per step on 256 CUs, 12.7 ms on 128 -- it cannot use the chip).  A clip's own
-arithmetic cannot be reordered, so the only work that can fill the idle compute units is ANOTHER clip.
+(inversion_utils.py:75-133; timestep-batched here: two U-Net calls at batch 200, throughput-bound: 0.39 of the bf16 MFMA peak
+on the whole chip in the split-bf16 arithmetic, 0.49 alone on a 128-CU partition) and the 100-step edit loop (:221-315; ~570
+dependent launches per step at U-Net batch 2, bound by launch / first-operand latency: 7.9 ms per step on 256 CUs, 13.0 ms on a
+64-CU lane -- it cannot use the chip).  A clip's own arithmetic cannot be reordered, so the only work that can fill the idle
+compute units is ANOTHER clip.  Since round 5 the steady state is bound by the chip's POWER budget, not by idle CUs
+(profiles/r05_power_probe.md): the options below that only re-schedule work (edit_group, steal, codec_queue="chip", more lanes)
+measure within 2 % of the default; they stay because a serving loop with other clip mixes may want them, each parity-tested.
 
 Plans (measured on the MI355X, profiles/r03_cu_partition.md and profiles/r03_lanes.md):
   * "partition" (default): a two-stage pipeline on DISJOINT CU partitions (streams.PartitionStream: hardware queues with

@@ -1,8 +1,8 @@
 """HIP streams restricted to a subset of the MI355X's compute units (include/aed.h: aed_stream_create_cu_mask).
 
 Why: one edited clip is two regimes.  The forward inversion (inversion_utils.py:75-133) runs two
-U-Net calls at batch 200 that fill every CU at ~0.63 of the fp32 MFMA peak; the 100-step edit loop (:221-315) is a chain
-of ~600 dependent launches per step at U-Net batch 2 that is latency-bound and leaves most CUs idle.  Two clips in flight
+U-Net calls at batch 200 that fill every CU (0.39 of the bf16 MFMA peak in the split-bf16 arithmetic); the 100-step edit loop
+(:221-315) is a chain of ~570 dependent launches per step at U-Net batch 2 that is latency-bound and leaves most CUs idle.  Two clips in flight
 -- clip i in its edit loop, clip i+1 in its inversion -- use the idle CUs, but only if the two kernel classes do not
 queue behind each other's workgroups: a 128x128-tile inversion workgroup holds its CU for 0.2-1 ms, a batch-2 kernel
 lasts ~10 us.  So each class gets its own hardware queue with a DISJOINT CU mask.

@@ -209,7 +209,7 @@ def test_default_line_has_the_contract_keys():
     assert abs(r["on_partition"]["peak"] - 2500.0 * 160 / 256) < 1e-9
     assert set(r["edit_step"]) == {"clips_1"} and r["edit_step"]["clips_1"]["unet_batch"] == 2
     assert r["traffic"] is None or r["traffic"] > 0
-    assert 0 < r["path"]["matrix_pipe_frac"] and "frac_fp32_equiv" in r["path"]
+    assert 0 < r["path"]["matrix_pipe_frac"] and "fp32_equiv_over_fp32_mfma_peak" in r["path"]
     assert "value_reference_order" in out and "value_single_clip_batched" in out and out["serial_legs_clips"] == 2
     assert out["schedule_deviation_rel_l2"] == 0.0          # the mocked edit returns the same latent for every schedule
     assert out["pipeline_vs_one_clip_at_a_time"] == dict(
@@ -259,10 +259,10 @@ def test_extras_are_reported_and_never_fatal():
 def test_roofline_fraction_check_refuses_fractions_above_their_own_roof():
     """check_fractions (round 5): EVERY `frac` of the roofline object -- at any depth -- is executed work over the peak of the
     instruction that did it and must lie in (0, 1]: round 3's path_frac = 4.23 and round 4's `frac` > 1 under bf16x6 both raise.
-    Keys named *_fp32_equiv are not roofline fractions (they may exceed 1) and are skipped."""
+    The comparison with an ideal fp32-MFMA implementation is a ratio under another name (`fp32_equiv_over_fp32_mfma_peak`)."""
     import pytest
-    ok = dict(frac=0.35, frac_fp32_equiv=0.93, forward=dict(families=dict(gemm_bf16x6=dict(frac=0.35), groupnorm=dict(frac=0.6))),
-              on_partition=dict(frac=0.41, cu_fraction_of_chip=0.625), path=dict(matrix_pipe_frac=0.3, frac_fp32_equiv=1.2))
+    ok = dict(frac=0.35, fp32_equiv_over_fp32_mfma_peak=0.93, forward=dict(families=dict(gemm_bf16x6=dict(frac=0.35), groupnorm=dict(frac=0.6))),
+              on_partition=dict(frac=0.41, cu_fraction_of_chip=0.625), path=dict(matrix_pipe_frac=0.3, fp32_equiv_over_fp32_mfma_peak=1.2))
     bench.check_fractions(ok)
     with pytest.raises(AssertionError, match="roofline.frac"):
         bench.check_fractions(dict(ok, frac=1.21))

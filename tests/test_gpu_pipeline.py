@@ -162,7 +162,6 @@ def test_partition_pipeline_full_size_repeated_runs_are_bit_identical(lanes, cod
             for i in range(4)]
     seeds = [7, 8, 9, 10]
     pipe = ClipPipeline(m, plan="partition", edit_cus=128, edit_lanes=lanes, codec_queue=codec_queue, timestep_group=G)
-    ed_front = None
     pipe.warm_up(mels[0], *ARGS, T, tstart)
     ed_front = pipe.workers[0].view.editor(256, 16)
     assert any(e.S == 2 for e in ed_front._unets.values())                # the inversion's engine shares the context-free head

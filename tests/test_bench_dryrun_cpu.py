@@ -270,3 +270,19 @@ def test_roofline_fraction_check_refuses_fractions_above_their_own_roof():
         bench.check_fractions(dict(ok, forward=dict(families=dict(gemm_bf16x6=dict(frac=4.23)))))
     with pytest.raises(AssertionError, match="matrix_pipe_frac"):
         bench.check_fractions(dict(ok, path=dict(matrix_pipe_frac=0.0)))
+
+
+def test_family_table_prices_streaming_ops_against_the_chips_hbm_and_marks_cache_resident_traffic():
+    """family_table (round 5): an HBM-bound family is priced against the WHOLE chip's HBM bandwidth whatever the CU partition (a CU
+    mask does not partition memory); a producer -> consumer copy served from the 256 MB Infinity Cache moves its algorithmic
+    bytes faster than HBM could: no fraction is stated for it (`served_from_cache`) instead of a `frac` above 1; MFMA families
+    scale their peak with the partition."""
+    from types import SimpleNamespace as NS
+    ops = [NS(flags=4, i=[0] * 40), NS(flags=0, i=[0] * 40), NS(flags=0, i=[0] * 40)]
+    meta = [dict(code=1, exec_flops=1e12, bytes=1e6), dict(code=22, exec_flops=0.0, bytes=2e9), dict(code=7, exec_flops=0.0, bytes=9e9)]
+    eng = NS(tape=NS(ops=ops, meta=meta))
+    t = bench.family_table(eng, [10.0, 1.0, 1.0], cu_frac=0.5)
+    assert abs(t["gemm_bf16x6"]["achieved_tflops"] - 600.0) < 1e-6 and abs(t["gemm_bf16x6"]["frac"] - 600.0 / 1250.0) < 1e-9
+    assert t["groupnorm"]["hbm_peak_gb_per_s"] == bench.PEAK_HBM_GBS and abs(t["groupnorm"]["frac"] - 2000.0 / bench.PEAK_HBM_GBS) < 1e-9
+    assert t["elementwise"].get("served_from_cache") is True and "frac" not in t["elementwise"]
+    bench.check_fractions(dict(families=t))

@@ -228,10 +228,11 @@ class EditEngine(LoopPlumbing):
     # context-free head of the U-Net is computed once per timestep instead of once per row.  False = every row through the whole
     # graph (rounds 1-4; A/B switch).
     # Used by the timestep-batched INVERSION only (shared head at batch G >= 2).  In the edit loop the shared head would run at
-    # batch 1; that engine is correct alone and under a forward-level stress test, but inside the clip pipeline the FIRST clip of
-    # a multi-clip run came out different from run to run in 6 of 14 runs on the MI355X (tools/diag/share_pipeline*.py,
-    # profiles/r05_cfg_row_sharing.md; never with the inversion's engines, never without sharing) and the cause was not found
-    # this round, so SHARE_IN_EDIT_LOOP stays off: the edit lanes have slack anyway, the inversion is what is power-bound.
+    # batch 1; that engine is correct alone and with eager launches, but replayed as a hipGraph on a CU-masked lane while the VAE
+    # encoder's kernels are co-resident on the same CUs (the next clips' set-up on the unmasked side stream) it came out different
+    # from run to run (6 of 8 repeats in tools/diag/share_edit_localize.py; never the inversion's engines, never without sharing;
+    # profiles/r05_cfg_row_sharing.md).  The first perturbed node was not named this round, so SHARE_IN_EDIT_LOOP stays off: the
+    # edit lanes have slack anyway, the inversion is what is power-bound.
     SHARE_CFG_ROWS = True
     SHARE_IN_EDIT_LOOP = False
 

@@ -8,6 +8,7 @@
 // LDS row-major, V tiles transposed (so both MFMA B-fragments are one ds_read_b128), P makes the
 // accumulator -> A-operand layout change through a wave-private LDS slab.  Online softmax keeps
 // (max, sum) per row in registers; nothing of size N_q x N_k ever reaches HBM.
+#include <mutex>
 #include "aed_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -412,12 +413,14 @@ static int launch_t(const AttnParams& p, int B, hipStream_t s) {
     constexpr int SLAB = 32 * (D + 4) + DT * 32 * 36;
     constexpr int MRG = (KSPLIT - 1) * 64 * (DT * 16 + 2);
     const size_t bytes = sizeof(float) * (4 * SLAB > MRG ? 4 * SLAB : MRG);
-    static bool attr_set = false;
-    if (!attr_set) {
-        AED_CHECK_HIP(hipFuncSetAttribute((const void*)attention_t_kernel<D, KSPLIT>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-        attr_set = true;
-    }
+    // once per instantiation, whichever host thread gets here first (the clip pipeline launches from ~5 threads)
+    static std::once_flag attr_once;
+    static hipError_t attr_rc = hipSuccess;
+    std::call_once(attr_once, [&] {
+        attr_rc = hipFuncSetAttribute((const void*)attention_t_kernel<D, KSPLIT>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    });
+    AED_CHECK_HIP(attr_rc);
     dim3 grid(aed_cdiv(p.Nq, KSPLIT == 1 ? 128 : 32), p.H, B);
     hipLaunchKernelGGL((attention_t_kernel<D, KSPLIT>), grid, dim3(256), bytes, s, p);
     return 0;

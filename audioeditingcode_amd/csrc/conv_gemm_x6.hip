@@ -513,14 +513,12 @@ int launch_conv_gemm_x6(const aed_op* op, hipStream_t s) {
         return launch_conv_gemm(op, s);
     }
     // flag bit 8 (256): wide chunks (BK = 32) on the 512-thread tiles 8 / 9, where two stages fill the CU's LDS; needs 32 | Cin
-    const bool wide = (op->flags & 256) && (cfg == 8 || cfg == 9) && Cin % 32 == 0;
-    // flag bit 9 (512): DEEP prefetch on the 256-thread tiles 2 / 3 / 4 -- four 32-wide chunks in flight in registers (DEPTH 4 x
-    // BK 32) instead of two 16-wide ones.  The latency regime (U-Net batch 2: a handful of workgroups per CU stream megabytes of
-    // weights through K loops of 20-360 chunks) is bound by bytes in flight per workgroup, not by the matrix pipe: 24 KB in
-    // flight at ~2 us of loaded HBM latency is 12 GB/s per workgroup (round 5, profiles/r05_small_m.md).
-    const bool deep = (op->flags & 512) && (cfg == 2 || cfg == 3 || cfg == 4) && Cin % 32 == 0 && !(op->flags & 16);
+    const bool wide = (op->flags & 256) && (cfg == 8 || cfg == 9) && Cin % 32 == 0 && !(op->flags & 16);   // (the three-term
+    //                  diagnostic, flag bit 4, only has the BK = 16 kernel: never count its K in 32-wide chunks)
+    // (flag bit 9, the deep-prefetch variant of round 5 -- DEPTH 4 x BK 32 on tiles 2 / 3 / 4, 0.8-7 % on ten shapes, never adopted --
+    // left the library in round 6: profiles/r05_small_m.md section 5, git history)
     CGParams p;
-    int rc = cg_fill_params(op, p, (wide || deep) ? 32 : X6_BK);
+    int rc = cg_fill_params(op, p, wide ? 32 : X6_BK);
     if (rc) return rc;
     if (p.ksplit > (p.K + 31) / 32) p.ksplit = (p.K + 31) / 32;     // launch_splitk_reduce clamps with 32-wide chunks
     if (cfg == 0) {
@@ -538,12 +536,9 @@ int launch_conv_gemm_x6(const aed_op* op, hipStream_t s) {
     if (p.geglu) AED_REQUIRE(cfg == 1 || cfg == 3 || cfg == 8 || cfg == 9, "conv_gemm_x6: the GEGLU epilogue needs 64-wide wave tiles (cfg %d)", cfg);
     switch (cfg) {
         case 1: rc = x6_launch<128, 128, 2, 2, 2, true>(p, plain, sched, terms, s); break;
-        case 2: rc = deep ? x6_launch<128, 64, 2, 2, 4, false, 32>(p, plain, sched, terms, s)
-                          : x6_launch<128, 64, 2, 2, 2, false>(p, plain, sched, terms, s); break;
-        case 3: rc = deep ? x6_launch<64, 128, 2, 2, 4, false, 32>(p, plain, sched, terms, s)
-                          : x6_launch<64, 128, 2, 2, 2, false>(p, plain, sched, terms, s); break;
-        case 4: rc = deep ? x6_launch<64, 64, 2, 2, 4, false, 32>(p, plain, sched, terms, s)
-                          : x6_launch<64, 64, 2, 2, 2, false>(p, plain, sched, terms, s); break;
+        case 2: rc = x6_launch<128, 64, 2, 2, 2, false>(p, plain, sched, terms, s); break;
+        case 3: rc = x6_launch<64, 128, 2, 2, 2, false>(p, plain, sched, terms, s); break;
+        case 4: rc = x6_launch<64, 64, 2, 2, 2, false>(p, plain, sched, terms, s); break;
         case 8: rc = wide && terms == 6 ? x6_launch<256, 128, 4, 2, 2, false, 32>(p, plain, sched, terms, s)
                                         : x6_launch<256, 128, 4, 2, 2, true>(p, plain, sched, terms, s); break;
         case 9: rc = wide && terms == 6 ? x6_launch<128, 256, 2, 4, 2, false, 32>(p, plain, sched, terms, s)

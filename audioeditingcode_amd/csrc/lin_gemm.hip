@@ -19,6 +19,7 @@
 //     upsample) and a two-source channel split, so up-block concatenations are never materialised.
 //
 // Same arithmetic contract as conv_gemm.hip: exact fp32 FMA chains, fixed summation order per (tile config).
+#include <mutex>
 #include "cg_params.h"
 
 // ordering of a wave's own LDS traffic: the hardware executes one wave's DS operations in issue order; this only
@@ -81,7 +82,6 @@ __global__ __launch_bounds__(64 * NW) void lin_gemm_kernel(CGParams p) {
 
     // loader rows of this lane
     int ay0[PA], ax0[PA], ab[PA];
-    float amask[PA];                 // 1.0 for rows that exist (GATHER: per chunk, see prefetch)
     unsigned aoff[PA], aoff2[PA];    // MODE 0/1: element offset of the row in A / in the second source
 #pragma unroll
     for (int j = 0; j < PA; ++j) {
@@ -155,9 +155,9 @@ __global__ __launch_bounds__(64 * NW) void lin_gemm_kernel(CGParams p) {
     }
 
     float4 ra[DEPTH][PA], rw[DEPTH][PW];
-    float rmask[DEPTH][GATHER ? PA : 1];
+    int rmask[DEPTH][GATHER ? PA : 1];   // GATHER: per staged row, all ones inside the map / 0 in the zero padding
 
-    auto prefetch = [&](int kc, float4 (&a)[PA], float4 (&w)[PW], float (&mask)[GATHER ? PA : 1]) {
+    auto prefetch = [&](int kc, float4 (&a)[PA], float4 (&w)[PW], int (&mask)[GATHER ? PA : 1]) {
         const int k0 = min(kc, nch - 1) * CH;               // dead prefetches past the end stay in bounds
         if constexpr (GATHER) {
             const int dy = pf_ty * p.dil_h, dx = pf_tx * p.dil_w;
@@ -174,13 +174,20 @@ __global__ __launch_bounds__(64 * NW) void lin_gemm_kernel(CGParams p) {
 #pragma unroll
             for (int j = 0; j < PA; ++j) {
                 const int iy = ay0[j] + dy, ix = ax0[j] + dx;
-                const bool ok = ((unsigned)iy < (unsigned)vIH) & ((unsigned)ix < (unsigned)vIW);
-                // clamped, always-valid address; the zero padding is a multiply by 0.0 at the LDS write, so the load is
-                // unconditional and stays in flight (a select lets the compiler sink the load into a branch)
+                // clamped, always-valid address; the zero padding is applied at the LDS write, so the load is unconditional
+                // and stays in flight (a select lets the compiler sink the load into a branch)
                 const int cy = min(max(iy, 0), vIH - 1) >> p.up, cx = min(max(ix, 0), vIW - 1) >> p.up;
                 const unsigned off = (unsigned)ab[j] * (unsigned)bs + (unsigned)(cy * p.IW + cx) * (unsigned)ld + c0 + lseg;
                 a[j] = *reinterpret_cast<const float4*>(src + off);
-                mask[j] = ok ? 1.0f : 0.0f;
+#ifdef LIN_GATHER_R5_FORM
+                mask[j] = (((unsigned)iy < (unsigned)vIH) & ((unsigned)ix < (unsigned)vIW)) ? 0x3f800000 : 0;
+#else
+                // keep bits: the sign of iy | (vIH-1-iy) | ix | (vIW-1-ix) is clear exactly when 0 <= iy < vIH and
+                // 0 <= ix < vIW.  (The shift is opaque to the optimiser, which would turn `x >> 31` back into v_cmp + select.)
+                int outside = iy | (vIH - 1 - iy) | ix | (vIW - 1 - ix);
+                asm volatile("v_ashrrev_i32 %0, 31, %0" : "+v"(outside));       // 0 inside, -1 in the padding
+                mask[j] = ~outside;
+#endif
             }
         } else {
             int c0 = k0;
@@ -197,12 +204,29 @@ __global__ __launch_bounds__(64 * NW) void lin_gemm_kernel(CGParams p) {
         for (int j = 0; j < PW; ++j) w[j] = *reinterpret_cast<const float4*>(p.W + woff[j] + k0);
     };
 
-    auto stage_write = [&](const float4 (&a)[PA], const float4 (&w)[PW], const float (&mask)[GATHER ? PA : 1]) {
+    auto stage_write = [&](const float4 (&a)[PA], const float4 (&w)[PW], const int (&mask)[GATHER ? PA : 1]) {
 #pragma unroll
         for (int j = 0; j < PA; ++j) {
             float4 v = a[j];
             if constexpr (GATHER) {
-                v.x *= mask[j]; v.y *= mask[j]; v.z *= mask[j]; v.w *= mask[j];
+#ifdef LIN_GATHER_R5_FORM
+                {   // rounds 1-5: data * (1.0 | 0.0), scheduled by the compiler as v_pk_mul_f32 ... op_sel_hi:[1,0].  Reproducibly
+                    // wrong in lanes 48-63 of single loader rows when split-bf16 GEMM workgroups of another queue share the CU
+                    // (tools/diag/lin_gather_stress.py builds this form to show that the harness still bites)
+                    const float m = __int_as_float(mask[j]);
+                    v.x *= m; v.y *= m; v.z *= m; v.w *= m;
+                }
+#else
+                // Zero padding by bitwise AND with the keep bits, FENCED: in rounds 1-5 this was a multiply by a 1.0 / 0.0 float
+                // that the compiler scheduled freely (v_pk_mul_f32 with a broadcast mask); on the MI355X that form produced wrong
+                // values in lanes 48-63 of single loader rows whenever split-bf16 GEMM workgroups of ANOTHER queue were
+                // co-resident on the CU -- the first perturbed node of round 5's CFG-row-sharing issue (tiles 11 / 15, the 72 KB
+                // configurations that fit beside them; profiles/r06_lin_gather_hazard.md: reproducer, 20 kernel variants, what
+                // cured it and what did not).  Every variant with the masking inside one asm volatile block was clean (7 forms x
+                // 400 launches x 2 tiles); the AND is also exact whatever the clamped load returned (0.0 * Inf would be NaN).
+                asm volatile("v_and_b32 %0, %0, %4\n\tv_and_b32 %1, %1, %4\n\tv_and_b32 %2, %2, %4\n\tv_and_b32 %3, %3, %4"
+                             : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w) : "v"(mask[j]));
+#endif
                 if (p.in_act == AED_ACT_SILU) {             // f(0) = 0 keeps the zero padding
                     v.x = v.x / (1.0f + __expf(-v.x)); v.y = v.y / (1.0f + __expf(-v.y));
                     v.z = v.z / (1.0f + __expf(-v.z)); v.w = v.w / (1.0f + __expf(-v.w));
@@ -419,12 +443,14 @@ template <int NW, int TM, int TN, int DEPTH, int MODE>
 static int launch_lin_mode(const CGParams& p, hipStream_t s) {
     constexpr int WAVE_LDS = (32 * TM + 32 * TN) * 36;
     const size_t bytes = sizeof(float) * NW * WAVE_LDS;
-    static bool attr_set = false;
-    if (!attr_set) {
-        AED_CHECK_HIP(hipFuncSetAttribute((const void*)lin_gemm_kernel<NW, TM, TN, DEPTH, MODE>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-        attr_set = true;
-    }
+    // once per instantiation, whichever host thread gets here first (the clip pipeline launches from ~5 threads)
+    static std::once_flag attr_once;
+    static hipError_t attr_rc = hipSuccess;
+    std::call_once(attr_once, [&] {
+        attr_rc = hipFuncSetAttribute((const void*)lin_gemm_kernel<NW, TM, TN, DEPTH, MODE>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    });
+    AED_CHECK_HIP(attr_rc);
     dim3 grid(aed_cdiv(p.N, 32 * TN), aed_cdiv(p.M, 32 * TM), 1);
     hipLaunchKernelGGL((lin_gemm_kernel<NW, TM, TN, DEPTH, MODE>), grid, dim3(64 * NW), bytes, s, p);
     return 0;

@@ -47,8 +47,18 @@ def init_distributed(backend=None, force=False):
     return rank, world, local
 
 
+def local_world_size(world: int) -> int:
+    """Ranks on THIS node: torchrun's LOCAL_WORLD_SIZE, else the global world size (one node)."""
+    try:
+        n = int(os.environ.get("LOCAL_WORLD_SIZE", "") or world)
+    except ValueError:
+        n = world
+    return max(1, min(n, max(1, world)))
+
+
 def pin_rank_resources(local_rank: int, world: int, threads: int = None, affinity: bool = True):
-    """Host-side budget of one rank on a node that runs `world` of them.  Per rank the clip pipeline
+    """Host-side budget of one rank on a node that runs `world` of them -- `world` here is the number of ranks PER NODE
+    (`local_world_size`): with the global world size a two-node job would leave half of every node's cores unused.  Per rank the clip pipeline
     keeps <= 5 host threads busy (front / back / codec workers, the noise-prefetch thread, the caller) and <= 5 HIP queues
     (inversion lane, edit lane(s), whole-chip fill / drain queue, side stream); torch's intra-op CPU pool (the per-clip RNG
     draws, the host-side scheduler tables) would otherwise default to ALL cores in every rank.  Caps torch's intra-op threads

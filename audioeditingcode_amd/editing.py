@@ -227,14 +227,13 @@ class EditEngine(LoopPlumbing):
     # carry the same x_t and timestep; with ONE clip per engine (n = 1) the blocks of a timestep are adjacent rows and the
     # context-free head of the U-Net is computed once per timestep instead of once per row.  False = every row through the whole
     # graph (rounds 1-4; A/B switch).
-    # Used by the timestep-batched INVERSION only (shared head at batch G >= 2).  In the edit loop the shared head would run at
-    # batch 1; that engine is correct alone and with eager launches, but replayed as a hipGraph on a CU-masked lane while the VAE
-    # encoder's kernels are co-resident on the same CUs (the next clips' set-up on the unmasked side stream) it came out different
-    # from run to run (6 of 8 repeats in tools/diag/share_edit_localize.py; never the inversion's engines, never without sharing;
-    # profiles/r05_cfg_row_sharing.md).  The first perturbed node was not named this round, so SHARE_IN_EDIT_LOOP stays off: the
-    # edit lanes have slack anyway, the inversion is what is power-bound.
+    # Both loops share: the timestep-batched inversion (shared head at batch G >= 2) and, since round 6, the edit loop (shared head at
+    # batch 1).  Round 5 kept the edit loop out because that engine came out different from run to run when VAE-encode kernels were
+    # co-resident on the lane's CUs; round 6 named the node -- the gather loader of csrc/lin_gemm.hip (tiles 11 / 15), which the shared
+    # head is the only user of at M = 1024 -- reproduced it outside the engine and fixed the kernel (profiles/r06_lin_gather_hazard.md;
+    # tests/test_gpu_coresidency.py).  SHARE_IN_EDIT_LOOP stays as the A/B switch.
     SHARE_CFG_ROWS = True
-    SHARE_IN_EDIT_LOOP = False
+    SHARE_IN_EDIT_LOOP = True
 
     def unet(self, B, L0=0, L1=0, share=1):
         arith = self._arith_for(B)

@@ -6,20 +6,17 @@ on the whole chip in the split-bf16 arithmetic, 0.49 alone on a 128-CU partition
 dependent launches per step at U-Net batch 2, bound by launch / first-operand latency: 7.9 ms per step on 256 CUs, 13.0 ms on a
 64-CU lane -- it cannot use the chip).  A clip's own arithmetic cannot be reordered, so the only work that can fill the idle
 compute units is ANOTHER clip.  Since round 5 the steady state is bound by the chip's POWER budget, not by idle CUs
-(profiles/r05_power_probe.md): the options below that only re-schedule work (edit_group, steal, codec_queue="chip", more lanes)
-measure within 2 % of the default; they stay because a serving loop with other clip mixes may want them, each parity-tested.
+(profiles/r05_power_probe.md): variants that only re-schedule work (lockstep edit groups, work stealing between the stages, whole
+clips on unpartitioned lanes) measured within 2 % of this layout and were removed from the package in round 6 (git history, and
+their write-ups: profiles/r05_group_plan.md, profiles/r03_lanes.md).
 
-Plans (measured on the MI355X, profiles/r03_cu_partition.md and profiles/r03_lanes.md):
-  * "partition" (default): a two-stage pipeline on DISJOINT CU partitions (streams.PartitionStream: hardware queues with
+The plan (measured on the MI355X, profiles/r03_cu_partition.md):
+  * a two-stage pipeline on DISJOINT CU partitions (streams.PartitionStream: hardware queues with
     CU masks).  Stage "front" (one worker, CUs [edit_cus, total)): waveform -> mel -> VAE encode -> forward inversion.
     Stage "back" (edit_lanes workers sharing CUs [0, edit_cus)): edit loop -> VAE decode -> vocoder.  While clip i is in
     its edit loop, clip i+1 is being inverted; the two kernel classes never queue behind each other's workgroups (without
     masks a batch-2 kernel waits for 128x128-tile workgroups that hold a CU for 0.2-1 ms: 28.9 ms per edit step).
     Fill and drain (no other stage to share with) run on the whole chip.
-  * "lanes": L workers, each running whole clips in the reference's step order on its own stream, unpartitioned.
-    Measured: chip time per U-Net forward 8.6 -> 6.0 / 5.2 / 6.1 ms at L = 2 / 3 / 4 -- the batch-2 kernels' CU-time
-    saturates the chip at ~1.6x, i.e. 1.6-1.9 s per clip: no better than one clip at a time with the batched inversion.
-    Kept as a plan because it is the only one that needs no timestep regrouping.
 
 Nothing about a clip's computation changes: a worker's plans, tapes, hipGraphs and kernels run in the same order on the
 same values whether other clips are in flight or not -- only the stream they are launched on differs -- so a pipelined clip
@@ -46,7 +43,6 @@ from .ddm_inversion.inversion_utils import (conditioning_from_text, inversion_re
 from .streams import PartitionStream
 
 DEFAULT_EDIT_CUS = 128          # CUs of the edit-loop partition (the two stages' per-clip times cross near 128 of 256)
-DEFAULT_LANES = 3
 _STOP = object()
 
 
@@ -101,45 +97,17 @@ class ClipPipeline:
     lane_type = PartitionStream
     event_type = torch.cuda.Event
 
-    def __init__(self, model, plan="partition", edit_cus=None, edit_lanes=1, lanes=None, launch="graph",
-                 timestep_group=100, overlap_prep=True, lane_cus=None, separate_queues=None, codec_stage=None,
-                 widen_on_drain=True, edit_group=1, group_sizes=None, group_wait_s=0.0, codec_queue="front", steal=False,
-                 steal_min_remaining=4):
+    def __init__(self, model, plan="partition", edit_cus=None, edit_lanes=1, launch="graph", timestep_group=100,
+                 overlap_prep=True, separate_queues=None, codec_stage=None, widen_on_drain=True, codec_queue="front",
+                 mask_prep=True):
         if getattr(model, "kind", None) == "stable_audio":
             raise NotImplementedError("ClipPipeline drives the mel-latent families (AudioLDM / AudioLDM2 / TANGO)")
-        if plan not in ("partition", "lanes"):
-            raise ValueError("plan must be 'partition' or 'lanes'")
+        if plan != "partition":
+            raise ValueError("plan must be 'partition' (the unpartitioned 'lanes' plan was removed in round 6)")
         if launch not in ("eager", "graph"):
             raise ValueError("launch must be 'eager' or 'graph'")
         self.model, self.plan, self.launch = model, plan, launch
         self.timestep_group = int(timestep_group)
-        # edit_group > 1 ("group plan", round 5): an edit lane steps up to `edit_group` clips IN LOCKSTEP -- one U-Net call per
-        # diffusion step at batch 2g for the g clips whose inversions are ready when the lane becomes free (the per-rank shape
-        # of BASELINE config 3, SURVEY 8e: "processed as one batch ... with cond+uncond stacked").  The batch-2 edit step is
-        # latency-bound (572 launches of ~25 us whatever their size: profiles/r04_lane_perop_cus64.json); at batch 16 the same
-        # lane runs 8 clip-steps in 3.5x the time of one (profiles/r05_batch_scaling.md).  Every clip's arithmetic is still its
-        # own rows of the batch; against the clip edited alone the values agree to fp32 rounding (other tiles / split-K orders
-        # per batch shape), not bit for bit -- tests and bench.py assert the tolerance instead of identity for this plan.
-        self.edit_group = max(1, int(edit_group))
-        if self.edit_group > 1 and plan != "partition":
-            raise ValueError("edit_group > 1 needs the partition plan")
-        sizes = sorted({int(g) for g in (group_sizes or [1 << k for k in range(self.edit_group.bit_length())])
-                        if 1 <= int(g) <= self.edit_group} | {1})
-        self.group_sizes = sizes                # U-Net batch 2g engines exist for exactly these g (built by warm_up)
-        self.group_log = []                     # sizes of the groups the last edit_clips formed
-        self.group_wait_s = float(group_wait_s)  # how long a free lane waits for a FULL group before taking what is ready
-        # steal (round 5): an edit lane whose queue is empty takes the next UNSTARTED clip and runs its whole chain -- forward
-        # inversion included -- on its own CUs.  Once the split-K tables made the batch-2 step 13 ms on a 64-CU lane, the lanes
-        # (1.3 s per clip each) wait for the front stage (0.84 s per clip); a lane's idle 0.4 s per cycle cannot host another
-        # edit loop, but summed over a run it is whole clips: front-fed clips cost a lane 1.3 s, a stolen one 2.7 s (two batch-200
-        # forwards at ~0.7 s on 64 CUs), the optimum of that mix is +14 % over the front-bound rate.  A
-        # lane's inversion engines are built under the FRONT stage's tile regime: same tiles, same split-K orders, so a clip's
-        # values do not depend on who inverted it (bit-identical; tests/test_gpu_pipeline.py).  Not before `steal_min_remaining`
-        # unstarted clips are left: the tail of a run belongs to the front stage (a stolen clip takes 2.7 s, the front's 0.84 s
-        # + a widened edit loop).
-        self.steal = bool(steal) and plan == "partition" and self.edit_group == 1
-        self.steal_min_remaining = int(steal_min_remaining)
-        self.stolen = []                        # clips the lanes inverted themselves in the last edit_clips
         dev = model.device
         acquire = getattr(self.lane_type, "acquire", None)
 
@@ -150,139 +118,106 @@ class ClipPipeline:
         self.full = Lane(dev)                                      # the whole chip
         self.total = self.full.total
         self.stages = []                                           # [(name, halves, [workers])]
-        if plan == "partition":
-            self.edit_cus = DEFAULT_EDIT_CUS if edit_cus is None else int(edit_cus)
-            if not 0 < self.edit_cus < self.total:
-                raise ValueError(f"edit_cus={self.edit_cus} must leave CUs for both partitions of {self.total}")
-            if self.timestep_group < 2:
-                raise ValueError("the partition plan needs the timestep-batched inversion (timestep_group >= 2): the "
-                                 "front stage must not share the edit loop's batch-2 engine regime")
-            self.edit_lanes = max(1, int(edit_lanes))
-            # The next clip's mel / VAE encode / text conditioning / x_t draws + upload do not touch the batch-2G loop engine:
-            # they go to a side stream, so their host-blocking copies and checks wait for THAT stream and the work itself
-            # overlaps the inversion still running on the partition (otherwise ~50 ms of set-up per clip sit exposed
-            # between two inversions: `assert min(y) >= -1` alone drains the lane before anything else is enqueued).
-            front_regime = None
-            for name, lo, hi in (("cus128", 96, 160), ("cus64", 24, 80)):       # tables swept on a stream of about that size
-                if lo <= self.total - self.edit_cus <= hi and name in tape_mod.REGIME_TABLES:
-                    front_regime = name
-            self._front_regime = front_regime
-            front = [_Worker("front", 0, self._view(), Lane(dev, cus=range(self.edit_cus, self.total), total=self.total),
-                             self.full, regime=front_regime, prep=Lane(dev, index=17) if overlap_prep else None)]
-            # the edit loop's batch-2 kernels on half the chip are no longer purely latency-bound: their tiles come from
-            # the sweep taken on a 128-CU stream (tile_table_cus128.py) when the partition is about that size
-            # Several edit lanes get DISJOINT slices of the edit partition when it splits into multiples of 32 CUs (a mask must
-            # give every shader engine of every XCD the same number of CUs; 64 consecutive mask bits = 8 CUs on each XCD):
-            # lane k runs on CUs [k * edit_cus / n, (k + 1) * edit_cus / n).  Otherwise the lanes SHARE the partition's CUs --
-            # measured in round 3 (128 CUs, 2 lanes: 2 x 2.87 s per clip per lane = the one-lane rate) and again in round 4 with
-            # one dispatch pipe per lane attempted (queues with the SAME mask cannot be separated: 0.71-0.78 clips/s against
-            # 0.95 for disjoint slices, profiles/r04_pipeline_variants.md).
-            n = self.edit_lanes
-            per = self.edit_cus // n if (n > 1 and self.edit_cus % n == 0 and (self.edit_cus // n) % 32 == 0) else None
-            self.edit_lane_cus = per or self.edit_cus
-            lane_cus = (lambda k: range(k * per, (k + 1) * per)) if per else (lambda k: range(self.edit_cus))
-            regime = None
-            for name, lo, hi in (("cus128", 96, 160), ("cus64", 24, 80)):       # tables swept on a stream of about that size
-                if lo <= self.edit_lane_cus <= hi and name in tape_mod.REGIME_TABLES:
-                    regime = name
-            back = [_Worker("back", k, self._view(), Lane(dev, cus=lane_cus(k), total=self.total, index=k),
-                            Lane(dev, index=1 + k), regime=regime) for k in range(n)]
-            # Several edit lanes: the edited latent's VAE decode + vocoder (throughput kernels, 44 ms on the whole chip, ~150 ms on
-            # a 64-CU lane) leave the lane.  A third stage with ONE worker decodes ON THE INVERSION PARTITION'S OWN QUEUE, in
-            # stream order between that stage's inversions: the front stage has the slack once two lanes share the back stage's
-            # work, and a queue of its own over the same CUs was measured 8x slower (codec and batch-200 workgroups then
-            # compete for the same CUs one workgroup at a time: 600 ms per clip, and the inversion slows as well).  The next
-            # clip's set-up stays on the front lane too: three busy hardware queues, each on a dispatch pipe of its own
-            # (streams.py).  With one edit lane the codec stays in the back stage on an unmasked stream (round 3).
-            self.codec_stage = (n > 1 or self.edit_group > 1) if codec_stage is None else bool(codec_stage)
-            if self.edit_group > 1 and not self.codec_stage:
-                raise ValueError("the group plan (edit_group > 1) hands every edited latent to the codec stage")
-            self.stages = [("front", ("front",), front), ("back", ("back",), back)]
-            if codec_queue not in ("front", "chip", "lane"):
-                raise ValueError("codec_queue must be 'front' (the inversion partition's queue), 'chip' (an unmasked queue) or "
-                                 "'lane' (the edit lane that edited the clip)")
-            self.codec_queue = codec_queue
-            if codec_queue == "lane":
-                # Round 5: with the split-K tables an edit lane needs 1.3 s per clip and gets one every 1.66 s (two lanes, front
-                # stage 0.83 s per clip): the lanes have the slack, the inversion queue has none.  The edited latent's VAE decode +
-                # two vocoder passes (44 ms on the whole chip, ~110 ms on 64 CUs) run on the lane that edited the clip, in stream
-                # order after its loop; no codec stage, and the next clip's set-up goes back to a side stream (round 3's
-                # overlap_prep) so that the inversion queue carries the two U-Net calls and little else.
-                if self.edit_group > 1:
-                    raise ValueError("the group plan hands its clips to a codec stage (codec_queue 'front' or 'chip')")
-                self.codec_stage = False
-            if self.codec_stage:
-                front[0].prep = None
-                # "chip" (round 5 A/B): the codec jobs on an UNMASKED queue of their own -- 44 ms of throughput kernels per clip
-                # leave the inversion queue (the critical stage once the edit lanes got faster) and take whatever CU is free
-                cq = front[0].lane if codec_queue == "front" else Lane(dev, index=70)
-                self.stages.append(("codec", ("codec",), [_Worker("codec", 0, self._view(), cq, None)]))
-            self.queue_log = []
-            if separate_queues is None:
-                separate_queues = n > 1 or self.edit_group > 1
+        self.edit_cus = DEFAULT_EDIT_CUS if edit_cus is None else int(edit_cus)
+        if not 0 < self.edit_cus < self.total:
+            raise ValueError(f"edit_cus={self.edit_cus} must leave CUs for both partitions of {self.total}")
+        if self.timestep_group < 2:
+            raise ValueError("the partition plan needs the timestep-batched inversion (timestep_group >= 2): the "
+                             "front stage must not share the edit loop's batch-2 engine regime")
+        self.edit_lanes = max(1, int(edit_lanes))
+        # The next clip's mel / VAE encode / text conditioning / x_t draws + upload do not touch the batch-2G loop engine:
+        # they go to a side stream, so their host-blocking copies and checks wait for THAT stream and the work itself
+        # overlaps the inversion still running on the partition (otherwise ~50 ms of set-up per clip sit exposed
+        # between two inversions: `assert min(y) >= -1` alone drains the lane before anything else is enqueued).
+        front_regime = None
+        for name, lo, hi in (("cus128", 96, 160), ("cus64", 24, 80)):       # tables swept on a stream of about that size
+            if lo <= self.total - self.edit_cus <= hi and name in tape_mod.REGIME_TABLES:
+                front_regime = name
+        self._front_regime = front_regime
+        # The side stream is MASKED to the inversion partition (round 6): the next clip's VAE encode has no business on the edit
+        # lanes' CUs -- co-resident split-bf16 workgroups are what exposed the round-5 hazard (profiles/r06_lin_gather_hazard.md),
+        # and the edit lanes' latency-bound kernels lose issue slots to them.  mask_prep=False: the unmasked queue of rounds 3-5 (A/B).
+        inv_cus = range(self.edit_cus, self.total)
+        prep = None
+        if overlap_prep:
+            prep = Lane(dev, cus=inv_cus, total=self.total, index=17) if mask_prep else Lane(dev, index=17)
+        self.mask_prep = bool(mask_prep) and overlap_prep
+        front = [_Worker("front", 0, self._view(), Lane(dev, cus=inv_cus, total=self.total), self.full, regime=front_regime,
+                         prep=prep)]
+        # the edit loop's batch-2 kernels on half the chip are no longer purely latency-bound: their tiles come from
+        # the sweep taken on a 128-CU stream (tile_table_cus128.py) when the partition is about that size
+        # Several edit lanes get DISJOINT slices of the edit partition when it splits into multiples of 32 CUs (a mask must
+        # give every shader engine of every XCD the same number of CUs; 64 consecutive mask bits = 8 CUs on each XCD):
+        # lane k runs on CUs [k * edit_cus / n, (k + 1) * edit_cus / n).  Otherwise the lanes SHARE the partition's CUs --
+        # measured in round 3 (128 CUs, 2 lanes: 2 x 2.87 s per clip per lane = the one-lane rate) and again in round 4 with
+        # one dispatch pipe per lane attempted (queues with the SAME mask cannot be separated: 0.71-0.78 clips/s against
+        # 0.95 for disjoint slices, profiles/r04_pipeline_variants.md).
+        n = self.edit_lanes
+        per = self.edit_cus // n if (n > 1 and self.edit_cus % n == 0 and (self.edit_cus // n) % 32 == 0) else None
+        self.edit_lane_cus = per or self.edit_cus
+        lane_cus = (lambda k: range(k * per, (k + 1) * per)) if per else (lambda k: range(self.edit_cus))
+        regime = None
+        for name, lo, hi in (("cus128", 96, 160), ("cus64", 24, 80)):       # tables swept on a stream of about that size
+            if lo <= self.edit_lane_cus <= hi and name in tape_mod.REGIME_TABLES:
+                regime = name
+        back = [_Worker("back", k, self._view(), Lane(dev, cus=lane_cus(k), total=self.total, index=k),
+                        Lane(dev, index=1 + k), regime=regime) for k in range(n)]
+        # Several edit lanes: the edited latent's VAE decode + vocoder (throughput kernels, 44 ms on the whole chip, ~150 ms on
+        # a 64-CU lane) leave the lane.  A third stage with ONE worker decodes ON THE INVERSION PARTITION'S OWN QUEUE, in
+        # stream order between that stage's inversions: the front stage has the slack once two lanes share the back stage's
+        # work, and a queue of its own over the same CUs was measured 8x slower (codec and batch-200 workgroups then
+        # compete for the same CUs one workgroup at a time: 600 ms per clip, and the inversion slows as well).  The next
+        # clip's set-up stays on the front lane too: three busy hardware queues, each on a dispatch pipe of its own
+        # (streams.py).  With one edit lane the codec stays in the back stage on an unmasked stream (round 3).
+        self.codec_stage = n > 1 if codec_stage is None else bool(codec_stage)
+        self.stages = [("front", ("front",), front), ("back", ("back",), back)]
+        if codec_queue not in ("front", "chip", "lane"):
+            raise ValueError("codec_queue must be 'front' (the inversion partition's queue), 'chip' (an unmasked queue) or "
+                             "'lane' (the edit lane that edited the clip)")
+        self.codec_queue = codec_queue
+        if codec_queue == "lane":
+            # Round 5: with the split-K tables an edit lane needs 1.3 s per clip and gets one every 1.66 s (two lanes, front
+            # stage 0.83 s per clip): the lanes have the slack, the inversion queue has none.  The edited latent's VAE decode +
+            # two vocoder passes (44 ms on the whole chip, ~110 ms on 64 CUs) run on the lane that edited the clip, in stream
+            # order after its loop; no codec stage, and the next clip's set-up goes back to a side stream (round 3's
+            # overlap_prep) so that the inversion queue carries the two U-Net calls and little else.
+            self.codec_stage = False
+        if self.codec_stage:
+            front[0].prep = None
+            # "chip" (round 5 A/B): the codec jobs on an UNMASKED queue of their own -- 44 ms of throughput kernels per clip
+            # leave the inversion queue (the critical stage once the edit lanes got faster) and take whatever CU is free
+            cq = front[0].lane if codec_queue == "front" else Lane(dev, index=70)
+            self.stages.append(("codec", ("codec",), [_Worker("codec", 0, self._view(), cq, None)]))
+        self.queue_log = []
+        if separate_queues is None:
+            separate_queues = n > 1
+        if separate_queues and hasattr(self.lane_type, "respin") and dev.type == "cuda":
+            # every lane that is busy at the same time needs its own dispatch pipe (streams.py)
+            from .streams import separate_queues as _separate
+            busy = [front[0].lane] + [w.lane for w in back]            # (the first stream is never replaced)
+            kept = _separate(busy, log=self.queue_log)
+            for w, ps in zip(back, kept[1:1 + n]):
+                w.lane = ps
+        # Drain: when the front stage has finished its last inversion, its CUs idle while the last edit loops run on
+        # their 64-CU lanes for another ~1.6 s.  Each edit lane gets a second queue over its own CUs PLUS its share of
+        # the inversion partition; the edit loop is issued in chunks of a few steps and moves there once the front
+        # stage is done (editing.LoopPlumbing._replay_in_chunks).  Same engines, same graphs, same values.
+        inv = self.total - self.edit_cus
+        if widen_on_drain and per and n > 1 and inv % 32 == 0 and inv // 32 >= n:
+            # the inversion partition is handed out in 32-CU units (a legal mask gives every shader engine of every XCD the
+            # same number of CUs): lane k gets units // n of them, the first units % n lanes one more
+            units, lo = inv // 32, self.edit_cus
+            for k, w in enumerate(back):
+                take = 32 * (units // n + (1 if k < units % n else 0))
+                w.wide = Lane(dev, cus=list(lane_cus(k)) + list(range(lo, lo + take)), total=self.total, index=50 + k)
+                lo += take
             if separate_queues and hasattr(self.lane_type, "respin") and dev.type == "cuda":
-                # every lane that is busy at the same time needs its own dispatch pipe (streams.py)
+                # busy together in the drain: the inversion queue (codec jobs) and the widened lanes
                 from .streams import separate_queues as _separate
-                busy = [front[0].lane] + [w.lane for w in back]            # (the first stream is never replaced)
-                kept = _separate(busy, log=self.queue_log)
-                for w, ps in zip(back, kept[1:1 + n]):
-                    w.lane = ps
-            # Drain: when the front stage has finished its last inversion, its CUs idle while the last edit loops run on
-            # their 64-CU lanes for another ~1.6 s.  Each edit lane gets a second queue over its own CUs PLUS its share of
-            # the inversion partition; the edit loop is issued in chunks of a few steps and moves there once the front
-            # stage is done (editing.LoopPlumbing._replay_in_chunks).  Same engines, same graphs, same values.
-            inv = self.total - self.edit_cus
-            if widen_on_drain and per and n > 1 and inv % 32 == 0 and inv // 32 >= n:
-                # the inversion partition is handed out in 32-CU units (a legal mask gives every shader engine of every XCD the
-                # same number of CUs): lane k gets units // n of them, the first units % n lanes one more
-                units, lo = inv // 32, self.edit_cus
-                for k, w in enumerate(back):
-                    take = 32 * (units // n + (1 if k < units % n else 0))
-                    w.wide = Lane(dev, cus=list(lane_cus(k)) + list(range(lo, lo + take)), total=self.total, index=50 + k)
-                    lo += take
-                if separate_queues and hasattr(self.lane_type, "respin") and dev.type == "cuda":
-                    # busy together in the drain: the inversion queue (codec jobs) and the widened lanes
-                    from .streams import separate_queues as _separate
-                    self.drain_queue_log = []
-                    kept = _separate([front[0].lane] + [w.wide for w in back], log=self.drain_queue_log)
-                    for w, ps in zip(back, kept[1:]):
-                        w.wide = ps
-            if widen_on_drain and self.edit_group > 1 and n == 1:
-                # one group lane: when the front stage has drained, the running group loop continues on the lane's unmasked queue
-                back[0].wide = back[0].full
-        else:
-            n = DEFAULT_LANES if lanes is None else int(lanes)
-            if n < 1:
-                raise ValueError("lanes must be >= 1")
-            self.edit_cus, self.edit_lanes = None, n
-            # lane_cus: every lane is a mini-chip of its own -- lane k owns CUs [k * lane_cus, (k + 1) * lane_cus) and runs whole
-            # clips there with the timestep-batched inversion (the inversion's CU-time does not depend on the partition size, the
-            # edit loop's falls with it: NOTES.md).  None: unmasked streams and the reference's step order (round 3's
-            # measurement: saturates at 1.6x of one chain).
-            self.lane_cus = None if lane_cus is None else int(lane_cus)
-            if self.lane_cus is not None:
-                if self.lane_cus % 32 or self.lane_cus < 32 or n * self.lane_cus > self.total:
-                    raise ValueError(f"{n} lanes of {self.lane_cus} CUs: a lane must be a multiple of 32 CUs and all of them "
-                                     f"fit the {self.total} CUs of the chip")
-                if self.timestep_group < 2:
-                    raise ValueError("masked lanes run the timestep-batched inversion (timestep_group >= 2)")
-            regime = None
-            for name, lo, hi in (("cus128", 96, 160), ("cus64", 24, 80)):
-                if self.lane_cus is not None and lo <= self.lane_cus <= hi and name in tape_mod.REGIME_TABLES:
-                    regime = name
-            cus_of = (lambda k: None) if self.lane_cus is None else \
-                (lambda k: range(k * self.lane_cus, (k + 1) * self.lane_cus))
-            self.stages = [("clip", ("front", "back"),
-                            [_Worker("clip", k, self._view(), Lane(dev, cus=cus_of(k), total=self.total, index=1 + k), None,
-                                     regime=regime) for k in range(n)])]
-            self.queue_log = []
-            if separate_queues is None:
-                separate_queues = self.lane_cus is not None and n > 1
-            if separate_queues and hasattr(self.lane_type, "respin") and dev.type == "cuda":
-                from .streams import separate_queues as _separate     # one dispatch pipe per busy lane (streams.py)
-                ws = self.stages[0][2]
-                for w, ps in zip(ws, _separate([w.lane for w in ws], log=self.queue_log)):
-                    w.lane = ps
+                self.drain_queue_log = []
+                kept = _separate([front[0].lane] + [w.wide for w in back], log=self.drain_queue_log)
+                for w, ps in zip(back, kept[1:]):
+                    w.wide = ps
         self._build_lock = threading.Lock()     # an un-warmed worker builds engines (and lazily folds shared weights)
         # The codec worker issues on the FRONT lane's stream from its own thread.  hipStreamBeginCapture(ThreadLocal) does not keep
         # another thread's launches out of a capturing stream: a late graph capture of the front worker (a new loop shape after
@@ -348,9 +283,8 @@ class ClipPipeline:
 
     def _claim_noise(self, job, index, shape, T, helper=False):
         """Clip `index`'s T noise maps, drawn ONCE per job: whoever claims the index first -- the consumer itself or a helper
-        thread running ahead -- draws them at the clip's turn; everybody else waits for that draw.  (With one front lane there
-        is one claimant per clip anyway; with work stealing several lanes reach their draws concurrently, and two draws of one
-        clip would both pass the gate at its turn and interleave on the global generator.)"""
+        thread running ahead -- draws them at the clip's turn; everybody else waits for that draw (two draws of one clip would
+        both pass the gate at its turn and interleave on the global generator)."""
         with job["lock"]:
             box = job["prefetch"].get(index)
             mine = box is None
@@ -460,40 +394,6 @@ class ClipPipeline:
         with self._stream_ctx(cs):
             return self._decode(v, w_edit, f["x0"])
 
-    def _back_group(self, w, st, job, fs):
-        """The edit loops of len(fs) clips in LOCKSTEP (inversion_utils.py:221-315 for each of them): one U-Net call per
-        diffusion step over the rows [uncond x g | target x g] (editing.EditEngine.edit with n = g: the layout of BASELINE
-        config 3's per-rank batch).  Returns one codec payload per clip."""
-        v, a = w.view, job["a"]
-        Z, g = int(a["tstart"]), len(fs)
-        for f in fs:
-            st.wait_event(f["done"])
-            for t in (f["x0"], f["zs"], f["wts"]):
-                if t.is_cuda:
-                    t.record_stream(st)
-        if w.wide is not None and st is w.lane.stream:
-            def chooser():          # the widened lane once the front stage has issued AND finished its last inversion
-                with job["lock"]:
-                    ev = job["front_event"]
-                    drained = job["stage_done"][0] and (ev is None or ev.query())
-                if drained:
-                    self.widened.add(w.k)
-                return w.wide.stream if drained else None
-            v._lane_chooser = chooser
-        try:
-            ed = v.editor(fs[0]["wts"].shape[-2], fs[0]["wts"].shape[-1])
-            x_z = ed.to_nhwc(torch.stack([f["wts"][Z] for f in fs]))                  # x_tstart of every clip   [g, H, W, C]
-            zs = ed.to_nhwc(torch.stack([f["zs"][:Z] for f in fs], 1))                # their noise maps         [Z, g, H, W, C]
-            cond_tgt = conditioning_from_text(v, v.encode_text(a["tgt"])).repeat(g)
-            cond_neg = conditioning_from_text(v, v.encode_text(a["neg"], negative=True))
-            w_edit = ed.to_nchw(ed.edit(x_z.unsqueeze(0).expand(Z + 1, *x_z.shape), zs, Z, cond_tgt, cond_neg, a["cfg_tar"],
-                                        eta=float(a["eta"])))
-        finally:
-            v._lane_chooser = None
-        edited = self.event_type()
-        edited.record(st)           # (_run_graph made st wait for whichever stream the last chunk of the loop ran on)
-        return [dict(x0=f["x0"], w_edit=w_edit[k:k + 1], done=edited) for k, f in enumerate(fs)]
-
     @staticmethod
     def _decode(v, w_edit, x0):
         x0_dec = v.vae_decode(w_edit)
@@ -517,8 +417,6 @@ class ClipPipeline:
         """The worker's partition -- or the whole chip while no other stage has work (fill / drain)."""
         if w.full is None or len(self.stages) == 1:
             return w.lane
-        if stage_idx == 0 and self.steal:
-            return w.lane               # the lanes invert clips of their own from the first moment: no whole-chip fill
         with job["lock"]:
             if stage_idx == 0:
                 idle = job["busy"][1] == 0 and job["queues"][1].qsize() == 0
@@ -532,11 +430,7 @@ class ClipPipeline:
         guard = self._build_lock if not w.warm else contextlib.nullcontext()
         with guard, tape_mod.tile_regime(w.regime), torch.inference_mode(), self._on(w, lane) as st:
             if "front" in halves:
-                if w.stage == "back":       # a stolen clip: the lane's inversion engines take the FRONT stage's tiles (same values)
-                    with tape_mod.tile_regime(getattr(self, "_front_regime", None)):
-                        payload = self._front(w, st, job, i)
-                else:
-                    payload = self._front(w, st, job, i)
+                payload = self._front(w, st, job, i)
             if "back" in halves:
                 payload = self._back(w, st, job, payload, with_codec=not getattr(self, "codec_stage", False))
             if "codec" in halves:
@@ -544,75 +438,14 @@ class ClipPipeline:
         w.warm = True
         return payload
 
-    def _process_group(self, w, job, fs, lane):
-        """A group of front-stage payloads through the back half on `lane` (group plan)."""
-        guard = self._build_lock if not w.warm else contextlib.nullcontext()
-        with guard, tape_mod.tile_regime(w.regime), torch.inference_mode(), self._on(w, lane) as st:
-            out = self._back_group(w, st, job, fs)
-        return out
-
-    def _run_group_worker(self, w, stage_idx, job):
-        """Back-stage worker of the group plan: takes every clip whose inversion is ready -- up to `edit_group`, rounded down to
-        a size an engine exists for (`group_sizes`) -- and steps them in lockstep.  Greedy on purpose: with a slow front stage
-        the groups stay small (latency), with a fast one they grow until the lane keeps up (throughput)."""
-        q = job["queues"][stage_idx]
-        pending, stopped = [], False
-        while True:
-            if not pending:
-                if stopped:
-                    return
-                got = q.get()
-                if got is _STOP:
-                    return
-                pending.append(got)
-            deadline = time.perf_counter() + self.group_wait_s
-            while len(pending) < self.edit_group and not stopped:
-                try:
-                    left = deadline - time.perf_counter()
-                    got = q.get(timeout=left) if left > 0 else q.get_nowait()
-                except queue.Empty:
-                    break
-                if got is _STOP:
-                    stopped = True
-                else:
-                    pending.append(got)
-            if job["error"] is not None:
-                return
-            g = max(s for s in self.group_sizes if s <= len(pending))
-            batch, pending = pending[:g], pending[g:]
-            self.group_log.append(g)
-            with job["lock"]:
-                job["busy"][stage_idx] += 1
-            t0 = time.perf_counter()
-            try:
-                outs = self._process_group(w, job, [f for _, f in batch], self._pick_lane(w, job, stage_idx))
-                w.warm = True
-            except BaseException as e:                          # noqa: BLE001 -- reported by edit_clips
-                with job["lock"]:
-                    if job["error"] is None:
-                        job["error"] = (batch[0][0], e)
-                return
-            finally:
-                with job["lock"]:
-                    job["busy"][stage_idx] -= 1
-            t1 = time.perf_counter()
-            for (i, _), payload in zip(batch, outs):
-                job["times"].append(dict(clip=i, stage=w.stage, worker=w.k, start=t0 - job["t0"], end=t1 - job["t0"],
-                                         group=g))
-                job["queues"][stage_idx + 1].put((i, payload))
-
     def _run_worker(self, w, stage_idx, halves, job):
-        if self.edit_group > 1 and halves == ("back",):
-            return self._run_group_worker(w, stage_idx, job)
         gate = job["gate"]
         v = w.view
-        stealing = self.steal and w.stage == "back"
-        if "front" in halves or stealing:
+        if "front" in halves:
             v.sample_xts_from_x0 = self._gated_sample(v, job)
         last_stage = stage_idx == len(self.stages) - 1
         try:
             while True:
-                run = halves
                 if stage_idx == 0:
                     with job["lock"]:
                         i = job["next"]
@@ -621,58 +454,26 @@ class ClipPipeline:
                         return
                     payload = None
                 else:
-                    got = None
-                    while got is None:
-                        try:
-                            got = job["queues"][stage_idx].get(timeout=0.005 if stealing else None)
-                        except queue.Empty:
-                            with job["lock"]:       # nothing to edit: take an unstarted clip, unless the run's tail has begun
-                                i = job["next"]
-                                take = len(job["items"]) - i >= self.steal_min_remaining and job["error"] is None
-                                if take:
-                                    job["next"] += 1
-                                    job["stealers"] += 1
-                            if take:
-                                got, run = (i, None), ("front",) + tuple(halves)
-                                self.stolen.append(i)
+                    got = job["queues"][stage_idx].get()
                     if got is _STOP or job["error"] is not None:
                         return
-                    ev = got[1].get("done") if (stealing and run == halves and isinstance(got[1], dict)) else None
-                    if ev is not None and not ev.query():
-                        # the queued clip's inversion is still running on the front partition (the front worker's HOST thread
-                        # runs ahead of its queue): editing it now means waiting.  If no other lane is inverting a clip of its
-                        # own, hand the payload back and take an unstarted clip instead.
-                        with job["lock"]:
-                            i2 = job["next"]
-                            take = (len(job["items"]) - i2 >= self.steal_min_remaining and job["error"] is None
-                                    and job["stealers"] == 0)
-                            if take:
-                                job["next"] += 1
-                                job["stealers"] += 1
-                        if take:
-                            job["queues"][stage_idx].put(got)
-                            got, run = (i2, None), ("front",) + tuple(halves)
-                            self.stolen.append(i2)
                     i, payload = got
                 v._clip_index, v._clip_seed, v._clip_drew = i, job["seeds"][i], False
                 with job["lock"]:
                     job["busy"][stage_idx] += 1
                 t0 = time.perf_counter()
                 try:
-                    payload = self._process(w, stage_idx, run, job, i, payload,
-                                            w.lane if "front" in run and stage_idx else self._pick_lane(w, job, stage_idx))
+                    payload = self._process(w, stage_idx, halves, job, i, payload, self._pick_lane(w, job, stage_idx))
                 except BaseException as e:                          # noqa: BLE001 -- reported by edit_clips
                     with job["lock"]:
                         if job["error"] is None:
                             job["error"] = (i, e)
-                    if "front" in run:
+                    if "front" in halves:
                         gate.done(i, failed=not v._clip_drew)
                     return
                 finally:
                     with job["lock"]:
                         job["busy"][stage_idx] -= 1
-                        if stage_idx and "front" in run:
-                            job["stealers"] -= 1
                 job["times"].append(dict(clip=i, stage=w.stage, worker=w.k, start=t0 - job["t0"],
                                          end=time.perf_counter() - job["t0"]))
                 if last_stage:
@@ -713,17 +514,15 @@ class ClipPipeline:
         return dict(items=list(items), seeds=seeds, prepare=prepare, a=a, out=[None] * K, next=0, uniform=uniform,
                     prefetch={}, lock=threading.Lock(), error=None, gate=_DrawGate(), t0=time.perf_counter(), times=[],
                     queues=[queue.Queue() for _ in self.stages], busy=[0] * len(self.stages),
-                    stage_done=[False] * len(self.stages), front_event=None, stealers=0)
+                    stage_done=[False] * len(self.stages), front_event=None)
 
     def _args(self, source_prompt, target_prompt, target_neg_prompt, cfg_src, cfg_tar, T, tstart, eta):
         if len(source_prompt) != 1 or len(target_prompt) != 1:
             raise ValueError("ClipPipeline edits with one source and one target prompt")
         if isinstance(tstart, (list, tuple)):
             tstart = tstart[0]
-        batched = self.plan == "partition" or getattr(self, "lane_cus", None) is not None
         return dict(src=source_prompt, tgt=target_prompt, neg=target_neg_prompt, cfg_src=cfg_src, cfg_tar=cfg_tar, T=T,
-                    tstart=int(tstart), eta=eta, schedule="batched" if batched else "sequential",
-                    group=self.timestep_group if batched else 1)
+                    tstart=int(tstart), eta=eta, schedule="batched", group=self.timestep_group)
 
     def edit_clips(self, items, source_prompt, target_prompt, target_neg_prompt, cfg_src, cfg_tar, T, tstart, eta=1.0,
                    prepare=None, seeds=None):
@@ -736,8 +535,6 @@ class ClipPipeline:
                                                           cfg_tar, T, tstart, eta))
         self.stats, self._times = [], job["times"]
         self.widened = set()
-        self.group_log = []
-        self.stolen = []
         if not job["items"]:
             return []
         self._base = None
@@ -752,6 +549,9 @@ class ClipPipeline:
         if job["error"] is not None:
             i, e = job["error"]
             raise RuntimeError(f"clip {i} failed in the clip pipeline: {e!r}") from e
+        missing = [i for i, o in enumerate(job["out"]) if o is None]
+        if missing:
+            raise RuntimeError(f"clips {missing} left the clip pipeline without an output")
         return job["out"]
 
     def warm_up(self, item, source_prompt, target_prompt, target_neg_prompt, cfg_src, cfg_tar, T, tstart, eta=1.0,
@@ -763,24 +563,14 @@ class ClipPipeline:
         payload = None
         for s, (_, halves, ws) in enumerate(self.stages):
             outs = []
-            if self.edit_group > 1 and halves == ("back",):
-                # one engine + loop plan + step graph per group size (U-Net batch 2g); the clip is simply repeated
-                for w in ws:
-                    job = self._job([item], [seed], prepare, a)
-                    for g in self.group_sizes:
-                        outs = self._process_group(w, job, [payload] * g, w.lane)
-                    w.warm = True
-                payload = outs[0]
-                continue
             for w in ws:
                 job = self._job([item], [seed], prepare, a)
                 v = w.view
                 v._clip_index, v._clip_seed, v._clip_drew = 0, seed, False
-                run = ("front",) + tuple(halves) if (self.steal and w.stage == "back") else halves
-                if "front" in run:
+                if "front" in halves:
                     v.sample_xts_from_x0 = self._gated_sample(v, job)
                 try:
-                    outs.append(self._process(w, s, run, job, 0, payload, w.lane))
+                    outs.append(self._process(w, s, halves, job, 0, payload, w.lane))
                 finally:
                     v.__dict__.pop("sample_xts_from_x0", None)
             payload = outs[0]
@@ -806,13 +596,11 @@ class ClipPipeline:
             d[0], d[1] = min(d[0], t["start"]), max(d[1], t["end"])
         lats = [1e3 * (b - a) for a, b in lat.values()]
         return dict(plan=self.plan, launch=self.launch, clips_in_flight=self.clips_in_flight, total_cus=self.total,
-                    edit_cus=self.edit_cus, edit_lanes=self.edit_lanes, edit_lane_cus=getattr(self, "edit_lane_cus", None), lane_cus=getattr(self, "lane_cus", None),
-                    inversion_cus=None if self.edit_cus is None else self.total - self.edit_cus,
+                    edit_cus=self.edit_cus, edit_lanes=self.edit_lanes, edit_lane_cus=getattr(self, "edit_lane_cus", None),
+                    inversion_cus=self.total - self.edit_cus, setup_stream_masked_to_inversion_partition=getattr(self, "mask_prep", False),
                     device_ms={k: dict(n=len(v), avg=sum(v) / len(v)) for k, v in acc.items()},
                     queue_separation=getattr(self, "queue_log", None), timeline=timeline,
                     widened_on_drain=sorted(getattr(self, "widened", ())),
-                    edit_group=self.edit_group, group_sizes=self.group_sizes, groups_formed=list(self.group_log),
-                    steal=self.steal, clips_inverted_by_edit_lanes=sorted(self.stolen),
                     drain_queue_separation=getattr(self, "drain_queue_log", None),
                     clip_latency_ms_avg=(sum(lats) / len(lats)) if lats else None,
                     clip_latency_ms_max=max(lats) if lats else None)

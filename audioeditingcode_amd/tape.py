@@ -65,15 +65,6 @@ for _reg, _mod in ((None, "tile_table_x6"), ("cus128", "tile_table_x6_cus128"), 
         X6_TABLES[_reg] = dict(__import__(f"{__package__}.{_mod}", fromlist=["TILE_TABLE"]).TILE_TABLE)
     except ImportError:
         pass
-# Round 5: the lockstep batch shapes of the group plan (U-Net batches 4 / 8 / 16 on an edit lane; pipeline.ClipPipeline
-# edit_group), swept on 64- and 96-CU streams (profiles/r05_sweeps/).  Keys are (M, N, K, geglu): a shape that also occurs at
-# batch 2 / 200 keeps the entry of the table it was first swept for.
-for _reg, _mod in (("cus128", "tile_table_x6_cus128_groups"), ("cus64", "tile_table_x6_cus64_groups")):
-    try:
-        for _k, _v in __import__(f"{__package__}.{_mod}", fromlist=["TILE_TABLE"]).TILE_TABLE.items():
-            X6_TABLES.setdefault(_reg, {}).setdefault(_k, _v)
-    except ImportError:
-        pass
 REGIME_CUS = {"cus128": 128, "cus64": 64}       # CUs of the stream a regime's engines run on
 _regime = threading.local()
 

@@ -208,28 +208,17 @@ def main():
     ap.add_argument("--clips-per-gpu", type=int, default=1,
                     help="independent clips edited together per step and GPU (BASELINE configs[2]: 8; default: the "
                          "headline configs[1] shape, 1)")
-    ap.add_argument("--plan", default="partition", choices=["partition", "lanes", "serial"],
+    ap.add_argument("--plan", default="partition", choices=["partition", "serial"],
                     help="how clips share the GPU (pipeline.ClipPipeline): 'partition' = clip i's edit loop and clip i+1's "
-                         "inversion on disjoint CU partitions; 'lanes' = --lanes whole clips at once in the reference's "
-                         "step order; 'serial' = one clip at a time")
+                         "inversion on disjoint CU partitions; 'serial' = one clip at a time")
     ap.add_argument("--edit-cus", type=int, default=128, help="partition plan: CUs of the edit-loop partition")
     ap.add_argument("--edit-lanes", type=int, default=2,
                     help="partition plan: concurrent edit loops (disjoint CU slices of the edit partition where they are "
                          "multiples of 32 CUs, shared otherwise)")
-    ap.add_argument("--edit-group", type=int, default=1,
-                    help="partition plan: an edit lane steps up to this many clips in lockstep (U-Net batch 2g for the g clips whose "
-                         "inversions are ready when the lane becomes free; pipeline.ClipPipeline `edit_group`); 1 = every clip alone "
-                         "in its U-Net batches (rounds 3-4)")
-    ap.add_argument("--steal", action="store_true",
-                    help="partition plan: an edit lane with an empty queue inverts the next unstarted clip itself "
-                         "(pipeline.ClipPipeline `steal`)")
-    ap.add_argument("--no-steal", action="store_true", help="switch --steal off where it is the default")
     ap.add_argument("--codec-queue", default="lane", choices=["front", "chip", "lane"],
                     help="partition plan: where the edited latent's VAE decode + vocoder run -- 'lane' (default since round 5): on the "
                          "edit lane that edited the clip (the lanes have the slack: 1.3 s of work per 1.66 s); 'front': a codec stage "
                          "on the inversion partition's queue (round 4); 'chip': a codec stage on an unmasked queue of its own")
-    ap.add_argument("--group-wait-ms", type=float, default=0.0,
-                    help="group plan: how long a free edit lane waits for a full group before it takes the clips that are ready")
     ap.add_argument("--arith", default="bf16x6", choices=["f32", "bf16x6"],
                     help="arithmetic of the U-Net engines' LDS-staged GEMMs: bf16x6 (default, the product since round 4) = every "
                          "fp32 operand cut exactly into three bf16 pieces in the loader, six piece products on the bf16 MFMAs, "
@@ -238,10 +227,6 @@ def main():
     ap.add_argument("--codec-arith", default=None, choices=["f32", "bf16x6"],
                     help="arithmetic of the codec engines' LDS-staged GEMMs (STFT-as-DFT, VAE, vocoder); default: the wrapper's "
                          "`codec_arith`")
-    ap.add_argument("--lanes", type=int, default=3, help="lanes plan: clips in flight")
-    ap.add_argument("--lane-cus", type=int, default=0,
-                    help="lanes plan: every lane on its own slice of this many CUs (a multiple of 32), whole clips with the "
-                         "timestep-batched inversion there; 0 = unmasked streams and the reference's step order")
     ap.add_argument("--lane-launch", default="graph", choices=["eager", "graph"],
                     help="how a pipeline worker issues one diffusion step: one hipGraphLaunch (default) or launch by launch")
     ap.add_argument("--no-overlap-prep", action="store_true",
@@ -254,6 +239,11 @@ def main():
                     help="DDIM steps of the config-1 CPU anchor clip measured end to end through the oracle (0 = skip; BASELINE "
                          "configs[0] is 50 steps: the un-extrapolated anchor SURVEY 8(d) asks for, ~50-110 s of CPU on the box's "
                          "host; round 4 cut it to 12 steps and extrapolated)")
+    ap.add_argument("--unmasked-prep", action="store_true",
+                    help="A/B: the next clip's set-up on an UNMASKED side stream (rounds 3-5) instead of one masked to the inversion "
+                         "partition's CUs (pipeline.ClipPipeline `mask_prep`)")
+    ap.add_argument("--no-share-in-edit-loop", action="store_true",
+                    help="A/B: CFG row sharing in the inversion only (round 5's shipped configuration; EditEngine.SHARE_IN_EDIT_LOOP)")
     ap.add_argument("--no-share-cfg-rows", action="store_true",
                     help="A/B: every classifier-free-guidance row through the whole U-Net graph (rounds 1-4) instead of computing "
                          "the context-free head once per latent (EditEngine.SHARE_CFG_ROWS)")
@@ -263,6 +253,7 @@ def main():
 
     from audioeditingcode_amd import configs, dist as adist, editing, models, weights
     editing.EditEngine.SHARE_CFG_ROWS = not args.no_share_cfg_rows
+    editing.EditEngine.SHARE_IN_EDIT_LOOP = not args.no_share_in_edit_loop
     from audioeditingcode_amd.main_run import edit_clip
     from audioeditingcode_amd.utils import prepare_waveform, synthetic_clip
 
@@ -271,7 +262,8 @@ def main():
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
     # N ranks share the host: cap torch's intra-op CPU threads per rank and pin each rank to its slice of the cores
-    rank_resources = adist.pin_rank_resources(local, world) if world > 1 else dict(torch_threads=torch.get_num_threads())
+    rank_resources = (adist.pin_rank_resources(local, adist.local_world_size(world)) if world > 1
+                      else dict(torch_threads=torch.get_num_threads()))
 
     # ---- weights: rank 0 materialises them, everyone else receives them over RCCL
     fam = configs.get_family(args.model_id)
@@ -403,12 +395,9 @@ def main():
     if PLAN != "serial":
         from audioeditingcode_amd.pipeline import ClipPipeline
         try:
-            pipe = ClipPipeline(m, plan=PLAN, edit_cus=args.edit_cus, edit_lanes=args.edit_lanes, lanes=args.lanes,
-                                launch=args.lane_launch, timestep_group=args.group, overlap_prep=not args.no_overlap_prep,
-                                **({"lane_cus": args.lane_cus} if args.lane_cus else {}),
-                                **({"edit_group": args.edit_group, "group_wait_s": 1e-3 * args.group_wait_ms,
-                                    "codec_queue": args.codec_queue, "steal": args.steal and not args.no_steal}
-                                   if PLAN == "partition" else {}))
+            pipe = ClipPipeline(m, plan=PLAN, edit_cus=args.edit_cus, edit_lanes=args.edit_lanes, launch=args.lane_launch,
+                                timestep_group=args.group, overlap_prep=not args.no_overlap_prep, codec_queue=args.codec_queue,
+                                mask_prep=not args.unmasked_prep)
             dt, gathered = timed_pipeline(args.steps, args.warmup)
         except Exception as e:                                  # noqa: BLE001
             # a driver / container without CU-masked streams (hipExtStreamCreateWithCUMask, HSA_CU_MASK set, <= edit_cus CUs)
@@ -418,27 +407,17 @@ def main():
             pipe, PLAN = None, "serial"
     if PLAN != "serial":
         extra["pipeline"] = pipe.report()
-        if PLAN == "partition":
-            lanes_txt = (f"{pipe.edit_lanes} edit loops on disjoint {pipe.edit_lane_cus}-CU lanes" if pipe.edit_lanes > 1 and
-                         pipe.edit_lane_cus != pipe.edit_cus else f"{pipe.edit_lanes} edit loop(s) on {pipe.edit_cus} CUs")
-            group_plan = getattr(pipe, "edit_group", 1) > 1
-            if group_plan:
-                lanes_txt += (f", each stepping up to {pipe.edit_group} clips in lockstep (U-Net batch 2g for the g clips whose "
-                              f"inversions are ready; groups formed in this run: {extra['pipeline'].get('groups_formed')})")
-            headline = (f"a STREAM of {args.steps} clips per GPU (throughput of the stream, not the latency of one clip: "
-                        f"`value_single_clip_batched` is the clip alone), "
-                        + ("every clip alone in its inversion U-Net batches, " if group_plan else
-                           f"up to {pipe.clips_in_flight} clips in flight, each alone in its U-Net batches: ")
-                        + f"forward inversion ({args.group} timesteps per U-Net call) on {pipe.total - pipe.edit_cus} CUs beside {lanes_txt}"
-                        + ("; VAE decode + vocoder as a third stage on the inversion partition's queue, between its inversions"
-                           if getattr(pipe, "codec_stage", False) else
-                           ("; VAE decode + vocoder on the edit lane that edited the clip, the next clip's set-up on a side stream"
-                            if getattr(pipe, "codec_queue", "") == "lane" else "")))
-        elif args.lane_cus:
-            headline = (f"{pipe.clips_in_flight} whole clips in flight per GPU, each on its own {args.lane_cus}-CU slice of the chip "
-                        f"(timestep-batched inversion, {args.group} timesteps per U-Net call, then the edit loop)")
-        else:
-            headline = f"reference step order, {pipe.clips_in_flight} whole clips in flight per GPU on as many HIP streams"
+        lanes_txt = (f"{pipe.edit_lanes} edit loops on disjoint {pipe.edit_lane_cus}-CU lanes" if pipe.edit_lanes > 1 and
+                     pipe.edit_lane_cus != pipe.edit_cus else f"{pipe.edit_lanes} edit loop(s) on {pipe.edit_cus} CUs")
+        headline = (f"a STREAM of {args.steps} clips per GPU (throughput of the stream, not the latency of one clip: "
+                    f"`value_single_clip_batched` is the clip alone), "
+                    f"up to {pipe.clips_in_flight} clips in flight, each alone in its U-Net batches: "
+                    + f"forward inversion ({args.group} timesteps per U-Net call) on {pipe.total - pipe.edit_cus} CUs beside {lanes_txt}"
+                    + ("; VAE decode + vocoder as a third stage on the inversion partition's queue, between its inversions"
+                       if getattr(pipe, "codec_stage", False) else
+                       ("; VAE decode + vocoder on the edit lane that edited the clip, the next clip's set-up on a side stream"
+                        + (" masked to the inversion partition" if getattr(pipe, "mask_prep", False) else "")
+                        if getattr(pipe, "codec_queue", "") == "lane" else "")))
         log(f"{PLAN} pipeline: {dt / args.steps:.3f} s/clip  {json.dumps(extra['pipeline'])}")
     else:
         dt, gathered = timed(args.schedule, args.steps, args.warmup)
@@ -500,15 +479,7 @@ def main():
                     rel_l2_vs_plain_serial_leg=vs_plain, plain_serial_schedule=twin)
                 log(f"pipeline vs the same clips alone through the same engines, {n_cmp} clips: bit-identical={same}, "
                     f"max |diff| {worst:.2e}; vs the plain {twin} leg: rel L2 {vs_plain:.2e}")
-                grouped_edit = getattr(pipe, "edit_group", 1) > 1
-                if grouped_edit:
-                    # group plan: a clip's rows ride in U-Net batches of 2g rows -- other tiles / split-K orders per batch shape,
-                    # so the clip alone (g = 1) agrees to fp32 rounding, not bit for bit
-                    vs_alone = rel(gathered[0][:n_cmp], alone)
-                    extra["pipeline_vs_one_clip_at_a_time"]["rel_l2_vs_same_engines_alone"] = vs_alone
-                    assert vs_alone < 1e-4, f"grouped edit loops deviate from the clips edited alone by {vs_alone:.3e}"
-                else:
-                    assert same, f"clip results changed under the clip pipeline (max |diff| {worst:.3e})"
+                assert same, f"clip results changed under the clip pipeline (max |diff| {worst:.3e})"
                 assert vs_plain < 5e-3, f"pipeline deviates from the plain serial leg by {vs_plain:.3e}"
 
     # ---- where one clip's time goes when it has the GPU to itself (single-clip latency mode: batched inversion)
@@ -727,8 +698,7 @@ def roofline_leg(m, pipe, args, NC, dt):
     G = max(1, min(args.group // NC if NC > 1 else args.group, args.T))
     while args.T % G:
         G -= 1
-    sequential_headline = (pipe is None and args.schedule == "sequential") or \
-        (pipe is not None and pipe.plan == "lanes" and not getattr(pipe, "lane_cus", None))
+    sequential_headline = pipe is None and args.schedule == "sequential"
     B_inv = 2 * NC if sequential_headline else 2 * G * NC
     views = [m] + ([w.view for w in pipe.workers] if pipe is not None else [])
     whole = torch.cuda.Stream(device=dev)
@@ -778,10 +748,10 @@ def roofline_leg(m, pipe, args, NC, dt):
                                    ms_as_graph=graph_ms(eng_f, front.lane.stream, 3), families=fam_f,
                                    note="the front stage's forward alone on its CU partition (nothing on the other CUs): the "
                                         "half-loaded chip holds a higher clock than the whole chip under the bf16 MFMA stream")
-        # ---- the edit loop's step on the edit lane, for every group size an engine exists for
+        # ---- the edit loop's step on the edit lane
         back = [w for w in pipe.workers if w.stage == "back"]
         steps = {}
-        for g in sorted(set(getattr(pipe, "group_sizes", [1]))):
+        for g in (1,):
             e = _find_engine([back[0].view], 2 * g * NC)
             if e is None:
                 continue
@@ -920,7 +890,7 @@ def sub_benchmarks(elapsed_s):
     one JSON line; a failure or timeout is recorded, never fatal."""
     py, env = sys.executable, dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
     jobs = [("config3_per_rank", [py, os.path.join(ROOT, "bench.py"), "--clips-per-gpu", "8", "--steps", "1", "--warmup",
-                                  "1", "--lanes", "1", "--no-extras", "--no-cpu-baseline", "--no-batched"], 240),
+                                  "1", "--no-extras", "--no-cpu-baseline", "--no-batched"], 240),
             ("config4_pc_extract_apply", [py, os.path.join(ROOT, "tools", "bench_config4.py")], 300),
             ("config5_stable_audio", [py, os.path.join(ROOT, "tools", "bench_stable_audio.py"), "--steps", "1",
                                            "--warmup", "1"], 300),

@@ -129,16 +129,12 @@ class _Pipe:
     """pipeline.ClipPipeline stand-in: workers with lane views / streams, clips handed back in order."""
     made = []
 
-    def __init__(self, model, plan="partition", edit_cus=None, edit_lanes=1, lanes=None, launch="graph", timestep_group=100,
-                 overlap_prep=True, edit_group=1, group_wait_s=0.0, codec_queue="front", steal=False):
-        assert launch in ("eager", "graph") and plan in ("partition", "lanes")
+    def __init__(self, model, plan="partition", edit_cus=None, edit_lanes=1, launch="graph", timestep_group=100,
+                 overlap_prep=True, codec_queue="front", mask_prep=True):
+        assert launch in ("eager", "graph") and plan == "partition"
         self.plan, self.total, self.edit_cus, self.edit_lanes = plan, 256, edit_cus, edit_lanes
-        self.edit_group, self.group_sizes = edit_group, [1]
-        self.edit_lane_cus, self.codec_stage = edit_cus, False
-        if plan == "partition":
-            self.workers = [_W("front", _Model([2 * timestep_group]))] + [_W("back", _Model([2])) for _ in range(edit_lanes)]
-        else:
-            self.workers = [_W("clip", _Model([2])) for _ in range(lanes)]
+        self.edit_lane_cus, self.codec_stage, self.codec_queue, self.mask_prep = edit_cus, False, codec_queue, mask_prep
+        self.workers = [_W("front", _Model([2 * timestep_group]))] + [_W("back", _Model([2])) for _ in range(edit_lanes)]
         self.clips_in_flight = len(self.workers)
         self.calls = []
         _Pipe.made.append(self)
@@ -217,13 +213,8 @@ def test_default_line_has_the_contract_keys():
         plain_serial_schedule="batched")
 
 
-def test_lanes_plan_single_clip_schedules_and_multi_clip_mode():
+def test_serial_plan_single_clip_schedules_and_multi_clip_mode():
     _Pipe.made.clear()
-    out = _run(["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--plan", "lanes", "--lanes", "3",
-                "--group", "20"], [2, 40])
-    assert out["config"]["clips_in_flight_per_gpu"] == 3 and "reference step order" in out["config"]["workload"]
-    assert out["roofline"]["forward"]["unet_batch"] == 2 and "on_partition" not in out["roofline"]
-    assert out["pipeline_vs_one_clip_at_a_time"]["plain_serial_schedule"] == "sequential"
     out = _run(["--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--plan", "serial", "--schedule",
                 "sequential", "--group", "20"], [2, 40])
     assert "value_single_clip_batched" in out and "reference order" in out["config"]["workload"]

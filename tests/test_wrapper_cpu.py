@@ -365,13 +365,13 @@ def _fake_hip_for_pipeline(monkeypatch, log):
     return ClipPipeline
 
 
-def test_clip_pipeline_plans_equal_serial_edit_clip(cpu_stack, monkeypatch):
+def test_clip_pipeline_equals_serial_edit_clip(cpu_stack, monkeypatch):
     """pipeline.ClipPipeline on the CPU stack with recording stand-ins for the HIP streams / events.
     Partition plan (front stage: inversion on CUs [96,256) | back stage: edit loop on CUs [0,96), 2 edit lanes): every
     clip equals main_run.edit_clip with the batched inversion, bit for bit, with per-clip seeds; fill runs on the whole
-    chip, steady state on the partitions; every back half waits for its clip's front-half event.  Lanes plan (whole clips
-    in the reference order, 2 lanes): equals the sequential edit_clip with per-clip seeds and with one continuous global
-    generator stream.  Lane views share the frozen weights and own their engines; a failing clip surfaces."""
+    chip, steady state on the partitions; every back half waits for its clip's front-half event; without per-clip seeds the
+    clips consume ONE continuous global generator stream in clip order.  Lane views share the frozen weights and own their
+    engines; a failing clip surfaces; the next clip's set-up stream is masked to the inversion partition (round 6)."""
     log = []
     ClipPipeline = _fake_hip_for_pipeline(monkeypatch, log)
     threads = torch.get_num_threads()
@@ -382,12 +382,10 @@ def test_clip_pipeline_plans_equal_serial_edit_clip(cpu_stack, monkeypatch):
         mels = [load_audio((synthetic_clip(seconds=0.32, seed=7 + i), 16000), m.get_fn_STFT(), device="cpu", stft=True)[0]
                 for i in range(3)]
         args = (["a dog barking"], ["a cat meowing"], [""], [3.0], [12.0], T, tstart)
-        serial_b, serial_s = [], []
+        serial_b = []
         for i, x0 in enumerate(mels):
             torch.manual_seed(40 + i)
             serial_b.append(edit_clip(m, x0, *args, schedule="batched", timestep_group=3))
-            torch.manual_seed(40 + i)
-            serial_s.append(edit_clip(m, x0, *args))
         # ---- partition plan
         seen = []
         ed_cls = type(m.editor(mels[0].shape[-2] // 4, mels[0].shape[-1] // 4))
@@ -415,17 +413,13 @@ def test_clip_pipeline_plans_equal_serial_edit_clip(cpu_stack, monkeypatch):
                                                         widen_on_drain=False).workers)
         # 64-CU lanes and the 128-CU inversion partition take the tile tables swept on streams of that size (round 4)
         assert split.edit_lane_cus == 64 and split.workers[1].regime == "cus64" and split.workers[0].regime == "cus128"
-        quad = ClipPipeline(m, plan="lanes", lanes=4, lane_cus=64, timestep_group=3)       # four mini-chips, whole clips each
-        assert [w.lane.cus for w in quad.workers] == [list(range(64 * k, 64 * k + 64)) for k in range(4)]
-        assert quad._args(["a"], ["b"], [""], [3.0], [12.0], 6, 4, 1.0)["schedule"] == "batched"
-        quad.warm_up(mels[0], *args)
-        for (a, o, w), (a2, o2, w2) in zip(quad.edit_clips(mels, *args, seeds=[40, 41, 42]), serial_b):
-            assert torch.equal(a, a2) and torch.equal(o, o2) and torch.equal(w, w2)
-        quad.close()
+        # the next clip's set-up stream is masked to the inversion partition (round 6); mask_prep=False: the unmasked queue of rounds 3-5
+        lane_q = ClipPipeline(m, plan="partition", edit_cus=128, edit_lanes=2, timestep_group=3, codec_queue="lane")
+        assert lane_q.workers[0].prep.cus == list(range(128, 256)) and lane_q.report()["setup_stream_masked_to_inversion_partition"]
+        assert ClipPipeline(m, plan="partition", edit_cus=128, edit_lanes=2, timestep_group=3, codec_queue="lane",
+                            mask_prep=False).workers[0].prep.cus is None
         with pytest.raises(ValueError):
-            ClipPipeline(m, plan="lanes", lanes=5, lane_cus=64)
-        with pytest.raises(ValueError):
-            ClipPipeline(m, plan="lanes", lanes=2, lane_cus=48)
+            ClipPipeline(m, plan="lanes")
         v0, v1 = pipe.workers[0].view, pipe.workers[1].view
         assert v0.unet_weights is m.unet_weights and v0.state_dicts is m.state_dicts and v0.model is m.model
         assert v0._engines is not m._engines and v0._editors is not v1._editors
@@ -451,71 +445,16 @@ def test_clip_pipeline_plans_equal_serial_edit_clip(cpu_stack, monkeypatch):
             ClipPipeline(m, plan="partition", edit_cus=256)
         with pytest.raises(ValueError):
             ClipPipeline(m, plan="partition", timestep_group=1)
-        # ---- lanes plan (reference order)
-        lanes = ClipPipeline(m, plan="lanes", lanes=2)
-        lanes.warm_up(mels[0], *args)
-        got = lanes.edit_clips(mels, *args, seeds=[40, 41, 42])
-        for (a, o, w), (a2, o2, w2) in zip(got, serial_s):
-            assert torch.equal(a, a2) and torch.equal(o, o2) and torch.equal(w, w2)
+        # ---- no per-clip seeds: one global generator stream, consumed in clip order
         torch.manual_seed(99)
-        ref = [edit_clip(m, x0, *args) for x0 in mels[:2]]
+        ref = [edit_clip(m, x0, *args, schedule="batched", timestep_group=3) for x0 in mels[:2]]
         after = torch.randn(2)
         torch.manual_seed(99)
-        got = lanes.edit_clips(mels[:2], *args)             # no per-clip seeds: one global stream, consumed in clip order
+        got = pipe.edit_clips(mels[:2], *args)
         for (a, o, w), (a2, o2, w2) in zip(got, ref):
             assert torch.equal(a, a2) and torch.equal(w, w2)
         assert torch.equal(torch.randn(2), after)           # and the generator ends where the serial loop leaves it
-        assert "sample_xts_from_x0" not in lanes.workers[0].view.__dict__      # the gated draw hook is removed again
-    finally:
-        torch.set_num_threads(threads)
-
-
-def test_clip_pipeline_group_plan_on_cpu(cpu_stack, monkeypatch):
-    """Group plan (round 5): the back stage steps the edit loops of several clips in LOCKSTEP (U-Net batch 2g) -- every clip
-    equals the clip edited alone to fp32 rounding (its rows of the batch are its own arithmetic; the batch shape only changes
-    tile / summation choices), groups are formed from the engine sizes that exist, every clip reaches the codec stage once."""
-    log = []
-    ClipPipeline = _fake_hip_for_pipeline(monkeypatch, log)
-    threads = torch.get_num_threads()
-    torch.set_num_threads(2)
-    try:
-        T, tstart = 3, 2
-        m = _model(T)
-        mels = [load_audio((synthetic_clip(seconds=0.32, seed=7 + i), 16000), m.get_fn_STFT(), device="cpu", stft=True)[0]
-                for i in range(5)]
-        args = (["a dog barking"], ["a cat meowing"], [""], [3.0], [12.0], T, tstart)
-        serial = []
-        for i, x0 in enumerate(mels):
-            torch.manual_seed(40 + i)
-            serial.append(edit_clip(m, x0, *args, schedule="batched", timestep_group=3))
-        with pytest.raises(ValueError):
-            ClipPipeline(m, plan="lanes", edit_group=2)
-        with pytest.raises(ValueError):
-            ClipPipeline(m, plan="partition", edit_cus=96, edit_group=2, codec_stage=False, timestep_group=3)
-        # a free lane waits (here: as long as it takes) for a full group of 2; the fifth clip goes alone
-        pipe = ClipPipeline(m, plan="partition", edit_cus=96, edit_group=2, timestep_group=3, group_wait_s=60.0)
-        assert [w.stage for w in pipe.workers] == ["front", "back", "codec"] and pipe.codec_stage and pipe.group_sizes == [1, 2]
-        assert pipe.workers[1].wide is pipe.workers[1].full          # drain: the group loop moves to the lane's unmasked queue
-        assert ClipPipeline(m, plan="partition", edit_cus=96, edit_group=8, timestep_group=3).group_sizes == [1, 2, 4, 8]
-        assert ClipPipeline(m, plan="partition", edit_cus=96, edit_group=6, group_sizes=[3, 6, 9], timestep_group=3).group_sizes \
-            == [1, 3, 6]
-        pipe.warm_up(mels[0], *args)
-        assert all(w.warm for w in pipe.workers)
-        ed = pipe.workers[1].view.editor(mels[0].shape[-2] // 4, mels[0].shape[-1] // 4)
-        assert sorted(k[1] for k in ed._plans if k[0] == "edit") == [1, 2]          # one loop plan per group size
-        got = pipe.edit_clips(mels, *args, seeds=[40 + i for i in range(5)])
-        rep = pipe.report()
-        assert rep["groups_formed"] == [2, 2, 1] and rep["edit_group"] == 2
-        for i, ((a, o, w), (a2, o2, w2)) in enumerate(zip(got, serial)):
-            assert rel(w, w2) < 2e-5 and rel(a, a2) < 2e-4, (i, rel(w, w2), rel(a, a2))
-            assert torch.equal(o, o2)                                # the original's vocoding does not pass the edit loop
-        # greedy (no wait): whatever is ready goes; every clip is edited exactly once whatever the grouping was
-        greedy = ClipPipeline(m, plan="partition", edit_cus=96, edit_group=4, timestep_group=3)
-        greedy.warm_up(mels[0], *args)
-        got = greedy.edit_clips(mels, *args, seeds=[40 + i for i in range(5)])
-        assert sum(greedy.report()["groups_formed"]) == 5 and set(greedy.report()["groups_formed"]) <= {1, 2, 4}
-        for (a, o, w), (a2, o2, w2) in zip(got, serial):
-            assert rel(w, w2) < 2e-5
+        assert "sample_xts_from_x0" not in pipe.workers[0].view.__dict__      # the gated draw hook is removed again
     finally:
         torch.set_num_threads(threads)
 
@@ -541,8 +480,6 @@ def test_clip_pipeline_codec_on_the_edit_lanes_on_cpu(cpu_stack, monkeypatch):
         assert [w.stage for w in pipe.workers] == ["front", "back", "back"] and not pipe.codec_stage
         assert pipe.workers[0].prep is not None                      # the set-up of the next clip overlaps the running inversion
         with pytest.raises(ValueError):
-            ClipPipeline(m, plan="partition", edit_cus=96, edit_group=2, timestep_group=3, codec_queue="lane")
-        with pytest.raises(ValueError):
             ClipPipeline(m, plan="partition", edit_cus=96, timestep_group=3, codec_queue="somewhere")
         pipe.warm_up(mels[0], *args)
         log.clear()
@@ -555,49 +492,10 @@ def test_clip_pipeline_codec_on_the_edit_lanes_on_cpu(cpu_stack, monkeypatch):
         torch.set_num_threads(threads)
 
 
-def test_clip_pipeline_work_stealing_on_cpu(cpu_stack, monkeypatch):
-    """steal=True (round 5): an edit lane with an empty queue inverts the next unstarted clip itself; a clip's values do not
-    depend on who inverted it, the tail of the run stays with the front stage, every clip is edited exactly once."""
-    log = []
-    ClipPipeline = _fake_hip_for_pipeline(monkeypatch, log)
-    threads = torch.get_num_threads()
-    torch.set_num_threads(2)
-    try:
-        T, tstart = 3, 2
-        m = _model(T)
-        mels = [load_audio((synthetic_clip(seconds=0.32, seed=7 + i), 16000), m.get_fn_STFT(), device="cpu", stft=True)[0]
-                for i in range(7)]
-        args = (["a dog barking"], ["a cat meowing"], [""], [3.0], [12.0], T, tstart)
-        serial = []
-        for i, x0 in enumerate(mels):
-            torch.manual_seed(40 + i)
-            serial.append(edit_clip(m, x0, *args, schedule="batched", timestep_group=3))
-        pipe = ClipPipeline(m, plan="partition", edit_cus=128, edit_lanes=2, timestep_group=3, steal=True, steal_min_remaining=3)
-        assert pipe.steal and not ClipPipeline(m, plan="partition", edit_cus=96, edit_group=2, timestep_group=3, steal=True).steal
-        pipe.warm_up(mels[0], *args)
-        back = [w for w in pipe.workers if w.stage == "back"]
-        for w in back:                          # a lane that may steal owns an inversion engine (U-Net batch 2 G) besides its edit engine
-            ed = w.view.editor(mels[0].shape[-2] // 4, mels[0].shape[-1] // 4)
-            assert sorted({k[0] for k in ed._plans}) == ["edit", "invert"]
-        got = pipe.edit_clips(mels, *args, seeds=[40 + i for i in range(7)])
-        rep = pipe.report()
-        stolen = rep["clips_inverted_by_edit_lanes"]
-        assert rep["steal"] and all(c <= 7 - 3 for c in stolen), stolen          # the last clips belong to the front stage
-        assert len(stolen) >= 1                  # (the CPU front stage is slow: the idle lanes do take clips)
-        for i, ((a, o, w), (a2, o2, w2)) in enumerate(zip(got, serial)):
-            assert torch.equal(w, w2) and torch.equal(a, a2) and torch.equal(o, o2), (i, stolen)
-        # one clip alone: nothing to steal
-        one = pipe.edit_clips(mels[:1], *args, seeds=[40])
-        assert pipe.report()["clips_inverted_by_edit_lanes"] == [] and torch.equal(one[0][2], serial[0][2])
-    finally:
-        torch.set_num_threads(threads)
-
-
 def test_noise_maps_of_a_clip_are_drawn_once_whoever_asks():
     """ClipPipeline._claim_noise: several lanes (and the helper thread running one clip ahead) may ask for the same clip's noise
     maps at the same moment; exactly one of them draws, at the clip's turn in the global draw order, and every asker sees that
-    draw.  (Two draws of one clip would both pass the order gate and interleave on the global generator -- what the full-size
-    work-stealing test caught on the MI355X in round 5.)"""
+    draw.  (Two draws of one clip would both pass the order gate and interleave on the global generator.)"""
     import threading
     from audioeditingcode_amd.pipeline import ClipPipeline, _DrawGate
     K, T, shape = 6, 5, (1, 2, 8, 4)

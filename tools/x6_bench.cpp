@@ -254,22 +254,7 @@ static int run_wide_cases(hipStream_t st) {
     int bad = 0;
     for (const Case& c : cases) bad += run_case(c, st, 12 | 256);
     fprintf(stderr, "wide-chunk cases: %d of %d failed\n", bad, (int)(sizeof(cases) / sizeof(cases[0])));
-    // deep prefetch (flag bit 9) on the 256-thread tiles 2 / 3 / 4
-    const Case deep[] = {
-        {"deep: 3x3 same, tile 4",                   4, 32, 16,  64,  64, 3, 3, 1, 1, 1, 1, 1, 0, 32, 16,  0, 0, 0, 0, 0, 0, 1, 1, 0, 4},
-        {"deep: 3x3 two-source A, tile 3",           4, 32, 16, 192, 128, 3, 3, 1, 1, 1, 1, 1, 0, 32, 16, 64, 0, 0, 0, 0, 0, 1, 1, 0, 3},
-        {"deep: 1x1 two-source + residual, tile 2",  4, 32, 16, 128, 128, 1, 1, 1, 0, 0, 1, 1, 0, 32, 16, 64, 0, 0, 1, 0, 0, 1, 1, 0, 2},
-        {"deep: 3x3 SiLU(A) + row vector + res, t4", 4, 32, 16,  64,  64, 3, 3, 1, 1, 1, 1, 1, 0, 32, 16,  0, 1, 0, 1, 1, 0, 1, 1, 0, 4},
-        {"deep: linear K = 96 (3 chunks), tile 3",   1, 1024, 1,  96, 192, 1, 1, 1, 0, 0, 1, 1, 0, 1024, 1, 0, 0, 0, 0, 0, 0, 1, 1, 0, 3},
-        {"deep: linear K = 640, tile 2",             1,  128, 1, 640, 640, 1, 1, 1, 0, 0, 1, 1, 0,  128, 1, 0, 0, 0, 1, 0, 0, 1, 1, 0, 2},
-        {"deep: 3x3 split-K 8, 128 rows, tile 3",    2, 32,  2, 640, 640, 3, 3, 1, 1, 1, 1, 1, 0, 32,  2,  0, 0, 0, 1, 0, 0, 8, 1, 0, 3},
-        {"deep: 3x3 stride 2, tile 4",               4, 32, 16,  64, 128, 3, 3, 2, 1, 1, 1, 1, 0, 16,  8,  0, 0, 0, 0, 0, 0, 1, 1, 0, 4},
-        {"deep: ragged M = 1000, N = 136, tile 3",   5, 20, 10,  32, 136, 3, 3, 1, 1, 1, 1, 1, 0, 20, 10,  0, 0, 0, 0, 0, 0, 1, 1, 0, 3},
-    };
-    int bad2 = 0;
-    for (const Case& c : deep) bad2 += run_case(c, st, 12 | 256 | 512);
-    fprintf(stderr, "deep-prefetch cases: %d of %d failed\n", bad2, (int)(sizeof(deep) / sizeof(deep[0])));
-    return bad + bad2;
+    return bad;
 }
 
 // ---- replay: the AED_OP_CONV_GEMM records of a whole U-Net forward (tools/dump_gemm_ops.py), each in both arithmetics ------
@@ -475,10 +460,8 @@ static int run_sweep(const char* path, int R, hipStream_t st, bool with_x6) {
         // at the edit loop's batch: a 128-row 3x3 convolution streams up to 29 MB of weights through a handful of workgroups
         // (~0.2 TB/s on a 64-CU lane).  K split across blockIdx.z gives every CU a slice of the weight stream; the partial slabs
         // are summed in a fixed order by AED_OP_SPLITK_REDUCE (second launch).  Not for LayerNorm-fold / GEGLU records (unsplit).
-        // tile codes 200 + t: the split-bf16 kernel with op flag bits 8 | 9 (32-wide chunks, four of them in flight: "deep")
-        if (!generic && with_x6 && M <= 8192) for (int t : (geglu ? std::vector<int>{3} : std::vector<int>{2, 3, 4})) cand.push_back(200 + t);
         if (!generic && !geglu && !i[31] && M <= 2048 && K >= 1024 && !i[27])
-            for (int t : (with_x6 ? std::vector<int>{4, 2, 104, 102, 103, 204, 202, 203} : std::vector<int>{4, 2}))
+            for (int t : (with_x6 ? std::vector<int>{4, 2, 104, 102, 103} : std::vector<int>{4, 2}))
                 for (int ks : {2, 4, 8, 16, 32})
                     if (K / 32 / ks >= 4 && (long)((M + 63) / 64) * ((N + 63) / 64) * ks <= 4096) cand.push_back(t + 1000 * ks);
         const size_t wbytes = (size_t)N * K * 4, step = (wbytes + 4095) / 4096 * 4096, span = POOL - wbytes - 4096;
@@ -493,7 +476,7 @@ static int run_sweep(const char* path, int R, hipStream_t st, bool with_x6) {
             op.code = AED_OP_CONV_GEMM;
             memcpy(op.i, r.i, sizeof(op.i));
             memcpy(op.f, r.f, sizeof(r.f));
-            op.flags = t >= 200 ? (12 | 256 | 512) : (t >= 100 ? 12 : 0);
+            op.flags = t >= 100 ? 12 : 0;
             op.i[29] = t % 100;
             op.i[28] = ks;
             op.p[0] = A; op.p[2] = r.have[0] ? bias : nullptr; op.p[3] = C; op.p[4] = r.have[1] ? res : nullptr;

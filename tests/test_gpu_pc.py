@@ -239,3 +239,113 @@ def test_full_size_power_iteration_vs_the_oracle_fixture(golden_dir):
     assert one[0] < 5e-5 and min(one[2]) > 0.99999, one              # one application of the Jacobian
     assert full[0] < 2e-3 and min(full[2]) > 0.9997, full           # five un-contracting iterations
     assert e_drift < 1e-4, e_drift
+
+
+def test_config4_three_consecutive_drift_timesteps_at_full_size(golden_dir):
+    """BASELINE config 4's OUTER loops at full size with the chained state between timesteps (round 6), through the product's own
+    `main_pc_extract_inv.extract_pcs` and `main_pc_apply_drift.apply_pcs`: AudioLDM2 (346.9 M), T = 200, drift window 120 -> 117
+    (trajectory iterations 80, 81, 82 after 80 guided lead-in steps), n_evs = 4, 5 power iterations per timestep, the
+    sign-continuity rule between consecutive timesteps, then apply_drift along PCs 1 + 2 with the drifted x_{t-1} feeding the next
+    step -- against the CPU oracle's run of the same loops (tests/golden/fullsize_pc_chain.npz, oracle/make_fullsize_pc_chain_
+    golden.py; the reference's main_pc_extract_inv.py:199-256 and main_pc_apply_drift.py:141-191).  Start vectors come from the
+    fixture's recipe on both sides (step 1: seeded draws; steps 2, 3: minus the oracle's previous PCs, so that the sign rule
+    fires).  Random weights give a flat spectrum: PCs are compared as subspaces and eigenvalues sorted, as in the one-timestep
+    test above; per-PC quantities (corrs, flips) are compared when the per-vector ordering agrees, which is printed."""
+    import numpy as np
+    from types import SimpleNamespace
+    from audioeditingcode_amd import main_pc_apply_drift as apply_mod, main_pc_extract_inv as extract_mod
+    from oracle.make_fullsize_pc_chain_golden import (AMOUNT, CFG, CONST, CORR_TO_SWAP, DRIFT_END, DRIFT_START, EVS, IT0, IT1,
+                                                      ITERS, N_EV, T, inputs)
+    path = os.path.join(golden_dir, "fullsize_pc_chain.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/fullsize_pc_chain.npz: run oracle/make_fullsize_pc_chain_golden.py")
+    fx = np.load(path)
+    assert (int(fx["T"]), list(fx["drift"]), int(fx["n_ev"]), int(fx["iters"])) == (T, [DRIFT_START, DRIFT_END], N_EV, ITERS)
+    f = lambda k: torch.from_numpy(fx[k])                                                             # noqa: E731
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())                    # noqa: E731
+    m = models.load_model("cvssp/audioldm2", DEV, T, seed=0, allow_synthetic=True)       # U-Net = random_state_dict(seed 0)
+    unc, txt, latents, init0 = inputs()
+    emb = lambda d: PromptEmbeddings(embedding_hidden_states=d["encoder_hidden_states"].to(DEV),     # noqa: E731
+                                     embedding_class_lables=d["encoder_hidden_states_1"].to(DEV),
+                                     boolean_prompt_mask=d["encoder_attention_mask_1"].to(DEV))
+    e_unc, e_txt = emb(unc), emb(txt)
+    assert [int(t) for t in m.model.scheduler.timesteps[IT0:IT1]] == [int(t) for t in fx["timesteps"]]
+
+    # ---- extraction through extract_pcs: seeded text embeddings, the seeded trajectory latents instead of an inversion, start
+    # vectors injected into get_eigenvectors (its `init_eigvecs` hook); the guided steps and the power iterations are the product's
+    calls = dict(n=0)
+
+    def fake_inversion(model, w0, **kw):
+        zs = torch.cat(latents[1:]).flip(0).to(DEV)                                     # extract_pcs flips them back
+        wts = torch.cat([torch.zeros_like(latents[0])] * T + [latents[0]]).to(DEV)     # only wts[-1] = x_T is read
+        return None, zs, wts, None
+
+    def get_eigenvectors(model, xt, text_emb, uncond_emb, lat, mask, t, x0_pred, pc_mode, const, cfg_tar, iters, dp, eta, n_ev):
+        j = calls["n"]
+        calls["n"] += 1
+        init = init0 if j == 0 else -f("eigvec")[j - 1]
+        return pc_drift.get_eigenvectors(model, xt, text_emb, uncond_emb, lat, mask, t, x0_pred, pc_mode, const, cfg_tar, iters,
+                                         dp, eta, n_ev, init_eigvecs=init)
+    fns = SimpleNamespace(forward_directional=pc_drift.forward_directional, get_eigenvectors=get_eigenvectors,
+                          PCStreamChoice=pc_drift.PCStreamChoice, inversion_forward_process=fake_inversion,
+                          get_text_embeddings=lambda a, b, model: (None, e_txt, e_unc))
+    args = extract_mod.finish_args(extract_mod.build_parser().parse_args(
+        ["--model_id", "cvssp/audioldm2", "--num_diffusion_steps", str(T), "--drift_start", str(DRIFT_START), "--drift_end",
+         str(DRIFT_END), "--n_evs", str(N_EV), "--iters", str(ITERS), "--const", str(CONST), "--cfg_tar", str(CFG),
+         "--corr_to_swap", str(CORR_TO_SWAP), "--source_prompt", "p", "--allow_synthetic"]))
+    ck = extract_mod.extract_pcs(m, torch.zeros(1, 8, 256, 16, device=DEV), args, fns=fns)
+    torch.cuda.synchronize()
+    assert calls["n"] == IT1 - IT0 and sorted(ck["eigdata"]) == sorted(int(t) for t in fx["timesteps"])
+    # the guided trajectory: 83 chained steps
+    e_traj = [rel(ck["xts"][it].cpu(), f("xts")[it - IT0:it - IT0 + 1]) for it in range(IT0, IT1 + 1)]
+    report, same_order = [], True
+    for j, t in enumerate(int(t) for t in fx["timesteps"]):
+        ev_c = ck["eigdata"][t]["eigvec"].reshape(N_EV, -1)
+        val_c = ck["eigdata"][t]["eigval"].reshape(-1)
+        ev_o, val_o = f("eigvec")[j].reshape(N_EV, -1), f("eigval")[j]
+        e_val = float(((val_c.sort().values - val_o.sort().values).abs() / val_o.sort().values).max())
+        cos = (ev_c * ev_o).sum(1)
+        principal = torch.linalg.svdvals(ev_c.double() @ ev_o.double().T)
+        assert ((ev_c @ ev_c.T) - torch.eye(N_EV)).abs().max() < 1e-4
+        report.append((t, e_val, [round(float(c), 5) for c in cos], round(float(principal.min()), 6)))
+        same_order &= bool((cos.abs() > 0.99).all())
+        assert e_val < 2e-3 and principal.min() > 0.9997, report[-1]
+    print(f"config 4 chain at full size, HIP vs oracle: trajectory rel {[f'{e:.1e}' for e in e_traj]}; per timestep (t, eigenvalues "
+          f"max rel, per-PC cos, min principal cos): {report}; per-PC order agrees: {same_order}")
+    assert max(e_traj) < 1e-4, e_traj
+    corr_c = torch.stack([c.cpu() for c in ck["corrs"]])
+    assert corr_c.shape == (IT1 - IT0 - 1, N_EV) and (corr_c > -CORR_TO_SWAP).all()      # the rule left no PC pointing backwards
+    for j in range(1, IT1 - IT0):               # stored corrs = correlation of the STORED (post-flip) consecutive PCs
+        ts = [int(t) for t in fx["timesteps"]]
+        a, b = ck["eigdata"][ts[j - 1]]["eigvec"].reshape(N_EV, -1), ck["eigdata"][ts[j]]["eigvec"].reshape(N_EV, -1)
+        assert ((a * b).sum(1) - corr_c[j - 1]).abs().max() < 1e-4
+    assert f("flips").any(), "the fixture's recipe is meant to make the sign rule fire"
+    if same_order:
+        # (start vectors are minus the ORACLE's previous PCs on both sides, so the pre-flip correlations are about -|c|: the product
+        # must have flipped exactly where the oracle did, and ended at the same post-flip correlations)
+        assert (corr_c - f("corrs")).abs().max() < 2e-2, (corr_c, f("corrs"))
+        for j, t in enumerate(int(t) for t in fx["timesteps"]):
+            assert ((ck["eigdata"][t]["eigvec"].reshape(N_EV, -1) * f("eigvec")[j].reshape(N_EV, -1)).sum(1) > 0.99).all(), (j, t)
+
+    # ---- the drifted trajectory through apply_pcs, with the ORACLE's PCs (a 1e-3 difference between two near-degenerate PCs must
+    # not decide which direction the sample is pushed): the drifted x_{t-1} of each window step feeds the next
+    seen = {}
+
+    def forward_directional(model, xt, t, *a, **k):
+        seen[len(seen)] = xt.detach().clone()              # call `it` sees the state after step it - 1
+        return pc_drift.forward_directional(model, xt, t, *a, **k)
+    load = dict(args=args, latents=[x.to(DEV) for x in latents], xts=None,
+                eigdata={int(t): dict(eigvec=f("eigvec")[j], eigval=f("eigval")[j]) for j, t in enumerate(fx["timesteps"])})
+    a_args = apply_mod.build_parser().parse_args(["--extraction_path", "unused", "--drift_start", str(DRIFT_START), "--drift_end",
+                                                  str(DRIFT_END), "--amount", str(AMOUNT), "--evs", *[str(e) for e in EVS],
+                                                  "--combine_evs"])
+    a_args.shift_x0_for_np, a_args.sub_iters = True, None
+    fns_a = SimpleNamespace(forward_directional=forward_directional, apply_drift=pc_drift.apply_drift,
+                            PCStreamChoice=pc_drift.PCStreamChoice, get_text_embeddings=lambda a, b, model: (None, e_txt, e_unc))
+    final = apply_mod.apply_pcs(m, load, a_args, torch.device(DEV), fns=fns_a)
+    torch.cuda.synchronize()
+    e_drift = [rel(seen[it + 1].cpu(), f("drifted")[it - IT0:it - IT0 + 1]) for it in range(IT0, IT1)]
+    moved = rel(seen[IT1].cpu(), f("xts")[IT1 - IT0:IT1 - IT0 + 1])
+    print(f"drifted trajectory over the window, HIP vs oracle: rel {[f'{e:.1e}' for e in e_drift]}; drifted vs undrifted x at the "
+          f"window's end: rel {moved:.2e}")
+    assert max(e_drift) < 1e-4 and moved > 1e-3 and torch.isfinite(final).all(), (e_drift, moved)

@@ -38,17 +38,23 @@ def family(n):
 PEAK_BF16 = 2500.0
 
 
-def tape_flops(B):
+def tape_flops(B, share=None):
     """(algorithmic GEMM flops, algorithmic forward flops, #ops, executed fp32-equivalent flops of the records the split-bf16
     kernel takes, ... of the records on fp32-input MFMAs) of the U-Net tape at batch B, laid out on the CPU in the product's
-    arithmetic (tape.arith_mode("bf16x6"), whole-chip tile tables)."""
+    arithmetic (tape.arith_mode("bf16x6"), whole-chip tile tables) AND with the product's CFG row sharing (share = 2: the traced
+    engines compute the context-free head once per [uncond | prompt] pair, so their EXECUTED flops are 3.6 % below the unshared
+    tape's -- round 5's trace summary counted the unshared tape and overstated the executed rate by that much; `AED_TRACE_SHARE=1`
+    counts the unshared tape for traces taken with --no-share-cfg-rows)."""
+    import os
+    if share is None:
+        share = int(os.environ.get("AED_TRACE_SHARE", "2"))
     import torch
     from audioeditingcode_amd import configs, tape as tape_mod, weights
     from audioeditingcode_amd.unet import UNetEngine
     fam = configs.FAMILIES["audioldm2"]
     sd = {k: torch.zeros(s) for k, s in weights.unet_param_shapes(fam["unet"]).items()}
     with tape_mod.arith_mode("bf16x6"):
-        eng = UNetEngine(fam["unet"], sd, "cpu", B, 256, 16, ctx_len0=8, ctx_len1=16)
+        eng = UNetEngine(fam["unet"], sd, "cpu", B, 256, 16, ctx_len0=8, ctx_len1=16, share=share if B % share == 0 else 1)
     conv = sum(m["flops"] for m in eng.tape.meta if m["code"] == 1)
     x6 = sum(m["exec_flops"] for op, m in zip(eng.tape.ops, eng.tape.meta) if m["code"] == 1 and (op.flags & 4) and op.i[29] < 10)
     f32 = sum(m["exec_flops"] for op, m in zip(eng.tape.ops, eng.tape.meta) if m["code"] == 1 and not ((op.flags & 4) and op.i[29] < 10))

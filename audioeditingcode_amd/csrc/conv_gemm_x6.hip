@@ -216,10 +216,23 @@ __global__ __launch_bounds__(64 * WROWS * WCOLS, 2) void conv_gemm_x6_kernel(CGP
     };
 
     // one fetched float4 -> three 8-byte piece groups of its LDS row
-    auto put_row = [&](uint4* st, int row, float4 v) {
+    auto put_row = [&](uint4* st, int row, float4 v, bool is_w = false) {
         unsigned h0, m0_, l0, h1, m1, l1;
-        x6_split_pair(v.x, v.y, h0, m0_, l0);
-        x6_split_pair(v.z, v.w, h1, m1, l1);
+#ifdef X6_DIAG_NOSPLIT
+        // DIAGNOSTIC BUILD ONLY (tools/leases/r06_l17.sh; never in libaed.so): what would a loader WITHOUT the split cost?  The hi
+        // piece is computed (one v_cvt_pk per pair) and stored three times -- wrong values, representative time: an upper bound
+        // on what pre-split operands in HBM could give (1 = the W rows only, 2 = A and W), before their 1.5x load bytes.
+        if (X6_DIAG_NOSPLIT == 2 || is_w) {
+            h0 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){v.x, v.y}, bf16x2));
+            h1 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){v.z, v.w}, bf16x2));
+            m0_ = l0 = h0;
+            m1 = l1 = h1;
+        } else
+#endif
+        {
+            x6_split_pair(v.x, v.y, h0, m0_, l0);
+            x6_split_pair(v.z, v.w, h1, m1, l1);
+        }
         uint2* dst = reinterpret_cast<uint2*>(st + row * X6_ROWQ) + lq;      // piece pl starts at uint2 index 2 * PQ * pl
         dst[0] = make_uint2(h0, h1);
         dst[2 * PQ] = make_uint2(m0_, m1);
@@ -245,7 +258,7 @@ __global__ __launch_bounds__(64 * WROWS * WCOLS, 2) void conv_gemm_x6_kernel(CGP
             put_row(st, lrow + RPP * q, v);
         }
 #pragma unroll
-        for (int q = 0; q < PB; ++q) put_row(st, BM + lrow + RPP * q, rb[q]);
+        for (int q = 0; q < PB; ++q) put_row(st, BM + lrow + RPP * q, rb[q], true);
     };
 
     f32x16 acc[TM][TN];

@@ -79,6 +79,38 @@ def pin_rank_resources(local_rank: int, world: int, threads: int = None, affinit
     return dict(torch_threads=n, cores_visible=len(cores), cores_per_rank=per, affinity=pinned)
 
 
+def broadcast_family(sds, shapes: Dict[str, Dict[str, tuple]], device, on_device: bool = True):
+    """What every rank of `bench.py --gpus N` does before building its wrapper: receive the frozen component weights (U-Net, VAE,
+    vocoder) from rank 0 -- one `broadcast_state_dict` per component, in the order of `shapes` on every rank.  `sds` is rank 0's
+    {component: state dict} (None elsewhere).  Returns ({component: state dict on `device`}, seconds, bytes received)."""
+    import time
+    t0 = time.time()
+    out = {k: broadcast_state_dict(None if sds is None else sds[k], shapes[k], device, on_device=on_device) for k in shapes}
+    if torch.device(device).type == "cuda":
+        torch.cuda.synchronize(device)
+    nbytes = 4 * sum(_arena_shapes(shapes[k])[1] for k in shapes)
+    return out, time.time() - t0, nbytes
+
+
+def per_rank_rates(units: float, seconds: float, device) -> List[float]:
+    """all_gather of every rank's own rate (units / seconds BEFORE the closing barrier): shows whether one rank lags; the
+    whole-job value is computed from the max-over-ranks time by the caller, not from these."""
+    mine = torch.tensor([units / max(seconds, 1e-9)], dtype=torch.float64, device=device)
+    allr = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(allr, mine)
+    return [float(t.item()) for t in allr]
+
+
+def distributed_fields(world: int, t_bcast: float, nbytes: int, per_rank, rank_resources) -> Dict:
+    """The `config` fields of the bench line that describe the N-rank run; asserted by tests/test_dist_cpu.py so that the first
+    real 8-rank run prints a usable line."""
+    assert per_rank is None or (len(per_rank) == world and all(r > 0 for r in per_rank)), per_rank
+    return dict(weights_broadcast_s=t_bcast, weights_broadcast_GB=nbytes / 1e9,
+                weights_broadcast_GBps=(nbytes / 1e9 / t_bcast) if t_bcast > 0 else None,
+                per_rank_clips_per_s=per_rank, rank_resources=rank_resources,
+                slowest_rank_over_fastest=(min(per_rank) / max(per_rank)) if per_rank else None)
+
+
 def shard_clips(n_clips: int, rank: int, world: int) -> List[int]:
     """Round-robin clip -> rank map (clip i runs on rank i mod W)."""
     return list(range(rank, n_clips, world))

@@ -92,6 +92,8 @@ def tile_regime(name):
 #   MX-FP8 (e4m3 elements, one e8m0 scale per 32 k of a row) in the loader and run v_mfma_scale_f32_32x32x64_f8f6f4
 #   (conv_gemm_f8.hip); ops that kernel does not take (channel counts not a multiple of 64, ...) and attention run split-bf16.
 ARITH_FLAGS = {"f32": 0, "bf16x6": 4 | 8, "fp8": 64 | 4 | 8}
+FP8_ONLY = None         # fp8 EXPERIMENT: callable(op name) -> bool restricting arith_mode("fp8") to some records, the rest stay
+#                         split-bf16 (tools/fp8_layer_budget.py: which GEMM family carries how much of the deviation)
 DEFAULT_ARITH = "f32"   # arithmetic of engines built OUTSIDE any arith_mode context (tests/conftest.py --codec-arith sets it)
 
 
@@ -307,6 +309,8 @@ class Tape:
         n_out = N // 2 if geglu else N
         flags = 2 if LATE_EPILOGUE else 0
         arith = ARITH_FLAGS[getattr(_regime, "arith", None) or DEFAULT_ARITH]
+        if arith & 64 and FP8_ONLY is not None and not FP8_ONLY(name):
+            arith = ARITH_FLAGS["bf16x6"]
         x6_ok = arith and vec_ok and B * a_bs + IH * IW * lda < (1 << 29) and N * K < (1 << 29) and \
             (x2 is None or B * a_bs2 + IH * IW * lda2 < (1 << 29)) and not (w_bs or vec_bs or sm_group or vec_ld != 1) and \
             self._ptr(x) % 16 == 0 and self._ptr(w) % 16 == 0      # buffer_load_dwordx4 (the launcher's `fits`)

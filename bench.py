@@ -272,13 +272,10 @@ def main():
     sds = None
     if rank == 0:
         sds = {k: weights.random_state_dict(shapes[k], seed=i) for i, k in enumerate(("unet", "vae", "vocoder"))}
-    t0 = time.time()
     grouped = torch.distributed.is_available() and torch.distributed.is_initialized()
+    t_bcast, bcast_bytes = 0.0, 0
     if grouped:             # world > 1, or a one-rank RCCL group under torchrun (executes the same collectives)
-        sds = {k: adist.broadcast_state_dict(None if sds is None else sds[k], shapes[k], dev, on_device=True)
-               for k in shapes}
-        torch.cuda.synchronize()
-    t_bcast = time.time() - t0
+        sds, t_bcast, bcast_bytes = adist.broadcast_family(sds, shapes, dev, on_device=True)
     m = models.load_model(args.model_id, dev, args.T, state_dicts=sds, allow_synthetic=True)   # no checkpoint exists offline
     m.arith = args.arith        # lane views of the pipeline copy it
     if args.codec_arith is not None:
@@ -426,12 +423,7 @@ def main():
         log(f"{args.schedule}: {dt / args.steps:.3f} s/clip")
     value = world * NC * args.steps / dt
     # per-rank rates (the driver computes scaling efficiency from `value`; these show whether one rank lags)
-    per_rank = None
-    if grouped:
-        mine = torch.tensor([NC * args.steps / max(dt_local, 1e-9)], dtype=torch.float64, device=dev)
-        allr = [torch.zeros_like(mine) for _ in range(world)]
-        torch.distributed.all_gather(allr, mine)
-        per_rank = [float(t.item()) for t in allr]
+    per_rank = adist.per_rank_rates(NC * args.steps, dt_local, dev) if grouped else None
 
     # ---- the same clips ONE AT A TIME (same waveforms, same seeds): reference order, and the timestep-batched inversion.
     # Every one of the 600 sample-forwards of a clip is computed in all three schedules; batched only regroups the
@@ -554,9 +546,10 @@ def main():
                           "clips_per_gpu_per_step": NC,
                           "clips_in_flight_per_gpu": NC if pipe_info is None else pipe_info["clips_in_flight"],
                           "parallelism": f"clip-dp{world}" + ("" if pipe_info is None else f" x {PLAN} pipeline"),
-                          "arith": ARITH_TEXT[args.arith], "cfg_row_sharing": not args.no_share_cfg_rows, "codec_arith": getattr(m, "codec_arith", "f32"),
-                          "weights_broadcast_s": t_bcast if grouped else 0.0,
-                          "per_rank_clips_per_s": per_rank, "rank_resources": rank_resources,
+                          "arith": ARITH_TEXT[args.arith], "cfg_row_sharing": not args.no_share_cfg_rows,
+                          "cfg_row_sharing_in_edit_loop": not (args.no_share_cfg_rows or args.no_share_in_edit_loop),
+                          "codec_arith": getattr(m, "codec_arith", "f32"),
+                          **adist.distributed_fields(world, t_bcast if grouped else 0.0, bcast_bytes, per_rank, rank_resources),
                           "process_group": (torch.distributed.get_backend() if grouped else None),
                           "gathered_latents": None if gathered is None else [list(g.shape) for g in gathered][:2]},
                "roofline": roof, "cpu_baseline": base, "parity": parity, "phases_ms_one_clip_alone": phases}
@@ -766,7 +759,7 @@ def roofline_leg(m, pipe, args, NC, dt):
         out["edit_step"] = steps
     # ---- HBM-side traffic of the dominant family from the committed PMC passes (separate runs; only if taken on this source tree)
     traffic = traffic_note = None
-    for name in ("r05_pmc_forward.json", "r04_pmc_forward.json"):
+    for name in ("r06_pmc_forward.json", "r05_pmc_forward.json", "r04_pmc_forward.json"):
         pmc_path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(pmc_path):
             continue

@@ -121,12 +121,17 @@ def _bench_worker(rank, world, port, q):
     from audioeditingcode_amd import dist as adist
     r, w, local = adist.init_distributed(backend="gloo")
     adist.pin_rank_resources(local, w, threads=2)                     # per-rank thread cap + CPU affinity (bench.py does the same)
+    import time
     shapes, sds = _family_state_dicts()
-    sds = {k: adist.broadcast_state_dict(sds[k] if r == 0 else None, shapes[k], "cpu", max_bucket=400_000) for k in shapes}
+    sds, t_bcast, nbytes = adist.broadcast_family(sds if r == 0 else None, shapes, "cpu", on_device=False)     # bench.py's call
+    t0 = time.perf_counter()
     lat = _edit_share(r, w, sds)
+    dt_local = time.perf_counter() - t0
     gathered = adist.gather_to_rank0(lat)
+    rates = adist.per_rank_rates(len(adist.shard_clips(CLIPS, r, w)), dt_local, "cpu")                      # bench.py's call
+    fields = adist.distributed_fields(w, t_bcast, nbytes, rates, dict(torch_threads=2))
     adist.barrier()
-    q.put((r, None if gathered is None else [g.numpy() for g in gathered]))
+    q.put((r, None if gathered is None else [g.numpy() for g in gathered], fields))
 
 
 def test_bench_level_world_size_invariance_world2_vs_world1():
@@ -136,11 +141,21 @@ def test_bench_level_world_size_invariance_world2_vs_world1():
     procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=600) for _ in range(2))
+    got = [q.get(timeout=600) for _ in range(2)]
+    res = {r: g for r, g, _ in got}
+    fields = {r: f for r, _, f in got}
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res[1] is None and len(res[0]) == 2
+    # the N-rank fields of the bench line (bench.py builds them with the same three calls): every rank saw both rates, the
+    # broadcast moved the whole family, nothing is None that the first real 8-rank run needs
+    for r in (0, 1):
+        f = fields[r]
+        assert len(f["per_rank_clips_per_s"]) == 2 and min(f["per_rank_clips_per_s"]) > 0
+        assert f["per_rank_clips_per_s"] == fields[0]["per_rank_clips_per_s"]
+        assert f["weights_broadcast_s"] > 0 and f["weights_broadcast_GB"] > 0 and f["weights_broadcast_GBps"] > 0
+        assert 0 < f["slowest_rank_over_fastest"] <= 1
     sys.path.insert(0, ROOT)
     _, sds = _family_state_dicts()
     one = _edit_share(0, 1, sds)                                      # world 1: the same four clips in this process

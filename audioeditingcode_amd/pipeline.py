@@ -222,7 +222,9 @@ class ClipPipeline:
         # The codec worker issues on the FRONT lane's stream from its own thread.  hipStreamBeginCapture(ThreadLocal) does not keep
         # another thread's launches out of a capturing stream: a late graph capture of the front worker (a new loop shape after
         # warm-up, an LRU plan eviction) must not interleave with a codec job.  Every lane view carries this lock;
-        # LoopPlumbing._run_graph holds it while capturing, _codec while issuing.
+        # LoopPlumbing._run_graph holds it while capturing, _codec while issuing.  The lock is one-directional on purpose:
+        # the codec engines (codec.py) never capture -- their tapes are launched record by record -- so the only captures on the front
+        # lane's stream are the front worker's own loop plans, taken by the thread that also issues everything else on that stream.
         self._capture_lock = threading.Lock()
         for w in self.workers:
             w.view._capture_lock = self._capture_lock

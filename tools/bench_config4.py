@@ -61,19 +61,25 @@ gram = vecs @ vecs.transpose(1, 2)
 eye = torch.eye(a.n_evs)
 last_corr = torch.stack([c[-1].abs().cpu() for c in ck["in_corrs"]])               # |<v_it, v_it-1>| of the last iteration
 rel_move = ((out.cpu() - ck["final"].cpu()).flatten(1).norm(dim=1) / ck["final"].cpu().norm()).tolist()
+# the chain between timesteps (main_pc_extract_inv.py:204-212): the stored corrs are the per-index correlations of the STORED
+# (post-flip) consecutive PCs, and the sign rule left none of them at or below -corr_to_swap
+corrs = torch.stack([c.cpu() for c in ck["corrs"]]) if ck["corrs"] else None
+chain_err = float(((vecs[:-1] * vecs[1:]).sum(-1) - corrs).abs().max()) if corrs is not None else None
 checks = dict(
     window_timesteps=n_win, finite=bool(torch.isfinite(vals).all() and torch.isfinite(vecs).all() and torch.isfinite(out).all()),
     eigenvalues_positive=bool((vals > 0).all()), eigenvalues_descending=bool((vals[:, :-1] >= vals[:, 1:] * (1 - 1e-4)).all()),
     eigval_first_last=[float(vals[0, 0]), float(vals[-1, 0])],
     orthonormality_max_err=float((gram - eye).abs().max()),
     last_iteration_cosine_min=float(last_corr.min()), last_iteration_cosine_median=float(last_corr.median()),
-    sign_continuity_min_corr=float(torch.stack([c.cpu() for c in ck["corrs"]]).min()) if ck["corrs"] else None,
+    sign_continuity_min_corr=float(corrs.min()) if corrs is not None else None,
+    stored_corrs_vs_stored_pcs_max_err=chain_err,
+    sign_rule_holds=bool((corrs > -getattr(a, "corr_to_swap", 0.8)).all()) if corrs is not None else None,
     drift_moves_sample_rel_l2=rel_move)
 # pass = the size-independent invariants.  Ordering / convergence of the returned eigenvalues are REPORTED only: the values
 # come from the last iteration before its sort (pc_drift.py:146-171, as in the reference), and seeded-random weights have
 # no dominant Jacobian directions for 50 power iterations to converge to.
 ok = (checks["finite"] and checks["eigenvalues_positive"] and checks["orthonormality_max_err"] < 1e-3
-      and min(rel_move) > 1e-4)
+      and min(rel_move) > 1e-4 and (chain_err is None or (chain_err < 1e-3 and checks["sign_rule_holds"])))
 print(json.dumps(dict(
     metric="seconds per PC extract + apply run (config 4)", value=t_ext + t_app, unit="s", higher_is_better=False,
     seconds=dict(extract=t_ext, apply=t_app), unet_sample_forwards=fwd, unet_sample_forwards_per_s=fwd / (t_ext + t_app),

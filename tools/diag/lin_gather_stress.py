@@ -4,7 +4,18 @@ One AED_OP_CONV_GEMM record on a 128-CU masked stream is launched R times into R
 on an unmasked stream (its workgroups land on the same CUs); every output is compared with the solo launch.  Census over tile
 codes 10..19, gather / uniform loader, shapes of the U-Net's latency regime; stressors with and without MFMA / LDS.
 
-    python tools/diag/lin_gather_stress.py [cases=head|census] [stress=x6,f32,copy,none] [R=60] [lib=path/to/libaed_variant.so]
+    python tools/diag/lin_gather_stress.py [cases=head|one|census] [stress=x6,f32,copy,none] [R=60] [lib=path/to/libaed_variant.so] [dump=1|2]
+
+`lib=`: a variant of the library, e.g. the round-5 form of the gather loader, to see that the harness still bites (about half of all
+launches of tiles 11 / 15 perturbed under the x6 stressor; the shipped kernel: none):
+
+    cd audioeditingcode_amd/csrc && bash build.sh && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DLIN_GATHER_R5_FORM -c lin_gemm.hip \
+        -o ../../scratch/lin_r5.o && hipcc --offload-arch=gfx950 -shared -fPIC $(ls obj/*.o | grep -v lin_gemm) ../../scratch/lin_r5.o \
+        -o ../../scratch/libaed_r5form.so
+    python tools/diag/lin_gather_stress.py cases=one stress=x6 R=200 lib=scratch/libaed_r5form.so
+
+(`dump=1|2` belong to instrumented builds of round 6 -- per-thread partial tiles / per-lane loader checksums -- whose kernel hooks were
+removed again; profiles/r06_lin_gather_hazard.md says what they showed.)
 """
 import os
 import sys

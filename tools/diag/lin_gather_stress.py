@@ -74,6 +74,101 @@ def make_case(name, B, IH, IW, Cin, N, k, stride, tile, R, gen, in_act=0):
     return dict(name=name, tape=tp, outs=outs, x=x, w=w, M=B * OH * OW, N=N, K=k * k * Cin, tile=tile, R=R, dbg=dbg)
 
 
+def make_victim(kind, R, gen):
+    """R + 1 records of another kernel family, each with its own output: do THEY depend on co-resident workgroups?  (Round 6 found the
+    defect in lin_gemm's gather loader only; this is the census over everything else an edit lane runs.)"""
+    tp = Tape(DEV)
+    fam, *arg = kind
+    if fam == "conv":                       # LDS-staged GEMM: (arith, tile code, k)
+        arith, tile, k = arg
+        B, IH, IW, Cin, N = 2, 128, 8, 256, 256
+        if tile in (8, 9):                  # the 512-thread split-bf16 tiles are the launcher's own pick at throughput shapes
+            B, N, tile = 32, (256 if tile == 8 else 768), 0
+        x = torch.randn(B, IH, IW, Cin, generator=gen, device=DEV)
+        w = torch.randn(N, k * k * Cin, generator=gen, device=DEV) / (k * k * Cin) ** 0.5
+        b = torch.randn(N, generator=gen, device=DEV)
+        outs = torch.zeros(R + 1, B, IH, IW, N, device=DEV)
+        with tape_mod.arith_mode(arith):
+            for r in range(R + 1):
+                tp.conv(x, w, b, outs[r], B=B, IH=IH, IW=IW, Cin=Cin, OH=IH, OW=IW, N=N, KH=k, KW=k, pad_h=k // 2, pad_w=k // 2,
+                        tile=tile, in_act=1 if k == 3 else 0, name="victim")
+    elif fam == "geglu":                    # FF1 + LayerNorm fold + GEGLU on the lin tiles that have it
+        (tile,) = arg
+        M, C = 2048, 256
+        x = torch.randn(M, C, generator=gen, device=DEV)
+        w = torch.randn(8 * C, C, generator=gen, device=DEV) / C ** 0.5
+        b = torch.randn(8 * C, generator=gen, device=DEV)
+        rs = w.sum(1).contiguous()
+        outs = torch.zeros(R + 1, M, 4 * C, device=DEV)
+        with tape_mod.arith_mode("f32"):
+            for r in range(R + 1):
+                tp.linear(x, w, b, outs[r], M=M, K=C, N=8 * C, ln_rowsum=rs, geglu=1, tile=tile, name="victim")
+    elif fam == "attn":                     # (variant, Nk, D)
+        variant, Nk, D = arg
+        B, H, Nq = 2, 8, 1024
+        C = H * D
+        q = torch.randn(B, Nq, C, generator=gen, device=DEV)
+        kk = torch.randn(B, Nk, C, generator=gen, device=DEV)
+        v = torch.randn(B, Nk, C, generator=gen, device=DEV)
+        outs = torch.zeros(R + 1, B, Nq, C, device=DEV)
+        with tape_mod.arith_mode("bf16x6" if variant == 3 else "f32"):
+            for r in range(R + 1):
+                tp.attention(q, kk, v, outs[r], B=B, H=H, Nq=Nq, Nk=Nk, D=D, ldq=C, ldk=C, ldv=C, ldo=C, bsq=Nq * C, bsk=Nk * C,
+                             bsv=Nk * C, bso=Nq * C, scale=D ** -0.5, variant=variant)
+    elif fam == "gn":                       # (HW, C): the single-launch kernel for small maps, stats + apply for large ones
+        HW, C = arg
+        x = torch.randn(2, HW, 1, C, generator=gen, device=DEV)
+        ga, be = torch.randn(C, generator=gen, device=DEV), torch.randn(C, generator=gen, device=DEV)
+        outs = torch.zeros(R + 1, 2, HW, 1, C, device=DEV)
+        for r in range(R + 1):
+            tp.groupnorm(x, ga, be, outs[r], B=2, HW=HW, C=C, G=32, eps=1e-5, act=1)
+    else:
+        raise ValueError(kind)
+    tp.finalize()
+    per = len(tp.ops) // (R + 1)
+    return dict(name=str(kind), tape=tp, outs=outs, per=per)
+
+
+VICTIMS = ([("conv", a, t, k) for a in ("bf16x6", "f32") for t in (1, 2, 3, 4) for k in (3, 1)] +
+           [("conv", "bf16x6", 8, 3), ("conv", "bf16x6", 9, 1)] +
+           [("geglu", t) for t in (13, 14, 15, 17)] +
+           [("attn", 0, 1024, 32), ("attn", 1, 1024, 32), ("attn", 3, 1024, 32), ("attn", 3, 1024, 64), ("attn", 0, 16, 32)] +
+           [("gn", 1024, 256), ("gn", 4096, 128), ("gn", 64, 1280)])
+
+
+def run_victims(R, lane, side, gen):
+    stress = make_stressor("x6", gen)
+    clean = 0
+    for kind in VICTIMS:
+        try:
+            c = make_victim(kind, R, gen)
+        except Exception as e:                                          # noqa: BLE001
+            print(f"victim {kind}: not built ({e!r})", flush=True)
+            continue
+        tp, outs, per = c["tape"], c["outs"], c["per"]
+        try:
+            with torch.cuda.stream(lane.stream):
+                tp.run(0, per)
+            torch.cuda.synchronize()
+            with torch.cuda.stream(side.stream):
+                for _ in range(max(1, R // 8)):
+                    stress.run()
+            with torch.cuda.stream(lane.stream):
+                tp.run(per, per * (R + 1))
+            torch.cuda.synchronize()
+        except Exception as e:                                          # noqa: BLE001
+            print(f"victim {c['name']}: not launched ({e!r})", flush=True)
+            continue
+        bad = [r for r in range(1, R + 1) if not torch.equal(outs[r], outs[0])]
+        clean += not bad
+        kernels = sorted({int(op.i[29]) for op in tp.ops if op.code == 1})
+        print(f"victim {c['name']}: {per} launch(es) per record, conv tiles {kernels}; perturbed records {len(bad)} of {R}"
+              + (f"; first: max |d| {float((outs[bad[0]] - outs[0]).abs().max()):.3g}" if bad else ""), flush=True)
+        del c, tp, outs
+        torch.cuda.empty_cache()
+    print(f"victims clean: {clean} of {len(VICTIMS)}", flush=True)
+
+
 def make_stressor(kind, gen):
     tp = Tape(DEV)
     if kind == "none":
@@ -108,6 +203,9 @@ def main():
     gen.manual_seed(0)
     lane = PartitionStream.acquire(DEV, cus=range(0, 128), total=256, index=0)
     side = PartitionStream.acquire(DEV, index=17)
+    if o["cases"] == "victims":
+        print(f"lib={L.LIB_PATH}", flush=True)
+        return run_victims(R, lane, side, gen)
     if o["cases"] == "head":
         specs = [("downsampler 3x3 s2 (M=1024,K=1152)", 1, 256, 16, 128, 128, 3, 2, t) for t in (11, 17, 10, 12)]
         specs += [("resnet conv1 3x3 (M=1024,K=1152->256)", 1, 128, 8, 128, 256, 3, 1, t) for t in (11, 17)]

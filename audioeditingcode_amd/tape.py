@@ -65,6 +65,15 @@ for _reg, _mod in ((None, "tile_table_x6"), ("cus128", "tile_table_x6_cus128"), 
         X6_TABLES[_reg] = dict(__import__(f"{__package__}.{_mod}", fromlist=["TILE_TABLE"]).TILE_TABLE)
     except ImportError:
         pass
+# Round 6: the BATCH-1 shapes of the edit lanes -- the CFG-shared head of the batch-2 edit engine (unet.UNetEngine share=2) runs at
+# batch 1 (M = 4096 / 1024 rows); without entries those shapes took the rule's fp32 lin tiles at twice the time of the swept
+# split-bf16 tiles (profiles/r06_sweeps/).  A shape that also occurs at batch 2 keeps the entry of the table it was first swept for.
+for _reg, _mod in (("cus128", "tile_table_x6_cus128_b1"), ("cus64", "tile_table_x6_cus64_b1")):
+    try:
+        for _k, _v in __import__(f"{__package__}.{_mod}", fromlist=["TILE_TABLE"]).TILE_TABLE.items():
+            X6_TABLES.setdefault(_reg, {}).setdefault(_k, _v)
+    except ImportError:
+        pass
 REGIME_CUS = {"cus128": 128, "cus64": 64}       # CUs of the stream a regime's engines run on
 _regime = threading.local()
 

@@ -512,7 +512,7 @@ int cg_fill_params(const aed_op* op, CGParams& p, int bkt) {
     p.ln_mode = i[31]; p.ln_eps = op->f[3];
     p.C1 = i[32]; p.lda2 = i[33]; p.a_bs2 = i[34]; p.geglu = i[35];
     p.A2 = (const float*)op->p[8];
-    p.stats = nullptr;
+    p.gm = 0;
     p.Wq = nullptr;
     p.Wsc = nullptr;
     p.sm_group = i[36]; p.w_bs = i[37]; p.vec_ld = i[38] > 0 ? i[38] : 1; p.vec_bs = i[39];

@@ -110,8 +110,17 @@ __global__ __launch_bounds__(64 * WROWS * WCOLS, 2) void conv_gemm_x6_kernel(CGP
         const unsigned orig = blockIdx.y * nx + blockIdx.x;
         const unsigned xcd = orig & 7u, q = nwg >> 3, r = nwg & 7u;
         const unsigned id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-        tile_y = (int)(id / nx);
-        tile_x = (int)(id - (unsigned)tile_y * nx);
+        if (p.gm > 1) {     // grouped order: p.gm row panels per group, m fastest inside a group (bijective for any grid)
+            const unsigned per_group = (unsigned)p.gm * nx;
+            const unsigned g = id / per_group, first = g * (unsigned)p.gm;
+            const unsigned gsz = min((unsigned)p.gm, gridDim.y - first);
+            const unsigned within = id - g * per_group;
+            tile_x = (int)(within / gsz);
+            tile_y = (int)(first + (within - (unsigned)tile_x * gsz));
+        } else {
+            tile_y = (int)(id / nx);
+            tile_x = (int)(id - (unsigned)tile_y * nx);
+        }
     }
     const int m0 = tile_y * BM;
     const int n0 = tile_x * BN;
@@ -542,6 +551,21 @@ int launch_conv_gemm_x6(const aed_op* op, hipStream_t s) {
         else if (blocks(128, 128) >= (long)cus && p.N >= 128) cfg = 1;
         else if (blocks(128, 64) >= 2L * cus) cfg = 2;
         else cfg = 4;
+    }
+    // Tile order (round 6).  The workgroups that run together on one XCD (its CUs x workgroups per CU) should touch as few
+    // distinct operand bytes as possible: g row panels x (resident / g) column tiles with g ~ sqrt(resident * BN / BM).  With n
+    // fastest (rounds 1-5) they covered ~1 panel x every column tile, and a wide Linear's W (FF1 at level 3: 13 MB against 4 MB of
+    // L2) was streamed again for every row panel.  Flag bit 10 (1024) keeps the old order (A/B).
+    if (!(op->flags & 1024) && p.ksplit <= 1) {
+        static const int BMs[10] = {0, 128, 128, 64, 64, 0, 0, 0, 256, 128}, BNs[10] = {0, 128, 64, 128, 64, 0, 0, 0, 128, 256};
+        const int nx = aed_cdiv(p.N, BNs[cfg]), ny = aed_cdiv(p.M, BMs[cfg]);
+        const int resident = (aed_num_cus() / 8) * ((cfg == 8 || cfg == 9) ? 1 : 2);
+        if (nx > 1 && ny > 1) {
+            int g = 1;
+            while (g * 2 <= ny && (long)(g * 2) * (g * 2) * BMs[cfg] <= (long)resident * BNs[cfg]) g *= 2;
+            if (resident / g < nx) p.gm = g;        // (n fastest already keeps every column tile of few panels together otherwise)
+            if (op->flags & 0x3800) p.gm = 1 << ((op->flags >> 11) & 7);       // flag bits 11-13: forced group height (sweeps)
+        }
     }
     const bool plain = p.in_act == 0 && p.ln_mode == 0;
     const int sched = (op->flags & 8) ? 1 : 0;

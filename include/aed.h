@@ -49,6 +49,9 @@ enum aed_opcode {
                                  bit 4: with bit 2, three-term DIAGNOSTIC arithmetic (~4e-6 rel error);
                                  bit 8 (256): with bit 2 on the 512-thread tiles 8 / 9, 32-wide K chunks -- two bf16 MFMA k-blocks
                                  per LDS stage and barrier (needs 32 | Cin; other records ignore it);
+                                 bit 10 (1024): with bit 2, keep the n-fastest tile order of rounds 1-5 (A/B; default since round 6:
+                                 groups of row panels, m fastest inside a group -- csrc/conv_gemm_x6.hip); bits 11-13: forced
+                                 group height 2^v (sweeps);
                                  bit 6 (EXPERIMENT, tapes built under tape.arith_mode("fp8")): contract on the MX-FP8 matrix
                                  cores (csrc/conv_gemm_f8.hip: OCP microscaling e4m3, one e8m0 scale per 32 k of a row,
                                  quantised in the loader, v_mfma_scale_f32_32x32x64_f8f6f4, fp32 accumulate).  NOT a parity

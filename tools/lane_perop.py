@@ -2,7 +2,7 @@
 edit lanes build it (tile regime of the lane size, split-bf16 arithmetic) on a CU-masked stream, summed per op category and
 U-Net level.
 
-    PYTHONPATH=. python tools/lane_perop.py [cus=64] > gpurun_out/lane_perop_cus64.json"""
+    PYTHONPATH=. python tools/lane_perop.py [cus=64] [arith] [share=2] > gpurun_out/lane_perop_cus64.json"""
 import collections
 import json
 import re
@@ -16,6 +16,9 @@ from audioeditingcode_amd.unet import PackedUNetWeights, UNetEngine
 
 CUS = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 ARITH = sys.argv[2] if len(sys.argv) > 2 else "bf16x6"
+FUSE = next((int(a.split("=")[1]) for a in sys.argv[3:] if a.startswith("fuse=")), 1)       # 0: split-K with reduce launches (A/B)
+tape_mod.FUSE_SPLITK = FUSE
+SHARE = next((int(a.split("=")[1]) for a in sys.argv[3:] if a.startswith("share=")), 1)     # 2: the edit loop's CFG-shared head
 fam = configs.FAMILIES["audioldm2"]
 sd = weights.random_state_dict(weights.unet_param_shapes(fam["unet"]), seed=0)
 pw = PackedUNetWeights(sd, "cuda:0")
@@ -23,7 +26,7 @@ regime = {64: "cus64", 128: "cus128"}.get(CUS)
 ps = PartitionStream.acquire("cuda:0", cus=None if CUS >= 256 else range(CUS))
 B = 2
 with tape_mod.tile_regime(regime), tape_mod.arith_mode(ARITH):
-    eng = UNetEngine(fam["unet"], pw, "cuda:0", B, 256, 16, ctx_len0=8, ctx_len1=16)
+    eng = UNetEngine(fam["unet"], pw, "cuda:0", B, 256, 16, ctx_len0=8, ctx_len1=16, share=SHARE)
 g = torch.Generator().manual_seed(1)
 eng.set_conditioning(ehs0=torch.randn(B, 8, 768, generator=g), ehs1=torch.randn(B, 16, 1024, generator=g), bias1=torch.zeros(B, 16))
 eng.x_in.copy_(torch.randn(B, 256, 16, 8, generator=g))
@@ -75,7 +78,7 @@ for op, mt, t in zip(eng.tape.ops, eng.tape.meta, ms):
                      K=int(op.i[2]) if op.code == 1 else None, tile=int(op.i[29]) if op.code == 1 else None,
                      flags=int(op.flags), ms=round(t, 4)))
 tot = sum(ms)
-out = dict(cus=CUS, arith=ARITH, regime=regime, ops=len(ms), per_op_sum_ms=round(tot, 3), graph_replay_ms=round(graph_ms, 3),
+out = dict(cus=CUS, arith=ARITH, regime=regime, share=SHARE, fuse_splitk=FUSE, ops=len(ms), per_op_sum_ms=round(tot, 3), graph_replay_ms=round(graph_ms, 3),
            by_category=[dict(category=k[0], rows=k[1], launches=v[0], ms=round(v[1], 3), share=round(v[1] / tot, 4),
                              tflops=round(v[2] / (v[1] * 1e-3) / 1e12, 1) if v[1] else None)
                         for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])], rows=rows)

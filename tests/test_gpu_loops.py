@@ -11,6 +11,7 @@ from audioeditingcode_amd.scheduler import DDIMScheduler                  # noqa
 from oracle import loops as oloops                                        # noqa: E402
 from oracle import unet as ounet                                          # noqa: E402
 from oracle.scheduler import OracleDDIMScheduler                          # noqa: E402
+from conftest import oracle_run                                           # noqa: E402
 
 DEV = "cuda:0"
 H, W = 32, 16
@@ -56,8 +57,12 @@ def test_ddpm_inversion_and_edit_match_oracle(kind):
     fam, eng, ow, conds, to_c, x0 = _setup(kind, T)
     gen = torch.Generator().manual_seed(3)
     xts0 = ow.sample_xts_from_x0(x0, T, generator=gen)                      # CPU draws, reference order
-    _, zs_o, xts_o = oloops.invert(ow, x0, conds["src"], conds["unc"], [3.0], T, eta=1.0, xts=xts0.clone())
-    w_o = oloops.edit(ow, xts_o, torch.tensor([tstart]), conds["tgt"], conds["unc"], [12.0], zs_o[:tstart], eta=1.0)
+
+    def oracle():
+        _, zs_o, xts_o = oloops.invert(ow, x0, conds["src"], conds["unc"], [3.0], T, eta=1.0, xts=xts0.clone())
+        w_o = oloops.edit(ow, xts_o, torch.tensor([tstart]), conds["tgt"], conds["unc"], [12.0], zs_o[:tstart], eta=1.0)
+        return zs_o, xts_o, w_o
+    zs_o, xts_o, w_o = oracle_run(f"loops_ddpm_T20_{kind}", oracle, xts0)
 
     xts_in = xts0.unsqueeze(1)                                              # [T+1, n=1, C, H, W]
     zs, xts = eng.invert(x0, to_c(conds["src"]), to_c(conds["unc"]), [3.0], eta=1.0, xts=xts_in)
@@ -123,8 +128,10 @@ def test_empty_source_prompt_skips_cond_pass():
 def test_ddim_baseline_matches_oracle():
     T, skip = 10, 3
     fam, eng, ow, conds, to_c, x0 = _setup("audioldm2", T)
-    wT_o = oloops.ddim_invert(ow, x0, conds["src"], conds["unc"], 3.0, T, skip)
-    we_o = oloops.ddim_sample(ow, wT_o, conds["tgt"], conds["unc"], 12.0, skip=skip)
+    def oracle():
+        wT_o = oloops.ddim_invert(ow, x0, conds["src"], conds["unc"], 3.0, T, skip)
+        return wT_o, oloops.ddim_sample(ow, wT_o, conds["tgt"], conds["unc"], 12.0, skip=skip)
+    wT_o, we_o = oracle_run("loops_ddim_T10", oracle, x0)
     wT = eng.ddim_invert(x0, to_c(conds["src"]), to_c(conds["unc"]), 3.0, skip=skip)
     we = eng.ddim_sample(wT, to_c(conds["tgt"]), to_c(conds["unc"]), 12.0, skip=skip)
     torch.cuda.synchronize()

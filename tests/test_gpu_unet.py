@@ -7,11 +7,12 @@ pytestmark = pytest.mark.gpu
 from audioeditingcode_amd import configs, weights              # noqa: E402
 from audioeditingcode_amd.unet import UNetEngine                # noqa: E402
 from oracle import unet as ounet                                # noqa: E402
+from conftest import oracle_run                                 # noqa: E402
 
 DEV = "cuda:0"
 
 
-def _run_case(fam, B, H, W, L0, L1, t, seed=0, use_ehs=True, heads=None, want_folded=0):
+def _run_case(fam, B, H, W, L0, L1, t, seed=0, use_ehs=True, heads=None, want_folded=0, oracle_key=None):
     cfg = fam["unet"]
     if heads is not None:
         cfg["attention_head_dim"] = heads
@@ -45,7 +46,9 @@ def _run_case(fam, B, H, W, L0, L1, t, seed=0, use_ehs=True, heads=None, want_fo
     assert sum(1 for o in eng.tape.ops if o.code == 1 and o.i[36] > 0) >= want_folded
     got = eng.eps.cpu().permute(0, 3, 1, 2)
     hs = eng.h_space.cpu().permute(0, 3, 1, 2)
-    ref, ref_h, _ = ounet.unet_forward(cfg, sd, x, torch.tensor(t), **okw)
+    oracle = lambda: ounet.unet_forward(cfg, sd, x, torch.tensor(t), **okw)[:2]                  # noqa: E731
+    # (oracle_key: the CPU forward of a full-size model is a committed oracle run, tests/conftest.py oracle_run)
+    ref, ref_h = oracle_run(oracle_key, oracle, x) if oracle_key else oracle()
     return got, ref, hs, ref_h, eng
 
 
@@ -80,7 +83,7 @@ def test_full_audioldm_s_unet_matches_oracle():
     """BASELINE config 1's model at its real size: AudioLDM-S U-Net (185 M parameters, CLAP FiLM conditioning through the
     concatenated class embedding, attn2 degenerating to self-attention), latent 8x256x16, cond+uncond batched."""
     fam = configs.get_family("cvssp/audioldm-s-full")
-    got, ref, hs, ref_h, eng = _run_case(fam, B=2, H=256, W=16, L0=0, L1=0, t=981, use_ehs=False)
+    got, ref, hs, ref_h, eng = _run_case(fam, B=2, H=256, W=16, L0=0, L1=0, t=981, use_ehs=False, oracle_key="unet_full_audioldm_s")
     rel = ((got - ref).norm() / ref.norm()).item()
     assert rel < 1e-4, rel
     assert ((hs - ref_h).norm() / ref_h.norm()).item() < 1e-4
@@ -93,7 +96,7 @@ def test_full_tango_unet_matches_oracle():
     block widths 320 / 640 / 1280 / 1280, linear projections, 64-wide heads, T5 cross-attention with the additive -10000
     key mask, self-attention over all 4096 latent tokens at level 0), latent 8x256x16, cond+uncond batched."""
     fam = configs.FAMILIES["tango"]
-    got, ref, hs, ref_h, eng = _run_case(fam, B=2, H=256, W=16, L0=16, L1=0, t=501)
+    got, ref, hs, ref_h, eng = _run_case(fam, B=2, H=256, W=16, L0=16, L1=0, t=501, oracle_key="unet_full_tango")
     rel = ((got - ref).norm() / ref.norm()).item()
     assert rel < 1e-4, rel
     assert ((hs - ref_h).norm() / ref_h.norm()).item() < 1e-4

@@ -16,6 +16,7 @@ struct CGParams {
     float* ws;
     long long* dbg;          // optional in-kernel timeline (block 0, lane 0): s_memtime stamps
     const float* A2;         // second A source (channels [C1, Cin) of every tap): the skip half of an up-block concat
+    int diag;                // A/B switches of conv_gemm_x6 (op flag bit 15 = 0x8000 -> bit 0: always the general epilogue)
     int gm;                  // tile order of conv_gemm_x6 (round 6): <= 1 = n fastest inside an XCD's range of tile ids; g > 1 = groups
                              // of g row panels, m fastest inside a group -- the workgroups that run together on an XCD then cover
                              // g A panels x (resident / g) W tiles instead of ~1 panel x ALL W tiles (wide Linears: W larger

@@ -347,6 +347,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 1) void conv_gemm
                     const float bv = p.bias ? p.bias[nv] : 0.f, bg = p.bias ? p.bias[ng] : 0.f;
                     const float sv = p.ln_mode ? p.rowvec[nv] : 0.f, sg = p.ln_mode ? p.rowvec[ng] : 0.f;
                     const int nf = ((n0 + wc * WN + b * 32) >> 1) + fi;      // output feature column
+                    const int gmb = min(mbase, p.M - 1), gb0 = gmb / p.rpb, gq0 = gmb - gb0 * p.rpb;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int dm = (r & 3) + 8 * (r >> 2);
@@ -361,8 +362,17 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 1) void conv_gemm
                         val += bv;
                         gate += bg;
                         if (m < p.M) {
-                            const int bb = m / p.rpb;
-                            const unsigned row = (unsigned)bb * (unsigned)p.out_bs + (unsigned)(m - bb * p.rpb);
+                            int bb, q;                      // (no division per element: see conv_gemm_x6.hip)
+                            if (p.rpb >= 32) {
+                                q = gq0 + dm;
+                                const bool wrap = q >= p.rpb;
+                                bb = wrap ? gb0 + 1 : gb0;
+                                q = wrap ? q - p.rpb : q;
+                            } else {
+                                bb = m / p.rpb;
+                                q = m - bb * p.rpb;
+                            }
+                            const unsigned row = (unsigned)bb * (unsigned)p.out_bs + (unsigned)q;
                             p.C[row * (unsigned)p.ldc + nf] = val * glu_gate(gate, p.geglu);
                         }
                     }
@@ -513,6 +523,7 @@ int cg_fill_params(const aed_op* op, CGParams& p, int bkt) {
     p.C1 = i[32]; p.lda2 = i[33]; p.a_bs2 = i[34]; p.geglu = i[35];
     p.A2 = (const float*)op->p[8];
     p.gm = 0;
+    p.diag = (op->flags & 0x8000) ? 1 : 0;
     p.Wq = nullptr;
     p.Wsc = nullptr;
     p.sm_group = i[36]; p.w_bs = i[37]; p.vec_ld = i[38] > 0 ? i[38] : 1; p.vec_bs = i[39];

@@ -98,22 +98,23 @@ __global__ __launch_bounds__(64 * WROWS * WCOLS, 2) void conv_gemm_x6_kernel(CGP
     static_assert(BM % RPP == 0 && BN % RPP == 0, "loader passes");
 
     __shared__ uint4 lds[2 * STAGE];
+    const unsigned nx = gridDim.x, ny = gridDim.y, bz = blockIdx.z, gz = gridDim.z;
+    const unsigned orig = blockIdx.y * nx + blockIdx.x;     // linear workgroup id in launch order (consecutive ids -> consecutive XCDs)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wr = wave / WCOLS, wc = wave % WCOLS;
     // XCD-aware tile order (see conv_gemm.hip): XCD x gets a contiguous range of tile ids, n fastest
-    int tile_x = blockIdx.x, tile_y = blockIdx.y;
-    if (gridDim.z == 1) {
-        const unsigned nx = gridDim.x, nwg = nx * gridDim.y;
-        const unsigned orig = blockIdx.y * nx + blockIdx.x;
+    int tile_y = (int)(orig / nx), tile_x = (int)(orig - (unsigned)tile_y * nx);
+    if (gz == 1) {
+        const unsigned nwg = nx * ny;
         const unsigned xcd = orig & 7u, q = nwg >> 3, r = nwg & 7u;
         const unsigned id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
         if (p.gm > 1) {     // grouped order: p.gm row panels per group, m fastest inside a group (bijective for any grid)
             const unsigned per_group = (unsigned)p.gm * nx;
             const unsigned g = id / per_group, first = g * (unsigned)p.gm;
-            const unsigned gsz = min((unsigned)p.gm, gridDim.y - first);
+            const unsigned gsz = min((unsigned)p.gm, ny - first);
             const unsigned within = id - g * per_group;
             tile_x = (int)(within / gsz);
             tile_y = (int)(first + (within - (unsigned)tile_x * gsz));
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(64 * WROWS * WCOLS, 2) void conv_gemm_x6_kernel(CGP
     int kc_begin = 0, kc_end = p.nchunks;
     if (p.ksplit > 1) {
         const int per = (p.nchunks + p.ksplit - 1) / p.ksplit;
-        kc_begin = blockIdx.z * per;
+        kc_begin = (int)bz * per;
         kc_end = min(p.nchunks, kc_begin + per);
     }
 
@@ -382,6 +383,7 @@ __global__ __launch_bounds__(64 * WROWS * WCOLS, 2) void conv_gemm_x6_kernel(CGP
                     const float bv = p.bias ? p.bias[nv] : 0.f, bg = p.bias ? p.bias[ng] : 0.f;
                     const float sv = p.ln_mode ? p.rowvec[nv] : 0.f, sg = p.ln_mode ? p.rowvec[ng] : 0.f;
                     const int nf = ((n0 + wc * WN + b * 32) >> 1) + fi;
+                    const int gmb = min(mbase, p.M - 1), gb0 = gmb / p.rpb, gq0 = gmb - gb0 * p.rpb;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int dm = (r & 3) + 8 * (r >> 2);
@@ -396,14 +398,87 @@ __global__ __launch_bounds__(64 * WROWS * WCOLS, 2) void conv_gemm_x6_kernel(CGP
                         val += bv;
                         gate += bg;
                         if (m < p.M) {
-                            const int bb = m / p.rpb;
-                            const unsigned row = (unsigned)bb * (unsigned)p.out_bs + (unsigned)(m - bb * p.rpb);
+                            // batch item of row m without a division per element (a run-time divisor is ~40 VALU instructions:
+                            // 32 of them per lane made this epilogue 5 us longer per 128x256 tile than the plain one -- round 6,
+                            // profiles/r06_short_k.md): at most one batch-item wrap inside a 32-row tile when rpb >= 32
+                            int bb, q;
+                            if (p.rpb >= 32) {
+                                q = gq0 + dm;
+                                const bool wrap = q >= p.rpb;
+                                bb = wrap ? gb0 + 1 : gb0;
+                                q = wrap ? q - p.rpb : q;
+                            } else {
+                                bb = m / p.rpb;
+                                q = m - bb * p.rpb;
+                            }
+                            const unsigned row = (unsigned)bb * (unsigned)p.out_bs + (unsigned)q;
                             p.C[row * (unsigned)p.ldc + nf] = val * glu_gate(gate, p.geglu);
                         }
                     }
                 }
             return;
         }
+    }
+    // ---- simple rows (round 6): output row = m (every Linear and stride-1 convolution of the U-Net / DiT engines: no row scatter, no
+    // accumulate mode).  The general epilogue below spends ~30 instructions per output on row arithmetic that is the identity here;
+    // at the batch-200 forward's short-K Linears (K = 256 / 384: 16-24 chunks) that was a third of a tile's time
+    // (profiles/r06_short_k.md).  Same operations on the values, in the same order: bit-identical.
+    if (p.ksplit <= 1 && p.o_mul == 1 && p.o_add == 0 && p.out_bs == p.rpb && p.o_len == p.rpb && p.accumulate == 0 && !(p.diag & 1)) {
+        const bool has_rv = p.rowvec != nullptr && !p.ln_mode;
+        const int bmax = (p.M - 1) / p.rpb;
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                const int n = n0 + wc * WN + b * 32 + fi;
+                const int mbase = m0 + wr * WM + a * 32 + 4 * fh;
+                if (n >= p.N) continue;
+                const float bias_v = p.bias ? p.bias[n] : 0.f;
+                float val[16], rv[16];
+                if (p.res) {                // requested first: in flight while the values are finished
+                    const float* rp = p.res + n;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        rv[r] = rp[(unsigned)min(mbase + (r & 3) + 8 * (r >> 2), p.M - 1) * (unsigned)p.ldr];
+                }
+                if (p.ln_mode) {
+                    const float sn = p.rowvec[n];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int lr = wr * WM + a * 32 + 4 * fh + (r & 3) + 8 * (r >> 2);
+                        val[r] = ln_stat[2 * lr + 1] * (acc[a][b][r] - ln_stat[2 * lr] * sn) + bias_v;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) val[r] = acc[a][b][r] + bias_v;
+                }
+                if (has_rv) {               // per-batch-item row vector (the resnets' time-embedding row)
+                    const int mb = min(mbase, p.M - 1), b0 = mb / p.rpb, q0 = mb - b0 * p.rpb;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int dm = (r & 3) + 8 * (r >> 2);
+                        int bb;
+                        if (p.rpb >= 32) bb = (q0 + dm >= p.rpb) ? b0 + 1 : b0;
+                        else bb = min(mbase + dm, p.M - 1) / p.rpb;
+                        val[r] += p.rowvec[(unsigned)min(bb, bmax) * (unsigned)p.ld_rv + n];
+                    }
+                }
+                if (p.res) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) val[r] += rv[r];
+                }
+                if (p.out_act != AED_ACT_NONE) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) val[r] = aed_apply_act(val[r], p.out_act, p.out_p);
+                }
+                float* cp = p.C + n;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mbase + (r & 3) + 8 * (r >> 2);
+                    if (m < p.M) cp[(unsigned)m * (unsigned)p.ldc] = val[r];
+                }
+            }
+        return;
     }
 #pragma unroll
     for (int a = 0; a < TM; ++a)
@@ -413,7 +488,7 @@ __global__ __launch_bounds__(64 * WROWS * WCOLS, 2) void conv_gemm_x6_kernel(CGP
             const int mbase = m0 + wr * WM + a * 32 + 4 * fh;
             if (n >= p.N) continue;
             if (p.ksplit > 1) {
-                float* wsp = p.ws + ((size_t)blockIdx.z * p.M + mbase) * p.N + n;
+                float* wsp = p.ws + ((size_t)bz * p.M + mbase) * p.N + n;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int dm = (r & 3) + 8 * (r >> 2);
@@ -559,7 +634,7 @@ int launch_conv_gemm_x6(const aed_op* op, hipStream_t s) {
     if (!(op->flags & 1024) && p.ksplit <= 1) {
         static const int BMs[10] = {0, 128, 128, 64, 64, 0, 0, 0, 256, 128}, BNs[10] = {0, 128, 64, 128, 64, 0, 0, 0, 128, 256};
         const int nx = aed_cdiv(p.N, BNs[cfg]), ny = aed_cdiv(p.M, BMs[cfg]);
-        const int resident = (aed_num_cus() / 8) * ((cfg == 8 || cfg == 9) ? 1 : 2);
+        const int resident = ((aed_num_cus() >> ((op->flags >> 16) & 3)) / 8) * ((cfg == 8 || cfg == 9) ? 1 : 2);
         if (nx > 1 && ny > 1) {
             int g = 1;
             while (g * 2 <= ny && (long)(g * 2) * (g * 2) * BMs[cfg] <= (long)resident * BNs[cfg]) g *= 2;

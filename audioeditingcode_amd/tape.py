@@ -339,6 +339,10 @@ class Tape:
             # wide chunks (two bf16 k-blocks per LDS stage and barrier; csrc/conv_gemm_x6.hip, flag bit 8): +3-4 % on the long-K
             # 3x3 convolutions at the inversion's batch, nothing on the short-K Linears (profiles/r05_small_m.md section 4)
             flags |= 256
+        if flags & 4:
+            # the CU budget of the stream this engine runs on (a pipeline partition): sizes conv_gemm_x6's tile groups
+            lane_cus = REGIME_CUS.get(getattr(_regime, "name", None), CU_COUNT)
+            flags |= {1: 0, 2: 1, 4: 2, 8: 3}.get(max(1, CU_COUNT // max(lane_cus, 1)), 0) << 16
         idx = self._add(L.OP_CONV_GEMM, i, [in_slope, out_p, out_div, ln_eps, sm_scale],
                         [x, w, bias, out, res, rowvec, None, None, x2, kbias], name=name,
                         flops=2 * M * N * K if alg_flops is None else alg_flops, exec_flops=2 * M * N * K,

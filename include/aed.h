@@ -51,7 +51,9 @@ enum aed_opcode {
                                  per LDS stage and barrier (needs 32 | Cin; other records ignore it);
                                  bit 10 (1024): with bit 2, keep the n-fastest tile order of rounds 1-5 (A/B; default since round 6:
                                  groups of row panels, m fastest inside a group -- csrc/conv_gemm_x6.hip); bits 11-13: forced
-                                 group height 2^v (sweeps);
+                                 group height 2^v (sweeps); bit 15 (0x8000): always the general epilogue (A/B of the simple-rows epilogue);
+                                 bits 16-17: the stream this record runs on is masked to (all CUs) >> v compute units (sizes the
+                                 tile groups; tapes built under tape.tile_regime set it);
                                  bit 6 (EXPERIMENT, tapes built under tape.arith_mode("fp8")): contract on the MX-FP8 matrix
                                  cores (csrc/conv_gemm_f8.hip: OCP microscaling e4m3, one e8m0 scale per 32 k of a row,
                                  quantised in the loader, v_mfma_scale_f32_32x32x64_f8f6f4, fp32 accumulate).  NOT a parity

@@ -8,6 +8,8 @@
 //   audioeditingcode_amd/x6_bench 1 cases           -> only the feature matrix (rc 1 if a case fails)
 //   audioeditingcode_amd/x6_bench 4 replay <records> [cus=N] [x6only]   -> every GEMM record of a forward, both arithmetics
 //   audioeditingcode_amd/x6_bench 4 replay <records> [cus=N] order [gm=v] -> tile-order A/B of the split-bf16 records (round 6)
+//   audioeditingcode_amd/x6_bench 4 replay <records> [cus=N] ab=A:B       -> A/B of two flag sets (e.g. 16384:0 = one tile per
+//                                                      workgroup vs the persistent walk), outputs compared bit for bit
 //   audioeditingcode_amd/x6_bench 60 sweep <records> [cus=N] [x6] > sweep.json   -> tile sweep (tools/tile_sweep.py without
 //                                                      Python; the JSON feeds tools/tile_table_from_sweep.py)
 //   (records: PYTHONPATH=. python tools/dump_gemm_ops.py <unet batch> > file)
@@ -270,6 +272,7 @@ static bool read_records(const char* path, std::vector<Rec>& recs);
 static bool g_ab_korder = false;
 static bool g_ab_order = false;      // tile-order A/B (round 6): C0 = n-fastest order (flag 1024), C1 = the launcher's grouped order
 static int g_all_flags = 0;          // OR-ed into the flags of every split-bf16 launch of a replay (counter passes of one variant)
+static int g_ab_a = 1024, g_ab_b = 0;    // flags OR-ed into launch A (C0) / launch B (C1) of the `order` A/B ("ab=A:B")
 static int g_force_gm = 0;           // ... or a forced group height 2^v (flag bits 11-13)
 static int run_replay_records(const char* path, const std::vector<Rec>& recs, int iters, hipStream_t st, bool x6only);
 
@@ -364,8 +367,8 @@ static int run_replay_records(const char* path, const std::vector<Rec>& recs, in
         // grouped order (cg_params.h kgroup) -- same sums in another order, so rel_l2 ~ 1e-7 doubles as the correctness check
         if (g_ab_order) {
             if (!flagged) continue;
-            const float t0 = timed(r.flags | 1024, r.i[29], C0, &rc0);
-            const float t1 = timed(r.flags | (g_force_gm << 11), r.i[29], C1, &rc1);
+            const float t0 = timed(r.flags | g_all_flags | g_ab_a, r.i[29], C0, &rc0);
+            const float t1 = timed(r.flags | g_all_flags | g_ab_b | (g_force_gm << 11), r.i[29], C1, &rc1);
             HIPCHECK(hipMemsetAsync(d_acc, 0, 16, st)); HIPCHECK(hipMemsetAsync(d_max, 0, 4, st));
             hipLaunchKernelGGL(compare_kernel, dim3(1024), dim3(256), 0, st, C1, C0, c, d_acc, d_max);
             double acc2[2]; unsigned mx = 0;
@@ -373,7 +376,7 @@ static int run_replay_records(const char* path, const std::vector<Rec>& recs, in
             HIPCHECK(hipMemcpy(acc2, d_acc, 16, hipMemcpyDeviceToHost)); HIPCHECK(hipMemcpy(&mx, d_max, 4, hipMemcpyDeviceToHost));
             if (mx != 0 || rc0 || rc1) ++n_bad;         // another tile order: the same sums, bit for bit
             tot32 += t0; tot6 += t1; ++n_flagged; flops += 2.0 * r.i[0] * (double)r.i[1] * r.i[2];
-            printf("{\"op\": \"%s\", \"M\": %d, \"N\": %d, \"K\": %d, \"tile_x6\": %d, \"us_n_fastest\": %.1f, \"us_grouped\": %.1f, "
+            printf("{\"op\": \"%s\", \"M\": %d, \"N\": %d, \"K\": %d, \"tile_x6\": %d, \"us_a\": %.1f, \"us_b\": %.1f, "
                    "\"max_abs_diff_bits\": %u}\n", r.name.c_str(), r.i[0], r.i[1], r.i[2], r.i[29], t0 * 1e3, t1 * 1e3, mx);
             continue;
         }
@@ -383,7 +386,12 @@ static int run_replay_records(const char* path, const std::vector<Rec>& recs, in
         double rel = 0.0;
         if (flagged || (g_ab_korder && r.i[12] * r.i[13] > 1)) {
             ms1 = timed(flagged ? (r.flags | g_all_flags) : (r.flags & ~28), flagged ? r.i[29] : r.tile_f32, C1, &rc1);
-            if (x6only) { tot6 += ms1; tot32 += ms0; flops += 2.0 * r.i[0] * (double)r.i[1] * r.i[2]; ++n_flagged; continue; }
+            if (x6only) {
+                tot6 += ms1; tot32 += ms0; flops += 2.0 * r.i[0] * (double)r.i[1] * r.i[2]; ++n_flagged;
+                printf("{\"op\": \"%s\", \"M\": %d, \"N\": %d, \"K\": %d, \"tile_x6\": %d, \"us_x6\": %.1f}\n", r.name.c_str(), r.i[0], r.i[1],
+                       r.i[2], r.i[29], ms1 * 1e3);
+                continue;
+            }
             HIPCHECK(hipMemsetAsync(d_acc, 0, 16, st)); HIPCHECK(hipMemsetAsync(d_max, 0, 4, st));
             hipLaunchKernelGGL(compare_kernel, dim3(1024), dim3(256), 0, st, C1, C0, c, d_acc, d_max);
             double acc2[2];
@@ -570,6 +578,7 @@ int main(int argc, char** argv) {
             if (!strcmp(argv[k], "x6only")) x6only = true;
             if (!strcmp(argv[k], "korder")) g_ab_korder = true;
             if (!strcmp(argv[k], "order")) g_ab_order = true;
+            if (!strncmp(argv[k], "ab=", 3)) { g_ab_order = true; sscanf(argv[k] + 3, "%d:%d", &g_ab_a, &g_ab_b); }
             if (!strncmp(argv[k], "allflags=", 9)) g_all_flags = atoi(argv[k] + 9);
             if (!strncmp(argv[k], "gm=", 3)) g_force_gm = atoi(argv[k] + 3);      // v: group height 2^v
             if (!strcmp(argv[k], "x6")) with_x6 = true;
@@ -581,6 +590,7 @@ int main(int argc, char** argv) {
                 if (aed_stream_create_cu_mask(&h, words, 8, 0)) { fprintf(stderr, "%s\n", aed_last_error()); return 2; }
                 rs = (hipStream_t)h;
                 fprintf(stderr, "replay on a stream masked to CUs [0, %d)\n", n);
+                g_all_flags |= (n <= 32 ? 3 : n <= 64 ? 2 : n <= 128 ? 1 : 0) << 16;     // what tapes of that tile regime carry
             }
         }
         if (!strcmp(argv[2], "sweep")) return run_sweep(argv[3], iters, rs, with_x6);       // iters = launches per graph

@@ -145,10 +145,13 @@ __global__ __launch_bounds__(64 * WROWS * WCOLS, 2) void conv_gemm_x6_kernel(CGP
         const int m = m0 + lrow + RPP * q;
         avalid[q] = m < p.M;
         const int mm = avalid[q] ? m : 0;
-        const int b = mm / p.rpb;
-        const int r = mm - b * p.rpb;
-        const int oy = r / p.OW;
-        const int ox = r - oy * p.OW;
+        int b = 0, r = mm, oy = mm, ox = 0;
+        if (p.rpb != p.M || p.OW != 1) {        // (a Linear is one batch item of M x 1 pixels: no run-time divisions in its prologue)
+            b = mm / p.rpb;
+            r = mm - b * p.rpb;
+            oy = r / p.OW;
+            ox = r - oy * p.OW;
+        }
         ay0[q] = oy * p.stride - p.pad_h;
         ax0[q] = ox * p.stride - p.pad_w;
         abase[q] = (unsigned)b * (unsigned)p.a_bs + lcol;
@@ -167,7 +170,9 @@ __global__ __launch_bounds__(64 * WROWS * WCOLS, 2) void conv_gemm_x6_kernel(CGP
     // [group of p.kgroup channels][tap][chunk within the group] (cg_params.h): pf_cg = first channel of the group
     int pf_cg, pf_sub, pf_ty, pf_tx;
     const int gq = p.kgroup / BK;             // chunks per (group, tap)
-    {
+    if (kc_begin == 0) {
+        pf_cg = pf_sub = pf_ty = pf_tx = 0;
+    } else {
         const int per_group = p.KH * p.KW * gq;
         const int g = kc_begin / per_group;
         const int rem = kc_begin - g * per_group;

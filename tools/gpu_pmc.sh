@@ -14,4 +14,7 @@ done
 if [ "$AB" = "ab" ]; then
   AED_PMC_TAPMAJOR=1 timeout 300 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/${TAG}_tapmajor/f -o f --output-format csv -- python $R/tools/pmc_forward.py 200 > $R/gpurun_out/${TAG}_tapmajor_f.log 2>&1; echo "pmc tap-major f rc=$?"
 fi
+if [ "$AB" = "order" ]; then
+  AED_PMC_NFASTEST=1 timeout 300 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/${TAG}_nfastest/f -o f --output-format csv -- python $R/tools/pmc_forward.py 200 > $R/gpurun_out/${TAG}_nfastest_f.log 2>&1; echo "pmc n-fastest f rc=$?"
+fi
 cd $R; grep "forward done" gpurun_out/${TAG}_f.log

@@ -14,6 +14,7 @@ from audioeditingcode_amd.unet import PackedUNetWeights, UNetEngine
 # tap-major K traversal (op flag 32) instead of the grouped one, for the traffic A/B (cg_params.h kgroup)
 ARITH = os.environ.get("AED_PMC_ARITH", "bf16x6")
 TAPMAJOR = os.environ.get("AED_PMC_TAPMAJOR", "0") == "1"
+NFASTEST = os.environ.get("AED_PMC_NFASTEST", "0") == "1"      # round 6: the n-fastest tile order of rounds 1-5 (op flag 1024), traffic A/B
 
 fam = configs.FAMILIES["audioldm2"]
 sd = weights.random_state_dict(weights.unet_param_shapes(fam["unet"]), seed=0)
@@ -23,10 +24,10 @@ for B in [int(a) for a in sys.argv[1:]] or [40, 2]:
     with tape_mod.arith_mode(ARITH):
         # the inversion's engine computes the context-free head once per [uncond | prompt] row pair (round 5); the edit loop's does not
         eng = UNetEngine(fam["unet"], pw, "cuda:0", B, 256, 16, ctx_len0=8, ctx_len1=16, share=2 if B > 2 else 1)
-    if TAPMAJOR:
+    if TAPMAJOR or NFASTEST:
         for op in eng.tape.ops:
             if op.code == 1:
-                op.flags |= 32
+                op.flags |= (32 if TAPMAJOR else 0) | (1024 if NFASTEST else 0)
         eng.tape._arr = None
     eng.set_conditioning(ehs0=torch.randn(B, 8, 768, generator=g), ehs1=torch.randn(B, 16, 1024, generator=g),
                          bias1=torch.zeros(B, 16))

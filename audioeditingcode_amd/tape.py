@@ -27,6 +27,9 @@ ATTN_VARIANT = 0        # 0 auto (transposed-score kernel when Nk > 64), 1 force
 ATTN_X6 = 1             # 0: attention records stay on the fp32 kernels under arith_mode("bf16x6") as well (A/B)
 GN_VARIANT = 0          # 1: never use the register-resident single-launch GroupNorm
 GN_FORCE_SMALL = 0      # 1: always take the single-launch GroupNorm when it fits
+GN_APPLY_BLOCKS_PER_CU = 8   # gn_apply grid: blocks per CU over the whole batch.  2 until round 6: at the inversion's batch (200 items x 2
+#                              blocks) the kernel had ~1.5 blocks per CU in flight and ran at 3.5 of 8 TB/s; 8 -> 4.8-5.7 TB/s, bit-identical
+#                              (tools/gn_bench.py, profiles/r06_gn_grid.jsonl)
 LIN_MODE = 1            # 1: small contractions go to the latency-regime kernels of lin_gemm.hip
 LATE_EPILOGUE = 0       # 1: lin_gemm fetches the residual after its reduction (measured slower)
 WIDE_CHUNKS = 1         # 1: split-bf16 3x3 convolutions on the 512-thread tiles take 32-wide K chunks (flag bit 8); 0 = A/B
@@ -393,8 +396,8 @@ class Tape:
         # apply: fine slabs for parallelism (~2 blocks per CU)
         s_rpc = max(4, math.ceil(HW / 32))
         s_chunks = math.ceil(HW / s_rpc)
-        a_target = max(1, (2 * CU_COUNT) // max(1, B))
-        a_rpc = max(4, math.ceil(HW / a_target))
+        a_target = max(1, (GN_APPLY_BLOCKS_PER_CU * CU_COUNT) // max(1, B))
+        a_rpc = max(16, math.ceil(HW / a_target))       # (>= 16 rows per block: every block first re-reduces the batch item's partials)
         a_chunks = math.ceil(HW / a_rpc)
         part = self.alloc(B, s_chunks, G, 2)
         nb = 4 * B * HW * C

@@ -378,6 +378,7 @@ __global__ __launch_bounds__(64 * WROWS * WCOLS, 2) void conv_gemm_x6_kernel(CGP
     // ---- epilogue (the semantics of conv_gemm.hip's): acc[a][b][r] = C[row (r&3) + 8*(r>>2) + 4*fh][col fi] of a 32x32 tile
     if constexpr (TN % 2 == 0) {
         if (p.geglu) {          // W rows packed [32 value | 32 gate] per 32 output features
+            const bool rows_are_m = p.out_bs == p.rpb;      // (every FF1 of the engines: output row = m, as in the simple-rows epilogue)
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -388,36 +389,36 @@ __global__ __launch_bounds__(64 * WROWS * WCOLS, 2) void conv_gemm_x6_kernel(CGP
                     const float bv = p.bias ? p.bias[nv] : 0.f, bg = p.bias ? p.bias[ng] : 0.f;
                     const float sv = p.ln_mode ? p.rowvec[nv] : 0.f, sg = p.ln_mode ? p.rowvec[ng] : 0.f;
                     const int nf = ((n0 + wc * WN + b * 32) >> 1) + fi;
-                    const int gmb = min(mbase, p.M - 1), gb0 = gmb / p.rpb, gq0 = gmb - gb0 * p.rpb;
+                    float out[16];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int dm = (r & 3) + 8 * (r >> 2);
-                        const int m = mbase + dm;
                         float val = acc[a][b][r], gate = acc[a][b + 1][r];
                         if (p.ln_mode) {
-                            const int lr = wr * WM + a * 32 + 4 * fh + dm;
+                            const int lr = wr * WM + a * 32 + 4 * fh + (r & 3) + 8 * (r >> 2);
                             const float mean = ln_stat[2 * lr], rstd = ln_stat[2 * lr + 1];
                             val = rstd * (val - mean * sv);
                             gate = rstd * (gate - mean * sg);
                         }
                         val += bv;
                         gate += bg;
-                        if (m < p.M) {
-                            // batch item of row m without a division per element (a run-time divisor is ~40 VALU instructions:
-                            // 32 of them per lane made this epilogue 5 us longer per 128x256 tile than the plain one -- round 6,
-                            // profiles/r06_short_k.md): at most one batch-item wrap inside a 32-row tile when rpb >= 32
-                            int bb, q;
-                            if (p.rpb >= 32) {
-                                q = gq0 + dm;
-                                const bool wrap = q >= p.rpb;
-                                bb = wrap ? gb0 + 1 : gb0;
-                                q = wrap ? q - p.rpb : q;
-                            } else {
-                                bb = m / p.rpb;
-                                q = m - bb * p.rpb;
+                        out[r] = val * glu_gate(gate, p.geglu);
+                    }
+                    if (rows_are_m) {
+                        float* cp = p.C + nf;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int m = mbase + (r & 3) + 8 * (r >> 2);
+                            if (m < p.M) cp[(unsigned)m * (unsigned)p.ldc] = out[r];
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int m = mbase + (r & 3) + 8 * (r >> 2);
+                            if (m < p.M) {
+                                const int bb = m / p.rpb;
+                                const unsigned row = (unsigned)bb * (unsigned)p.out_bs + (unsigned)(m - bb * p.rpb);
+                                p.C[row * (unsigned)p.ldc + nf] = out[r];
                             }
-                            const unsigned row = (unsigned)bb * (unsigned)p.out_bs + (unsigned)q;
-                            p.C[row * (unsigned)p.ldc + nf] = val * glu_gate(gate, p.geglu);
                         }
                     }
                 }
